@@ -1,0 +1,380 @@
+// Device-resident best-first beam search: decode_sequence_beam + Node of seq2seq.py:1356-1608, for
+// all lines of a batch at once.  One 256-thread workgroup owns one line: its priority queue
+// (next_beam), its list of finished hypotheses (final_beam) and its trie of nodes live in HBM and
+// never visit the host.  Per search iteration the workgroup
+//   A  turns the step's output rows into child nodes (rejection candidate seq2seq.py:1457-1470,
+//      beam threshold :1472-1480, successive-reset feedback :1515-1520),
+//   B  merges them into the queue in `insort_left` order and caps it (:1529-1532),
+//   C  pops the next <= N hypotheses (:1399-1420), files finished ones, evaluates the stop
+//      conditions and builds the next step's input rows and parent indices.
+// Order of nodes = (pro_cost descending, creation order ascending): `insort_left` + `pop()` take,
+// among equal pro_cost, the node inserted first.
+#include "common.h"
+#include <math.h>
+
+namespace casv {
+
+constexpr int NEWMAX = 4096;      // N * (beam_width_in + 1) must not exceed this
+constexpr int ROWMAX = 256;       // N <= 256
+constexpr int VPL = 16;           // V <= 64 * VPL
+
+__device__ __forceinline__ bool before(double ka, int ia, double kb, int ib) {
+    if (ia == 0x7fffffff) return false;
+    if (ib == 0x7fffffff) return true;
+    return ka > kb || (ka == kb && ia < ib);
+}
+// candidate order inside one row: score descending, ties towards the higher index
+__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) {
+    return va > vb || (va == vb && ia > ib);
+}
+
+__global__ void beam_init_kernel(const BeamState s, const BeamParams p) {
+    const int line = blockIdx.x;
+    const int N = p.N, Vp = (s.V + 31) & ~31;
+    const long long nb = (long long)line * s.node_cap;
+    if (threadIdx.x == 0) {
+        s.n_parent[nb] = -1; s.n_chr[nb] = -1; s.n_prob[nb] = 0.f; s.n_cum[nb] = 0.0; s.n_len[nb] = 1;
+        s.n_exp[nb] = line * N; s.n_k[nb] = 0; s.n_rejpos[nb] = -1; s.n_pos[nb] = 0.0; s.n_is1[nb] = 0;
+        s.n_count[line] = 1;
+        s.q_n[line] = 0; s.q_n[s.B + line] = 0;      // [0..B) count, [B..2B) head offset
+        s.f_n[line] = 0; s.f_total[line] = 0;
+        s.nact[line] = 1; s.line_done[line] = 0; s.line_steps[line] = 0;
+        s.beam_node[line * N] = 0;
+        s.beam0_key[line] = 0.0;
+        if (line == 0) *s.active_lines = s.B;
+    }
+    for (int i = threadIdx.x; i < N; i += blockDim.x) s.prev[line * N + i] = line * N;
+    for (int i = threadIdx.x; i < N * Vp; i += blockDim.x) s.p_in[(long long)line * N * Vp + i] = 0.f;
+}
+void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(beam_init_kernel, dim3(s.B), dim3(256), 0, stream, s, p);
+}
+
+__global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const BeamParams p) {
+    __shared__ double s_key[NEWMAX];
+    __shared__ int s_id[NEWMAX];
+    __shared__ int r_count[ROWMAX], r_off[ROWMAX + 1], r_beampos[ROWMAX], r_rej[ROWMAX], r_srcpos[ROWMAX];
+    __shared__ int r_nan[ROWMAX], r_rejlate[ROWMAX];
+    __shared__ int sh_nnew, sh_npop, sh_nb, sh_done;
+    __shared__ int pop_id[64], pop_chr[64];
+
+    const int line = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int step = *s.step_ptr;
+    if (s.line_done[line]) return;
+    const int N = p.N, V = s.V, Vp = (V + 31) & ~31, T = s.T, R = s.R;
+    const int CMAX = p.width_in + 1;
+    const int nact = s.nact[line];
+    const long long nbase = (long long)line * s.node_cap;
+    if (tid == 0) s.line_steps[line] = step + 1;
+    if (step + 1 >= s.S) return;       // children of the last iteration are never popped (s2s:1398)
+
+    // ---------------- A1: per row, rejection overwrite + child count ----------------
+    for (int i = wave; i < nact; i += 4) {
+        const int r = line * N + i;
+        const long long exp = (long long)(step + 1) * R + r;
+        float* sc = const_cast<float*>(s.p_base) + exp * Vp;
+        const int node = s.beam_node[r];
+        const int plen = s.n_len[nbase + node];
+        const double ppos = s.n_pos[nbase + node];
+        const int pis1 = s.n_is1[nbase + node];
+        const double pos = s.apos[r];
+        double mis = 0.0;
+        int srcpos = 0;
+        if (plen > 1) {
+            mis = fabs(pos - ppos - 1.0);
+            if (pis1) srcpos = (int)ppos + 1;
+            else srcpos = (pos == pos && fabs(pos) < 1e9) ? (int)rint(pos) : -1;
+        }
+        int rej = -1;
+        if (p.rejection != 0.0 && (mis < 0.1 || pis1) && srcpos >= 0 && srcpos < T)
+            rej = s.src_rej[line * T + srcpos];           // -1: input row all zero (np.any false)
+        float vals[VPL];
+        bool anynan = false;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int v = lane + 64 * k;
+            vals[k] = v < V ? sc[v] : -INFINITY;
+            if (v < V && vals[k] != vals[k]) anynan = true;
+        }
+        anynan = __any(anynan);
+        if (rej >= 0) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const int v = lane + 64 * k;
+                if (v == rej && (double)vals[k] < p.rejection) { vals[k] = (float)p.rejection; sc[v] = vals[k]; }
+            }
+        }
+        float hi = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) hi = fmaxf(hi, vals[k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        const double thr = (double)hi * p.threshold_in;
+        float v0 = __shfl(vals[0], 0, 64);                  // score of index 0
+        float vr = 0.f;
+        if (rej >= 0) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) if (lane + 64 * k == rej) vr = vals[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vr = fmaxf(vr, __shfl_xor(vr, o, 64));   // scores are >= 0
+        }
+        int cnt = 0, rank0 = 0, rankr = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int v = lane + 64 * k;
+            if (v < V) {
+                cnt += ((double)vals[k] >= thr) ? 1 : 0;
+                rank0 += better(vals[k], v, v0, 0) ? 1 : 0;
+                if (rej >= 0) rankr += better(vals[k], v, vr, rej) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_xor(cnt, o, 64); rank0 += __shfl_xor(rank0, o, 64); rankr += __shfl_xor(rankr, o, 64);
+        }
+        rank0 += 1; rankr += 1;
+        const int beampos = cnt < p.width_in ? cnt : p.width_in;
+        int count = beampos - (rank0 <= beampos ? 1 : 0);          // '' never becomes a node (s2s:1505)
+        const int rejlate = (rej > 0 && rankr > beampos) ? 1 : 0;  // `if rej_idx:` is false for 0 (s2s:1498)
+        count += rejlate;
+        if (anynan) count = 0;
+        if (lane == 0) {
+            r_count[i] = count; r_beampos[i] = beampos; r_rej[i] = rej; r_srcpos[i] = srcpos;
+            r_nan[i] = anynan ? 1 : 0; r_rejlate[i] = rejlate;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0;
+        for (int i = 0; i < nact; ++i) { r_off[i] = o; o += r_count[i]; }
+        r_off[nact] = o;
+        sh_nnew = o;
+    }
+    __syncthreads();
+    const int nnew = sh_nnew;
+    const int id0 = s.n_count[line];
+
+    // ---------------- A2: iterative selection, node records, keys ----------------
+    for (int i = wave; i < nact; i += 4) {
+        if (r_count[i] == 0) continue;
+        const int r = line * N + i;
+        const long long exp = (long long)(step + 1) * R + r;
+        const float* sc = s.p_base + exp * Vp;
+        const int node = s.beam_node[r];
+        const int plen = s.n_len[nbase + node];
+        const double pcum = s.n_cum[nbase + node];
+        const double pos = s.apos[r];
+        const int is1 = s.amax1[r];
+        const int beampos = r_beampos[i], srcpos = r_srcpos[i];
+        int rej = r_rej[i];
+        float vals[VPL];
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; vals[k] = v < V ? sc[v] : -INFINITY; }
+        unsigned taken = 0;
+        int created = 0;
+        const int total = beampos + r_rejlate[i];
+        for (int ps = 1; ps <= total; ++ps) {
+            float bv = -INFINITY; int bi = -1;
+            if (ps <= beampos) {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) {
+                    const int v = lane + 64 * k;
+                    if (v < V && !((taken >> k) & 1u) && (bi < 0 || better(vals[k], v, bv, bi))) { bv = vals[k]; bi = v; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                    if (oi >= 0 && (bi < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+                }
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) if (lane + 64 * k == bi) taken |= 1u << k;
+            } else {                                   // the rejection candidate beyond the beam width
+                bi = rej; bv = 0.f;
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) if (lane + 64 * k == rej) bv = vals[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) bv = fmaxf(bv, __shfl_xor(bv, o, 64));
+            }
+            bool isrej = false;
+            if (rej >= 0 && bi == rej) { isrej = true; rej = -1; }
+            if (bi == 0) continue;
+            if (lane == 0) {
+                const int k = created;
+                const int slot = r_off[i] + k;
+                const int id = id0 + slot;
+                const float cost = -logf(bv);
+                const double cum = pcum + (double)cost;
+                const int len = plen + 1;
+                const long long g = nbase + id;
+                s.n_parent[g] = node; s.n_chr[g] = bi; s.n_prob[g] = bv; s.n_cum[g] = cum; s.n_len[g] = len;
+                s.n_exp[g] = (int)exp; s.n_k[g] = k;
+                s.n_rejpos[g] = isrej ? srcpos : -1;
+                s.n_pos[g] = isrej ? (double)srcpos : pos;
+                s.n_is1[g] = isrej ? 1 : is1;
+                s.created[exp * CMAX + k] = (short)bi;
+                s_key[slot] = -(cum + p.cost0 * fabs((double)(len - T)));
+                s_id[slot] = id;
+            }
+            ++created;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) s.n_count[line] = id0 + nnew;
+
+    // ---------------- B: sort the new nodes, merge with the queue, cap ----------------
+    int npow = 1;
+    while (npow < nnew) npow <<= 1;
+    for (int i = nnew + tid; i < npow; i += 256) { s_key[i] = 0.0; s_id[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int k = 2; k <= npow; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const double ka = s_key[i], kb = s_key[l];
+                    const int ia = s_id[i], ib = s_id[l];
+                    const bool sw = up ? before(kb, ib, ka, ia) : before(ka, ia, kb, ib);
+                    if (sw) { s_key[i] = kb; s_id[i] = ib; s_key[l] = ka; s_id[l] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int par = step & 1;
+    const long long qstride = (long long)s.B * s.q_cap;
+    const int qn_old = s.q_n[line], qhead = s.q_n[s.B + line];
+    const double* okey = s.q_key + par * qstride + (long long)line * s.q_cap + qhead;
+    const int* oid = s.q_id + par * qstride + (long long)line * s.q_cap + qhead;
+    double* nkey = s.q_key + (par ^ 1) * qstride + (long long)line * s.q_cap;
+    int* nid = s.q_id + (par ^ 1) * qstride + (long long)line * s.q_cap;
+    const int qcap = 2 * T * N;                   // max_batches * batch_size (s2s:1531)
+    for (int i = tid; i < qn_old; i += 256) {     // old element i moves behind the new ones before it
+        const double k = okey[i]; const int id = oid[i];
+        int lo = 0, hi = nnew;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(s_key[mid], s_id[mid], k, id)) lo = mid + 1; else hi = mid; }
+        const int pos = i + lo;
+        if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
+    }
+    for (int j = tid; j < nnew; j += 256) {
+        const double k = s_key[j]; const int id = s_id[j];
+        int lo = 0, hi = qn_old;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(okey[mid], oid[mid], k, id)) lo = mid + 1; else hi = mid; }
+        const int pos = j + lo;
+        if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int qn = (qn_old + nnew) < qcap ? (qn_old + nnew) : qcap;
+
+    // ---------------- C: pop the next beam ----------------
+    const int pre = qn < 64 ? qn : 64;
+    if (tid < pre) { const int id = nid[tid]; pop_id[tid] = id; pop_chr[tid] = s.n_chr[nbase + id]; }
+    __syncthreads();
+    if (tid == 0) {
+        int nb = 0, h = 0;
+        int fn = s.f_n[line], ftot = s.f_total[line];
+        double* fkey = s.f_key + (long long)line * s.f_cap;
+        int* fid = s.f_id + (long long)line * s.f_cap;
+        double b0 = 0.0;
+        while (h < qn && nb < N) {
+            const int id = h < 64 ? pop_id[h] : nid[h];
+            const int chr = h < 64 ? pop_chr[h] : s.n_chr[nbase + id];
+            const double key = nkey[h];
+            if (chr == 1) {                        // '\n': finished hypothesis -> final_beam (s2s:1402)
+                ++ftot;
+                int ppos = fn;
+                while (ppos > 0 && before(key, id, fkey[ppos - 1], fid[ppos - 1])) --ppos;
+                if (ppos < s.f_cap) {
+                    const int last = fn < s.f_cap ? fn : s.f_cap - 1;
+                    for (int q = last; q > ppos; --q) { fkey[q] = fkey[q - 1]; fid[q] = fid[q - 1]; }
+                    fkey[ppos] = key; fid[ppos] = id;
+                    if (fn < s.f_cap) ++fn;
+                }
+            } else {
+                if (nb == 0) b0 = key;
+                s.beam_node[line * N + nb] = id;
+                ++nb;
+            }
+            ++h;
+        }
+        s.f_n[line] = fn; s.f_total[line] = ftot;
+        int done = 0;
+        if (nb == 0) done = 1;                                             // s2s:1416
+        else if (ftot > p.width_out && fkey[0] > b0) done = 1;            // s2s:1418-1420
+        s.q_n[line] = qn - h; s.q_n[s.B + line] = h;
+        sh_nb = nb; sh_npop = h; sh_done = done;
+        if (done) { s.line_done[line] = 1; s.nact[line] = 0; atomicSub(s.active_lines, 1); }
+        else s.nact[line] = nb;
+    }
+    __syncthreads();
+    if (sh_done) return;
+    const int nb = sh_nb;
+    // next step's inputs: fed-back scores with the better siblings reset (s2s:1515-1520)
+    for (int j = 0; j < N; ++j) {
+        const int r = line * N + j;
+        float* pin = s.p_in + (long long)r * Vp;
+        if (j < nb) {
+            const int id = s.beam_node[r];
+            const int exp = s.n_exp[nbase + id];
+            const float* src = s.p_base + (long long)exp * Vp;
+            for (int v = tid; v < Vp; v += 256) pin[v] = src[v];
+            if (tid == 0) s.prev[r] = exp;
+        } else {
+            for (int v = tid; v < Vp; v += 256) pin[v] = 0.f;
+            if (tid == 0) s.prev[r] = line * N;
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        const int r = line * N + j;
+        const int id = s.beam_node[r];
+        const int k = s.n_k[nbase + id];
+        const long long exp = s.n_exp[nbase + id];
+        if (tid < k) s.p_in[(long long)r * Vp + s.created[exp * CMAX + tid]] = 0.f;
+    }
+}
+void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(beam_step_kernel, dim3(s.B), dim3(256), 0, stream, s, p);
+}
+
+// Results, best first (seq2seq.py:1538-1544): walk the trie from each finished node to the root.
+__global__ void beam_extract_kernel(const BeamState s, const BeamParams p, const BeamOut o) {
+    __shared__ int chain[1024];
+    const int line = blockIdx.x / p.max_results, k = blockIdx.x % p.max_results;
+    const int tid = threadIdx.x;
+    const long long nbase = (long long)line * s.node_cap;
+    const int fn = s.f_n[line];
+    const long long ob = (long long)blockIdx.x;
+    if (tid == 0 && k == 0) { o.n_found[line] = s.f_total[line]; o.n_steps[line] = s.line_steps[line]; }
+    if (k >= fn) { if (tid == 0) { o.len[ob] = 0; o.score[ob] = 0.0; } return; }
+    const int fnode = s.f_id[(long long)line * s.f_cap + k];
+    const int len = s.n_len[nbase + fnode] - 1;
+    if (tid == 0) {
+        int cur = fnode;
+        for (int j = len - 1; j >= 0 && j < 1024; --j) { chain[j] = cur; cur = s.n_parent[nbase + cur]; }
+        o.len[ob] = len;
+        o.score[ob] = s.n_cum[nbase + fnode] / (double)len;
+    }
+    __syncthreads();
+    for (int j = tid; j < len && j < s.S; j += blockDim.x) {
+        const int nd = chain[j];
+        o.idx[ob * s.S + j] = s.n_chr[nbase + nd];
+        o.prob[ob * s.S + j] = s.n_prob[nbase + nd];
+        o.rejpos[ob * s.S + j] = s.n_rejpos[nbase + nd];
+    }
+    if (o.align) {
+        for (int j = 0; j < len && j < s.S; ++j) {
+            const int nd = chain[j];
+            const int rp = s.n_rejpos[nbase + nd];
+            const float* src = o.a_base + (long long)s.n_exp[nbase + nd] * s.T;
+            float* dst = o.align + (ob * s.S + j) * s.T;
+            for (int t = tid; t < s.T; t += blockDim.x) dst[t] = rp >= 0 ? (t == rp ? 1.0f : 0.0f) : src[t];
+        }
+    }
+}
+void launch_beam_extract(const BeamState& s, const BeamParams& p, const BeamOut& o, hipStream_t stream) {
+    hipLaunchKernelGGL(beam_extract_kernel, dim3(s.B * p.max_results), dim3(256), 0, stream, s, p, o);
+}
+
+}  // namespace casv

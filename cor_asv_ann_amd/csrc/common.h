@@ -1,0 +1,134 @@
+// Shared declarations of the HIP hot path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace casv {
+
+// One K-segment of a GEMM's A operand: rows of `width` floats (a multiple of 32) taken from
+//   base + slot * slot_stride + row_id * ld,   slot = step * step_mul + step_add,
+// where row_id = rows ? rows[m] : m.  `skip_first` drops the segment (treated as zeros) at
+// step 0 -- the zero initial LSTM state of the encoder.
+struct Seg {
+    const float* base;
+    const int* rows;
+    long long slot_stride;
+    int step_mul, step_add;
+    int ld;
+    int width;
+    int skip_first;
+    int koff;   // offset of this segment in the fused weight's K dimension
+};
+
+// Output / state pointer that moves with the step the same way.
+struct SlotPtr {
+    float* base;
+    long long slot_stride;
+    int step_mul, step_add;
+    int ld;
+};
+
+struct GemmArgs {
+    Seg a[3];
+    int nseg;
+    const float* Bt;      // [N][Ktot], K contiguous (LSTM: rows in gate-interleaved order)
+    const float* bias;    // [N] (same order) or nullptr
+    int M, N, Ktot;
+    SlotPtr out;          // PLAIN: C[M][N]; LSTM: h'[M][N/4]
+    // LSTM epilogue only
+    Seg c_in;             // previous cell state rows (width = units), skip_first = zero state
+    SlotPtr c_out;
+    // step source
+    int step_imm;
+    const int* step_ptr;
+};
+
+enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
+
+void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream);
+
+// ---- small kernels (decode_kernels.hip) ----
+struct AttnArgs {
+    const float* wq;        // [R][W]  h_d . W_a + b_UW
+    const float* u;         // [B][T][W]
+    const float* enc;       // [B][T][C]
+    const float* va;        // [W]
+    const float* bv;        // [1]
+    const float* a_base;    // alignment store [(S+1)*R][T]
+    const int* prev;        // [R] global row id of the parent expansion
+    const int* line;        // [R] or nullptr (then line = r / rows_per_line)
+    int rows_per_line;
+    float* ctx;             // [R][C]
+    int R, T, W, C, window;
+    int step_imm; const int* step_ptr;   // output slot = step + 1
+    double* apos;           // [R] sum_s a'[s]*s
+    int* amax1;             // [R] max(a') == 1.0
+    const int* nrows;       // optional device row count (rows >= *nrows are skipped)
+};
+void launch_attention(const AttnArgs& a, hipStream_t stream);
+
+struct SoftmaxArgs {
+    const float* logits;    // [R][V]
+    float* p_base;          // score store [(S+1)*R][V], output slot = step + 1
+    int R, V;
+    int step_imm; const int* step_ptr;
+    // greedy bookkeeping (mode < 0: none)
+    int mode;               // 0: argmax over 1..V-1; 1: argmax over all V with index-0 NaN write-back
+    int* out_idx;           // [R][S]
+    float* out_prob;        // [R][S]
+    int S;
+    int* nan_flag;          // set when a row is all NaN (numpy would raise)
+};
+void launch_softmax(const SoftmaxArgs& a, hipStream_t stream);
+
+void launch_embed_sparse(const float* E, const int* idx, const float* val, float* x0,
+                         int rows, int A, int V, int W, hipStream_t stream);
+void launch_fill_prev(int* prev, int R, int step_imm, const int* step_ptr, hipStream_t stream);
+void launch_advance_step(int* step_ptr, hipStream_t stream);
+void launch_scatter_rows(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,
+                         int dst_row_mul, hipStream_t stream);
+
+// ---- beam search (beam_kernels.hip) ----
+struct BeamParams {
+    int N, width_in, width_out, max_results;
+    double threshold_in, rejection, cost0;
+};
+
+struct BeamState {
+    // per line
+    int B, T, V, S, R;          // R = B*N
+    int node_cap, q_cap, f_cap;
+    // node pool [B][node_cap]
+    int* n_parent; int* n_chr; float* n_prob; double* n_cum; int* n_len; int* n_exp;
+    int* n_k; int* n_rejpos; double* n_pos; int* n_is1;
+    int* n_count;               // [B]
+    // per expansion row [(S+1)*R]
+    short* created;             // [..][16]
+    // queue [B][q_cap + 16N] keys + ids, ping-pong not needed (rebuilt through LDS)
+    double* q_key; int* q_id; int* q_n;
+    // finals
+    double* f_key; int* f_id; int* f_n; int* f_total;
+    // current beam
+    int* beam_node;             // [R]
+    int* nact;                  // [B] active rows of the current step
+    double* beam0_key;          // [B]
+    int* line_done;             // [B]
+    int* line_steps;            // [B]
+    int* active_lines;          // [1]
+    // step io
+    int* prev;                  // [R]
+    float* p_in;                // [R][V]
+    const float* p_base;        // score store
+    const double* apos; const int* amax1;
+    const int* src_rej;         // [B][T]
+    const int* step_ptr;
+};
+void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t stream);
+void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream);
+struct BeamOut {
+    int* idx; float* prob; int* len; double* score; int* rejpos; float* align; int* n_found; int* n_steps;
+    const float* a_base;
+};
+void launch_beam_extract(const BeamState& s, const BeamParams& p, const BeamOut& o, hipStream_t stream);
+
+}  // namespace casv

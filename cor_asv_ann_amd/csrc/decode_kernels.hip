@@ -1,0 +1,223 @@
+// HBM/L2-bound kernels of the decoder step: local monotonic additive attention (window + context),
+// tied-projection softmax with greedy bookkeeping, sparse embedding of the encoder input, and the
+// little helpers that move per-step state.  One 64-lane wave owns one decoder row throughout, so all
+// row reductions are DPP/shuffle butterflies with a fixed order (results do not depend on batch size).
+#include "common.h"
+#include <math.h>
+
+namespace casv {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention.py:526-575.  Only the <= 2*window+1 positions that survive the window mask are evaluated
+// (the reference evaluates all T and multiplies by a 0/1 mask, attention.py:540-569: same values).
+//   t' = sum_s a_prev[s]*s + 1 (float64 accumulate, rounded once to fp32 -- see oracle/model.py)
+//   keep s with |t' - s| <= window ; e[s] = exp(tanh(wq + u[s]).v_a + b_v) ; a' = e / sum e
+//   ctx = sum_s a'[s] * enc[s]
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXWIN = 11;
+
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    const int nrows = a.nrows ? *a.nrows : a.R;
+    if (r >= nrows) return;
+    const int step = a.step_ptr ? *a.step_ptr : a.step_imm;
+    const int ln = a.line ? a.line[r] : r / a.rows_per_line;
+    const int T = a.T, W = a.W, C = a.C;
+    const float* ap = a.a_base + (long long)a.prev[r] * T;
+    float* aout = const_cast<float*>(a.a_base) + ((long long)(step + 1) * a.R + r) * T;
+
+    double acc = 0.0;
+    for (int s = lane; s < T; s += 64) acc += (double)ap[s] * (double)s;
+    const float tp = (float)(wave_sum_d(acc) + 1.0);
+    const float win = (float)a.window;
+
+    int s_lo = 0, s_hi = -1;                    // empty unless t' is a number
+    if (tp == tp && fabsf(tp) < 1.0e9f) {
+        int lo = (int)floorf(tp - win) - 1, hi = (int)floorf(tp + win) + 1;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > T - 1 ? T - 1 : hi;
+        s_lo = T; s_hi = -1;
+        for (int s = lo; s <= hi; ++s)
+            if (fabsf(tp - (float)s) <= win) { s_lo = s < s_lo ? s : s_lo; s_hi = s; }
+    }
+    const int cnt = s_hi - s_lo + 1;            // <= MAXWIN
+
+    const float* wq = a.wq + (long long)r * W;
+    const float* ub = a.u + ((long long)ln * T) * W;
+    const float bv = a.bv[0];
+    float e[MAXWIN];
+    float denom = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXWIN; ++i) {
+        e[i] = 0.0f;
+        if (i < cnt) {
+            const float* us = ub + (long long)(s_lo + i) * W;
+            float part = 0.0f;
+            for (int j = lane; j < W; j += 64) part += tanhf(wq[j] + us[j]) * a.va[j];
+            e[i] = expf(wave_sum(part) + bv);
+            denom += e[i];
+        }
+    }
+    const float nanv = __builtin_nanf("");
+    float amax = 0.0f;
+    double pos = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXWIN; ++i) {
+        if (i < cnt) {
+            e[i] = e[i] / denom;
+            amax = fmaxf(amax, e[i]);
+            pos += (double)e[i] * (double)(s_lo + i);
+        }
+    }
+    for (int s = lane; s < T; s += 64) {
+        float v = 0.0f;
+        if (cnt <= 0) v = nanv;                 // 0/0 everywhere, as in the reference
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i)
+            if (i < cnt && s == s_lo + i) v = e[i];
+        aout[s] = v;
+    }
+    const float* eb = a.enc + ((long long)ln * T) * C;
+    float* ctx = a.ctx + (long long)r * C;
+    for (int c = lane; c < C; c += 64) {
+        float v = cnt <= 0 ? nanv : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i)
+            if (i < cnt) v += e[i] * eb[(long long)(s_lo + i) * C + c];
+        ctx[c] = v;
+    }
+    if (lane == 0) {
+        if (a.apos) a.apos[r] = cnt <= 0 ? (double)nanv : pos;
+        if (a.amax1) a.amax1[r] = (amax == 1.0f) ? 1 : 0;
+    }
+}
+
+void launch_attention(const AttnArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(attention_kernel, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax(h . E^T) (seq2seq.py:379) + the greedy pick of seq2seq.py:1250 / :1329-1338.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_kernel(const SoftmaxArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= a.R) return;
+    const int step = a.step_ptr ? *a.step_ptr : a.step_imm;
+    const int V = a.V, Vp = (V + 31) & ~31;
+    const float* x = a.logits + (long long)r * Vp;
+    float* p = a.p_base + ((long long)(step + 1) * a.R + r) * Vp;
+    float m = -INFINITY;
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+    // fmaxf drops NaN; a NaN logit row must stay NaN like numpy's max does
+    float anynan = 0.0f;
+    for (int v = lane; v < V; v += 64) anynan += (x[v] != x[v]) ? 1.0f : 0.0f;
+    m = wave_max(m);
+    if (wave_sum(anynan) > 0.0f) m = __builtin_nanf("");
+    float sum = 0.0f;
+    for (int v = lane; v < V; v += 64) sum += expf(x[v] - m);
+    sum = wave_sum(sum);
+    float best = -INFINITY; int bidx = 0x7fffffff;          // over v >= 1
+    float p0 = 0.0f;
+    for (int v = lane; v < V; v += 64) {
+        const float pv = expf(x[v] - m) / sum;
+        p[v] = pv;
+        if (v == 0) p0 = pv;
+        if (v >= 1 && pv > best) { best = pv; bidx = v; }
+    }
+    if (a.mode < 0) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    p0 = __shfl(p0, 0, 64);
+    if (lane == 0) {
+        int idx = bidx; float pr = best;
+        if (bidx == 0x7fffffff) {                 // every candidate NaN: numpy raises here
+            if (a.nan_flag) atomicOr(a.nan_flag, 1);
+            idx = 1; pr = __builtin_nanf("");
+        } else if (a.mode == 1) {
+            // np.nanargmax over all V: index 0 wins only if strictly greater than everything after it
+            if (p0 >= best && p0 == p0) p[0] = __builtin_nanf("");   // s2s:1334, stays in the feedback
+        }
+        a.out_idx[(long long)r * a.S + step] = idx;
+        a.out_prob[(long long)r * a.S + step] = pr;
+    }
+}
+
+void launch_softmax(const SoftmaxArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(softmax_kernel, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// char_input_projection on the encoder side (seq2seq.py:243-244) for sparse input rows:
+// x0[row] = sum_a val[row][a] * E[idx[row][a]]   (one-hot: a single exact row copy)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void embed_sparse_kernel(const float* __restrict__ E, const int* __restrict__ idx,
+                                                           const float* __restrict__ val, float* __restrict__ x0,
+                                                           int rows, int A, int V, int W) {
+    const int row = blockIdx.x;
+    if (row >= rows) return;
+    for (int w = threadIdx.x * 4; w < W; w += 128 * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < A; ++k) {
+            const int i = idx[(long long)row * A + k];
+            if (i < 0 || i >= V) continue;
+            const float c = val[(long long)row * A + k];
+            const float4 ev = *reinterpret_cast<const float4*>(E + (long long)i * W + w);
+            acc.x += c * ev.x; acc.y += c * ev.y; acc.z += c * ev.z; acc.w += c * ev.w;
+        }
+        *reinterpret_cast<float4*>(x0 + (long long)row * W + w) = acc;
+    }
+}
+void launch_embed_sparse(const float* E, const int* idx, const float* val, float* x0, int rows, int A,
+                         int V, int W, hipStream_t stream) {
+    hipLaunchKernelGGL(embed_sparse_kernel, dim3(rows), dim3(128), 0, stream, E, idx, val, x0, rows, A, V, W);
+}
+
+__global__ void fill_prev_kernel(int* prev, int R, int step_imm, const int* step_ptr) {
+    const int step = step_ptr ? *step_ptr : step_imm;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) prev[r] = step * R + r;
+}
+void launch_fill_prev(int* prev, int R, int step_imm, const int* step_ptr, hipStream_t stream) {
+    hipLaunchKernelGGL(fill_prev_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, prev, R, step_imm, step_ptr);
+}
+
+__global__ void advance_step_kernel(int* step_ptr) { *step_ptr += 1; }
+void launch_advance_step(int* step_ptr, hipStream_t stream) {
+    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, stream, step_ptr);
+}
+
+__global__ void scatter_rows_kernel(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,
+                                    int dst_row_mul) {
+    const int i = blockIdx.x;
+    for (int w = threadIdx.x; w < width; w += blockDim.x)
+        dst[(long long)i * dst_row_mul * dst_ld + w] = src[(long long)i * src_ld + w];
+}
+void launch_scatter_rows(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,
+                         int dst_row_mul, hipStream_t stream) {
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(rows), dim3(128), 0, stream, src, src_ld, dst, dst_ld, rows, width,
+                       dst_row_mul);
+}
+
+}  // namespace casv

@@ -1,0 +1,748 @@
+// Host side of the C ABI (include/cor_asv_ann_hip.h): weight repacking, device buffers, and the launch
+// sequences of the encoder (seq2seq.py:237-314), the decoder step (seq2seq.py:416-480) and the
+// greedy / beam decode loops (seq2seq.py:1215-1544).  All device memory and the HIP stream belong to
+// the handle; callers pass plain host pointers.
+#include "common.h"
+#include "../../include/cor_asv_ann_hip.h"
+
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace casv;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail(e_ == hipErrorOutOfMemory ? CASV_ERR_NOMEM : CASV_ERR_HIP, "%s failed: %s (%s:%d)", #x, \
+                hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(CASV_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum ProfClass { PC_LSTM = 0, PC_GEMM, PC_ATTN, PC_SOFTMAX, PC_BEAM, PC_EMBED, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"lstm_gemm", "gemm", "attention", "softmax", "beam", "embed"};
+
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    struct Rec { hipEvent_t a, b; int cls; };
+    std::vector<Rec> recs;
+    double flops[PC_COUNT] = {0}, bytes[PC_COUNT] = {0};
+    long long launches[PC_COUNT] = {0};
+    double ms[PC_COUNT] = {0};
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+        return pool[used++];
+    }
+    void reset() { used = 0; recs.clear(); for (int i = 0; i < PC_COUNT; ++i) { flops[i] = bytes[i] = ms[i] = 0; launches[i] = 0; } }
+    void collect() {
+        for (auto& r : recs) { float t = 0; if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t; }
+        recs.clear(); used = 0;
+    }
+};
+
+struct LstmW { DevBuf wt, bias; int kin = 0; };   // packed [4W][kin + W], gate-interleaved
+
+}  // namespace
+
+struct casv_model {
+    casv_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int W = 0, V = 0, Vp = 0, C = 0, D = 0;
+    std::map<std::string, std::vector<float>> host;      // Keras-layout tensors
+    std::map<std::string, size_t> expect;                // name -> element count
+    bool committed = false;
+    // packed device weights
+    DevBuf E, ETp, WaT, bUW, va, bv, UT;
+    LstmW enc_fw, enc_bw;
+    std::vector<LstmW> enc, dec;                         // enc[n] for layer n>=2 at index n; dec[n] n=1..D
+    // encoder session
+    int B = 0, T = 0, A = 0;
+    bool encoded = false;
+    DevBuf d_idx, d_val, d_srcrej, x0, H1, Ha, Hb, cfin, hfin, u;
+    float* enc_out = nullptr;
+    // decode session
+    int R = 0, S = 0;
+    std::vector<DevBuf> st_h, st_c;
+    DevBuf st_a, st_p, y0, ctx, wq, logits, prev, pin, apos, amax1, d_step, d_line, d_nan;
+    DevBuf o_idx, o_prob, o_align;
+    // beam
+    DevBuf b_parent, b_chr, b_prob, b_cum, b_len, b_exp, b_k, b_rejpos, b_pos, b_is1, b_count, b_created;
+    DevBuf b_qkey, b_qid, b_qn, b_fkey, b_fid, b_fn, b_ftotal, b_beamnode, b_nact, b_beam0, b_done, b_steps, b_active;
+    DevBuf bo_idx, bo_prob, bo_len, bo_score, bo_rej, bo_align, bo_found, bo_nsteps;
+    // options
+    bool use_graph = false;
+    Prof prof;
+
+    void prof_begin(int cls, double fl, double by, hipEvent_t& a) {
+        if (!prof.on) return;
+        a = prof.get(); (void)hipEventRecord(a, stream);
+        prof.flops[cls] += fl; prof.bytes[cls] += by; prof.launches[cls] += 1;
+    }
+    void prof_end(int cls, hipEvent_t a) {
+        if (!prof.on) return;
+        hipEvent_t b = prof.get(); (void)hipEventRecord(b, stream);
+        prof.recs.push_back({a, b, cls});
+    }
+};
+
+static std::map<std::string, size_t> expected_shapes(const casv_config& c) {
+    const size_t W = c.width, V = c.voc_size, D = c.depth, C = (D == 1 ? 2 * W : W);
+    std::map<std::string, size_t> m;
+    m["E"] = V * W;
+    for (const char* d : {"fw", "bw"}) {
+        m[std::string("enc1_") + d + "_K"] = W * 4 * W; m[std::string("enc1_") + d + "_R"] = W * 4 * W;
+        m[std::string("enc1_") + d + "_b"] = 4 * W;
+    }
+    for (size_t n = 2; n <= D; ++n) {
+        const size_t nin = n == 2 ? 2 * W : W; const std::string p = "enc" + std::to_string(n);
+        m[p + "_K"] = nin * 4 * W; m[p + "_R"] = W * 4 * W; m[p + "_b"] = 4 * W;
+    }
+    m["att_U"] = C * W;
+    for (size_t n = 1; n < D; ++n) {
+        const std::string p = "dec" + std::to_string(n);
+        m[p + "_K"] = W * 4 * W; m[p + "_R"] = W * 4 * W; m[p + "_b"] = 4 * W;
+    }
+    m["att_Wa"] = W * W; m["att_va"] = W; m["att_bUW"] = W; m["att_bv"] = 1;
+    const std::string p = "dec" + std::to_string(D);
+    m[p + "_K"] = (W + C) * 4 * W; m[p + "_R"] = W * 4 * W; m[p + "_b"] = 4 * W;
+    return m;
+}
+
+extern "C" const char* casv_last_error(void) { return g_err; }
+extern "C" const char* casv_version(void) { return "cor_asv_ann_amd 0.1 (gfx950)"; }
+extern "C" int casv_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+extern "C" int casv_model_create(const casv_config* cfg, int device_id, casv_model** out) {
+    if (!cfg || !out) return fail(CASV_ERR_ARG, "null argument");
+    if (cfg->residual_connections || cfg->deep_bidirectional_encoder || cfg->bridge_dense || cfg->lm || cfg->stateful)
+        return fail(CASV_ERR_ARG, "only the default topology is implemented (residual_connections, "
+                    "deep_bidirectional_encoder, bridge_dense, lm_loss/lm_predict, stateful must be off)");
+    if (cfg->depth < 1 || cfg->depth > 8) return fail(CASV_ERR_ARG, "depth %d out of range 1..8", cfg->depth);
+    if (cfg->width < 32 || cfg->width % 32) return fail(CASV_ERR_ARG, "width %d must be a positive multiple of 32", cfg->width);
+    if (cfg->voc_size < 2 || cfg->voc_size > 1024) return fail(CASV_ERR_ARG, "voc_size %d out of range 2..1024", cfg->voc_size);
+    if (cfg->window_width < 1 || cfg->window_width > 5) return fail(CASV_ERR_ARG, "window_width %d out of range 1..5", cfg->window_width);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(CASV_ERR_ARG, "device %d not available (%d devices)", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+    casv_model* m = new casv_model();
+    m->cfg = *cfg; m->device = device_id;
+    m->W = cfg->width; m->V = cfg->voc_size; m->Vp = (cfg->voc_size + 31) & ~31; m->D = cfg->depth;
+    m->C = cfg->depth == 1 ? 2 * cfg->width : cfg->width;
+    m->expect = expected_shapes(*cfg);
+    hipError_t e = hipStreamCreate(&m->stream);
+    if (e != hipSuccess) { delete m; return fail(CASV_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    m->enc.resize(m->D + 1); m->dec.resize(m->D + 1); m->st_h.resize(m->D + 1); m->st_c.resize(m->D + 1);
+    *out = m;
+    return CASV_OK;
+}
+
+extern "C" void casv_model_destroy(casv_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    DevBuf* bufs[] = {&m->E, &m->ETp, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
+        &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->cfin,
+        &m->hfin, &m->u, &m->st_a, &m->st_p, &m->y0, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
+        &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->b_parent, &m->b_chr, &m->b_prob,
+        &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos, &m->b_pos, &m->b_is1, &m->b_count, &m->b_created,
+        &m->b_qkey, &m->b_qid, &m->b_qn, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_beamnode, &m->b_nact,
+        &m->b_beam0, &m->b_done, &m->b_steps, &m->b_active, &m->bo_idx, &m->bo_prob, &m->bo_len, &m->bo_score,
+        &m->bo_rej, &m->bo_align, &m->bo_found, &m->bo_nsteps};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& l : m->enc) { l.wt.release(); l.bias.release(); }
+    for (auto& l : m->dec) { l.wt.release(); l.bias.release(); }
+    for (auto& b : m->st_h) b.release();
+    for (auto& b : m->st_c) b.release();
+    for (auto e : m->prof.pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int casv_set_weight(casv_model* m, const char* name, const float* data, int64_t count) {
+    if (!m || !name || !data) return fail(CASV_ERR_ARG, "null argument");
+    auto it = m->expect.find(name);
+    if (it == m->expect.end()) return fail(CASV_ERR_ARG, "unknown weight '%s' for depth %d", name, m->D);
+    if ((size_t)count != it->second) return fail(CASV_ERR_ARG, "weight '%s': expected %zu elements, got %lld", name, it->second, (long long)count);
+    m->host[name].assign(data, data + count);
+    m->committed = false;
+    return CASV_OK;
+}
+
+extern "C" int casv_get_weight(casv_model* m, const char* name, float* out, int64_t capacity) {
+    if (!m || !name || !out) return fail(CASV_ERR_ARG, "null argument");
+    auto it = m->host.find(name);
+    if (it == m->host.end()) return fail(CASV_ERR_STATE, "weight '%s' has not been set", name);
+    if ((size_t)capacity < it->second.size()) return fail(CASV_ERR_ARG, "buffer too small for '%s'", name);
+    memcpy(out, it->second.data(), it->second.size() * sizeof(float));
+    return CASV_OK;
+}
+
+static int upload(DevBuf& b, const std::vector<float>& v) {
+    if (int rc = b.ensure(v.size() * sizeof(float))) return rc;
+    HIPCHK(hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Keras (in,4W) kernel + (W,4W) recurrent kernel + (4W) bias -> [4W][in+W] rows in the
+// gate-interleaved order n = (u/32)*128 + g*32 + u%32, K contiguous.
+static int pack_lstm(casv_model* m, LstmW& dst, const std::string& prefix, int kin) {
+    const int W = m->W, Kt = kin + W;
+    const auto& K = m->host[prefix + "_K"]; const auto& R = m->host[prefix + "_R"]; const auto& b = m->host[prefix + "_b"];
+    std::vector<float> wt((size_t)4 * W * Kt), bias(4 * W);
+    for (int u = 0; u < W; ++u)
+        for (int g = 0; g < 4; ++g) {
+            const int n = (u / 32) * 128 + g * 32 + (u % 32), col = g * W + u;
+            float* row = &wt[(size_t)n * Kt];
+            for (int k = 0; k < kin; ++k) row[k] = K[(size_t)k * 4 * W + col];
+            for (int k = 0; k < W; ++k) row[kin + k] = R[(size_t)k * 4 * W + col];
+            bias[n] = b[col];
+        }
+    dst.kin = kin;
+    if (int rc = upload(dst.wt, wt)) return rc;
+    return upload(dst.bias, bias);
+}
+
+extern "C" int casv_commit_weights(casv_model* m) {
+    if (!m) return fail(CASV_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->device));
+    for (auto& kv : m->expect)
+        if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());
+    const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, D = m->D;
+    const auto& E = m->host["E"];
+    if (int rc = upload(m->E, E)) return rc;
+    std::vector<float> etp((size_t)W * Vp, 0.f);
+    for (int v = 0; v < V; ++v) for (int w = 0; w < W; ++w) etp[(size_t)w * Vp + v] = E[(size_t)v * W + w];
+    if (int rc = upload(m->ETp, etp)) return rc;
+    if (int rc = pack_lstm(m, m->enc_fw, "enc1_fw", W)) return rc;
+    if (int rc = pack_lstm(m, m->enc_bw, "enc1_bw", W)) return rc;
+    for (int n = 2; n <= D; ++n) if (int rc = pack_lstm(m, m->enc[n], "enc" + std::to_string(n), n == 2 ? 2 * W : W)) return rc;
+    for (int n = 1; n < D; ++n) if (int rc = pack_lstm(m, m->dec[n], "dec" + std::to_string(n), W)) return rc;
+    if (int rc = pack_lstm(m, m->dec[D], "dec" + std::to_string(D), W + C)) return rc;
+    const auto& Wa = m->host["att_Wa"]; const auto& U = m->host["att_U"];
+    std::vector<float> wat((size_t)W * W), ut((size_t)W * C);
+    for (int j = 0; j < W; ++j) for (int k = 0; k < W; ++k) wat[(size_t)j * W + k] = Wa[(size_t)k * W + j];
+    for (int j = 0; j < W; ++j) for (int c = 0; c < C; ++c) ut[(size_t)j * C + c] = U[(size_t)c * W + j];
+    if (int rc = upload(m->WaT, wat)) return rc;
+    if (int rc = upload(m->UT, ut)) return rc;
+    if (int rc = upload(m->bUW, m->host["att_bUW"])) return rc;
+    if (int rc = upload(m->va, m->host["att_va"])) return rc;
+    if (int rc = upload(m->bv, m->host["att_bv"])) return rc;
+    m->committed = true;
+    return CASV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static Seg mkseg(const float* base, int ld, int width, int koff, const int* rows = nullptr,
+                 long long slot_stride = 0, int mul = 0, int add = 0, int skip_first = 0) {
+    Seg s; s.base = base; s.rows = rows; s.slot_stride = slot_stride; s.step_mul = mul; s.step_add = add;
+    s.ld = ld; s.width = width; s.skip_first = skip_first; s.koff = koff; return s;
+}
+static SlotPtr mkslot(float* base, int ld, long long slot_stride = 0, int mul = 0, int add = 0) {
+    SlotPtr s; s.base = base; s.slot_stride = slot_stride; s.step_mul = mul; s.step_add = add; s.ld = ld; return s;
+}
+
+static void run_gemm(casv_model* m, int epi, GemmArgs& g) {
+    hipEvent_t a{};
+    const int cls = epi == EPI_LSTM ? PC_LSTM : PC_GEMM;
+    int kact = 0;
+    for (int i = 0; i < g.nseg; ++i) kact += g.a[i].width;
+    const double fl = 2.0 * g.M * (double)g.N * kact;
+    const double by = 4.0 * ((double)g.M * kact + (double)g.N * kact + (double)g.M * g.N);
+    m->prof_begin(cls, fl, by, a);
+    launch_gemm(epi, g, m->stream);
+    m->prof_end(cls, a);
+}
+
+extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const int32_t* idx, const float* val,
+                           const int32_t* src_rej) {
+    if (!m || !idx || !val) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->committed) return fail(CASV_ERR_STATE, "weights not committed");
+    if (B < 1 || T < 1 || A < 1) return fail(CASV_ERR_ARG, "bad shape B=%d T=%d A=%d", B, T, A);
+    if (2 * T > 1024) return fail(CASV_ERR_ARG, "line length %d exceeds the supported maximum of 512", T);
+    HIPCHK(hipSetDevice(m->device));
+    const int W = m->W, C = m->C, D = m->D;
+    const size_t BT = (size_t)B * T;
+    if (int rc = m->d_idx.ensure(BT * A * 4)) return rc;
+    if (int rc = m->d_val.ensure(BT * A * 4)) return rc;
+    if (int rc = m->d_srcrej.ensure(BT * 4)) return rc;
+    if (int rc = m->x0.ensure(BT * W * 4)) return rc;
+    if (int rc = m->H1.ensure(BT * 2 * W * 4)) return rc;
+    if (D >= 2) { if (int rc = m->Ha.ensure(BT * W * 4)) return rc; }
+    if (D >= 3) { if (int rc = m->Hb.ensure(BT * W * 4)) return rc; }
+    if (int rc = m->cfin.ensure((size_t)(D + 1) * B * W * 4)) return rc;     // slot D: forward c of layer 1 (unused later)
+    if (int rc = m->hfin.ensure((size_t)D * B * W * 4)) return rc;
+    if (int rc = m->u.ensure(BT * W * 4)) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_idx.p, idx, BT * A * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_val.p, val, BT * A * 4, hipMemcpyHostToDevice, m->stream));
+    if (src_rej) HIPCHK(hipMemcpyAsync(m->d_srcrej.p, src_rej, BT * 4, hipMemcpyHostToDevice, m->stream));
+    else HIPCHK(hipMemsetAsync(m->d_srcrej.p, 0xff, BT * 4, m->stream));
+    m->B = B; m->T = T; m->A = A;
+
+    hipEvent_t ev{};
+    m->prof_begin(PC_EMBED, 2.0 * BT * A * W, 4.0 * BT * W * (A + 1), ev);
+    launch_embed_sparse(m->E.as<float>(), m->d_idx.as<int>(), m->d_val.as<float>(), m->x0.as<float>(), (int)BT, A,
+                        m->V, W, m->stream);
+    m->prof_end(PC_EMBED, ev);
+
+    float* x0 = m->x0.as<float>(); float* H1 = m->H1.as<float>();
+    float* cfin = m->cfin.as<float>();
+    // layer 1, both directions (seq2seq.py:272-281)
+    for (int t = 0; t < T; ++t) {
+        for (int dir = 0; dir < 2; ++dir) {
+            GemmArgs g{};
+            const LstmW& w = dir == 0 ? m->enc_fw : m->enc_bw;
+            const int mul = dir == 0 ? 1 : -1;
+            const int addx = dir == 0 ? 0 : T - 1, addh = dir == 0 ? -1 : T;
+            g.nseg = 2;
+            g.a[0] = mkseg(x0, T * W, W, 0, nullptr, W, mul, addx);
+            g.a[1] = mkseg(H1 + dir * W, T * 2 * W, W, W, nullptr, 2 * W, mul, addh, 1);
+            g.Bt = w.wt.as<float>(); g.bias = w.bias.as<float>();
+            g.M = B; g.N = 4 * W; g.Ktot = 2 * W;
+            g.out = mkslot(H1 + dir * W, T * 2 * W, 2 * W, mul, addx);
+            float* cb = cfin + (size_t)(dir == 0 ? D : 0) * B * W;
+            g.c_in = mkseg(cb, W, W, 0, nullptr, 0, 0, 0, 1);
+            g.c_out = mkslot(cb, W);
+            g.step_imm = t; g.step_ptr = nullptr;
+            run_gemm(m, EPI_LSTM, g);
+        }
+    }
+    // backward final h = output at time 0 (seq2seq.py:280)
+    launch_scatter_rows(H1 + W, T * 2 * W, m->hfin.as<float>(), W, B, W, 1, m->stream);
+    float* in = H1; int win = 2 * W;
+    float* outb = nullptr;
+    for (int n = 2; n <= D; ++n) {
+        outb = (n % 2 == 0) ? m->Ha.as<float>() : m->Hb.as<float>();
+        for (int t = 0; t < T; ++t) {
+            GemmArgs g{};
+            g.nseg = 2;
+            g.a[0] = mkseg(in, T * win, win, 0, nullptr, win, 1, 0);
+            g.a[1] = mkseg(outb, T * W, W, win, nullptr, W, 1, -1, 1);
+            g.Bt = m->enc[n].wt.as<float>(); g.bias = m->enc[n].bias.as<float>();
+            g.M = B; g.N = 4 * W; g.Ktot = win + W;
+            g.out = mkslot(outb, T * W, W, 1, 0);
+            float* cb = cfin + (size_t)(n - 1) * B * W;
+            g.c_in = mkseg(cb, W, W, 0, nullptr, 0, 0, 0, 1);
+            g.c_out = mkslot(cb, W);
+            g.step_imm = t;
+            run_gemm(m, EPI_LSTM, g);
+        }
+        launch_scatter_rows(outb + (size_t)(T - 1) * W, T * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1,
+                            m->stream);
+        in = outb; win = W;
+    }
+    m->enc_out = D == 1 ? H1 : outb;
+    // u = attention_dense(enc_out) once per line (seq2seq.py:313; the reference redoes it every step)
+    {
+        GemmArgs g{};
+        g.nseg = 1; g.a[0] = mkseg(m->enc_out, C, C, 0);
+        g.Bt = m->UT.as<float>(); g.bias = nullptr; g.M = (int)BT; g.N = W; g.Ktot = C;
+        g.out = mkslot(m->u.as<float>(), W);
+        run_gemm(m, EPI_PLAIN, g);
+    }
+    HIPCHK(hipGetLastError());
+    m->encoded = true;
+    return CASV_OK;
+}
+
+extern "C" int casv_get_encoder_outputs(casv_model* m, float* enc_out, float* states) {
+    if (!m) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->encoded) return fail(CASV_ERR_STATE, "nothing encoded");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const size_t BW = (size_t)m->B * m->W;
+    if (enc_out) HIPCHK(hipMemcpy(enc_out, m->enc_out, (size_t)m->B * m->T * m->C * 4, hipMemcpyDeviceToHost));
+    if (states)
+        for (int n = 0; n < m->D; ++n) {
+            HIPCHK(hipMemcpy(states + (2 * n) * BW, m->hfin.as<float>() + n * BW, BW * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(states + (2 * n + 1) * BW, m->cfin.as<float>() + n * BW, BW * 4, hipMemcpyDeviceToHost));
+        }
+    return CASV_OK;
+}
+
+// ---- decode session ----
+static int ensure_session(casv_model* m, int R, int S) {
+    const int W = m->W, Vp = m->Vp, C = m->C, T = m->T, D = m->D;
+    const size_t slots = (size_t)(S + 1) * R;
+    for (int n = 1; n <= D; ++n) {
+        if (int rc = m->st_h[n].ensure(slots * W * 4)) return rc;
+        if (int rc = m->st_c[n].ensure(slots * W * 4)) return rc;
+    }
+    if (int rc = m->st_a.ensure(slots * T * 4)) return rc;
+    if (int rc = m->st_p.ensure(slots * Vp * 4)) return rc;
+    if (int rc = m->y0.ensure((size_t)R * W * 4)) return rc;
+    if (int rc = m->ctx.ensure((size_t)R * C * 4)) return rc;
+    if (int rc = m->wq.ensure((size_t)R * W * 4)) return rc;
+    if (int rc = m->logits.ensure((size_t)R * Vp * 4)) return rc;
+    if (int rc = m->prev.ensure((size_t)R * 4)) return rc;
+    if (int rc = m->pin.ensure((size_t)R * Vp * 4)) return rc;
+    if (int rc = m->apos.ensure((size_t)R * 8)) return rc;
+    if (int rc = m->amax1.ensure((size_t)R * 4)) return rc;
+    if (int rc = m->d_step.ensure(16)) return rc;
+    if (int rc = m->d_nan.ensure(16)) return rc;
+    m->R = R; m->S = S;
+    return 0;
+}
+
+// Initial decoder state = encoder final states (seq2seq.py:339,352), zero alignment, zero input.
+static int init_root(casv_model* m, int rows_per_line) {
+    const int W = m->W, Vp = m->Vp, T = m->T, D = m->D, R = m->R, B = m->B;
+    HIPCHK(hipMemsetAsync(m->st_a.p, 0, (size_t)R * T * 4, m->stream));
+    HIPCHK(hipMemsetAsync(m->st_p.p, 0, (size_t)R * Vp * 4, m->stream));
+    HIPCHK(hipMemsetAsync(m->logits.p, 0, (size_t)R * Vp * 4, m->stream));
+    for (int n = 1; n <= D; ++n) {
+        launch_scatter_rows(m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, m->st_h[n].as<float>(), W, B, W, rows_per_line, m->stream);
+        launch_scatter_rows(m->cfin.as<float>() + (size_t)(n - 1) * B * W, W, m->st_c[n].as<float>(), W, B, W, rows_per_line, m->stream);
+    }
+    HIPCHK(hipMemsetAsync(m->d_step.p, 0, 16, m->stream));
+    HIPCHK(hipMemsetAsync(m->d_nan.p, 0, 16, m->stream));
+    return 0;
+}
+
+// One decoder_model step on R rows (seq2seq.py:416-480).  beam=true reads the input rows from `pin`,
+// otherwise from the previous slot of the score store (the fed-back softmax, seq2seq.py:1252).
+static void launch_step(casv_model* m, bool beam, int mode, const int* line, int rows_per_line,
+                        int* o_idx, float* o_prob, const int* step_ptr, int step_imm) {
+    const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
+    const long long RW = (long long)R * W;
+    const int* prev = m->prev.as<int>();
+    {   // char_input_proj (seq2seq.py:319,418): y0 = p_in . E
+        GemmArgs g{};
+        g.nseg = 1;
+        g.a[0] = beam ? mkseg(m->pin.as<float>(), Vp, Vp, 0) : mkseg(m->st_p.as<float>(), Vp, Vp, 0, nullptr, (long long)R * Vp, 1, 0);
+        g.Bt = m->ETp.as<float>(); g.M = R; g.N = W; g.Ktot = Vp;
+        g.out = mkslot(m->y0.as<float>(), W);
+        g.step_ptr = step_ptr; g.step_imm = step_imm;
+        run_gemm(m, EPI_PLAIN, g);
+    }
+    auto xseg = [&](int n) {   // input of layer n = output of layer n-1 at this step
+        return n == 1 ? mkseg(m->y0.as<float>(), W, W, 0) : mkseg(m->st_h[n - 1].as<float>(), W, W, 0, nullptr, RW, 1, 1);
+    };
+    for (int n = 1; n < D; ++n) {
+        GemmArgs g{};
+        g.nseg = 2;
+        g.a[0] = xseg(n);
+        g.a[1] = mkseg(m->st_h[n].as<float>(), W, W, W, prev);
+        g.Bt = m->dec[n].wt.as<float>(); g.bias = m->dec[n].bias.as<float>();
+        g.M = R; g.N = 4 * W; g.Ktot = 2 * W;
+        g.out = mkslot(m->st_h[n].as<float>(), W, RW, 1, 1);
+        g.c_in = mkseg(m->st_c[n].as<float>(), W, W, 0, prev);
+        g.c_out = mkslot(m->st_c[n].as<float>(), W, RW, 1, 1);
+        g.step_ptr = step_ptr; g.step_imm = step_imm;
+        run_gemm(m, EPI_LSTM, g);
+    }
+    {   // attention query: h_{t-1} . W_a + b_UW (attention.py:539)
+        GemmArgs g{};
+        g.nseg = 1; g.a[0] = mkseg(m->st_h[D].as<float>(), W, W, 0, prev);
+        g.Bt = m->WaT.as<float>(); g.bias = m->bUW.as<float>(); g.M = R; g.N = W; g.Ktot = W;
+        g.out = mkslot(m->wq.as<float>(), W);
+        g.step_ptr = step_ptr; g.step_imm = step_imm;
+        run_gemm(m, EPI_PLAIN, g);
+    }
+    {
+        AttnArgs a{};
+        a.wq = m->wq.as<float>(); a.u = m->u.as<float>(); a.enc = m->enc_out; a.va = m->va.as<float>(); a.bv = m->bv.as<float>();
+        a.a_base = m->st_a.as<float>(); a.prev = prev; a.line = line; a.rows_per_line = rows_per_line;
+        a.ctx = m->ctx.as<float>(); a.R = R; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
+        a.step_ptr = step_ptr; a.step_imm = step_imm; a.apos = m->apos.as<double>(); a.amax1 = m->amax1.as<int>(); a.nrows = nullptr;
+        hipEvent_t ev{};
+        const double win = 2.0 * m->cfg.window_width + 1;
+        m->prof_begin(PC_ATTN, (double)R * win * (4.0 * W + 2.0 * C), 4.0 * R * (win * (W + C) + W + 2.0 * T + C), ev);
+        launch_attention(a, m->stream);
+        m->prof_end(PC_ATTN, ev);
+    }
+    {   // top cell on [x | ctx] (attention.py:341-342, seq2seq.py:343-349)
+        GemmArgs g{};
+        g.nseg = 3;
+        g.a[0] = xseg(D);
+        g.a[1] = mkseg(m->ctx.as<float>(), C, C, W);
+        g.a[2] = mkseg(m->st_h[D].as<float>(), W, W, W + C, prev);
+        g.Bt = m->dec[D].wt.as<float>(); g.bias = m->dec[D].bias.as<float>();
+        g.M = R; g.N = 4 * W; g.Ktot = 2 * W + C;
+        g.out = mkslot(m->st_h[D].as<float>(), W, RW, 1, 1);
+        g.c_in = mkseg(m->st_c[D].as<float>(), W, W, 0, prev);
+        g.c_out = mkslot(m->st_c[D].as<float>(), W, RW, 1, 1);
+        g.step_ptr = step_ptr; g.step_imm = step_imm;
+        run_gemm(m, EPI_LSTM, g);
+    }
+    {   // tied output projection (seq2seq.py:379)
+        GemmArgs g{};
+        g.nseg = 1; g.a[0] = mkseg(m->st_h[D].as<float>(), W, W, 0, nullptr, RW, 1, 1);
+        g.Bt = m->E.as<float>(); g.M = R; g.N = V; g.Ktot = W;
+        g.out = mkslot(m->logits.as<float>(), Vp);
+        g.step_ptr = step_ptr; g.step_imm = step_imm;
+        run_gemm(m, EPI_PLAIN, g);
+    }
+    {
+        SoftmaxArgs a{};
+        a.logits = m->logits.as<float>(); a.p_base = m->st_p.as<float>(); a.R = R; a.V = V;
+        a.step_ptr = step_ptr; a.step_imm = step_imm; a.mode = mode; a.out_idx = o_idx; a.out_prob = o_prob; a.S = m->S;
+        a.nan_flag = m->d_nan.as<int>();
+        hipEvent_t ev{};
+        m->prof_begin(PC_SOFTMAX, 4.0 * R * V, 8.0 * R * V, ev);
+        launch_softmax(a, m->stream);
+        m->prof_end(PC_SOFTMAX, ev);
+    }
+}
+
+extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, const float* p_in,
+                                 const float* states_in, const float* a_in, float* probs, float* states_out,
+                                 float* a_out) {
+    if (!m || !line || !p_in || !states_in || !a_in) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->encoded) return fail(CASV_ERR_STATE, "casv_encode must run first");
+    if (R < 1) return fail(CASV_ERR_ARG, "R must be positive");
+    for (int r = 0; r < R; ++r) if (line[r] < 0 || line[r] >= m->B) return fail(CASV_ERR_ARG, "line[%d]=%d out of range", r, line[r]);
+    HIPCHK(hipSetDevice(m->device));
+    const int W = m->W, V = m->V, Vp = m->Vp, T = m->T, D = m->D;
+    if (int rc = ensure_session(m, R, 1)) return rc;
+    if (int rc = m->d_line.ensure((size_t)R * 4)) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_line.p, line, (size_t)R * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemsetAsync(m->st_p.p, 0, (size_t)R * Vp * 4, m->stream));
+    HIPCHK(hipMemsetAsync(m->logits.p, 0, (size_t)R * Vp * 4, m->stream));
+    HIPCHK(hipMemcpy2DAsync(m->st_p.p, (size_t)Vp * 4, p_in, (size_t)V * 4, (size_t)V * 4, R, hipMemcpyHostToDevice, m->stream));
+    for (int n = 1; n <= D; ++n) {
+        HIPCHK(hipMemcpyAsync(m->st_h[n].p, states_in + (size_t)(2 * n - 2) * R * W, (size_t)R * W * 4, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(m->st_c[n].p, states_in + (size_t)(2 * n - 1) * R * W, (size_t)R * W * 4, hipMemcpyHostToDevice, m->stream));
+    }
+    HIPCHK(hipMemcpyAsync(m->st_a.p, a_in, (size_t)R * T * 4, hipMemcpyHostToDevice, m->stream));
+    launch_fill_prev(m->prev.as<int>(), R, 0, nullptr, m->stream);
+    launch_step(m, false, -1, m->d_line.as<int>(), 1, nullptr, nullptr, nullptr, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (probs) HIPCHK(hipMemcpy2D(probs, (size_t)V * 4, m->st_p.as<float>() + (size_t)R * Vp, (size_t)Vp * 4, (size_t)V * 4, R, hipMemcpyDeviceToHost));
+    if (states_out)
+        for (int n = 1; n <= D; ++n) {
+            HIPCHK(hipMemcpy(states_out + (size_t)(2 * n - 2) * R * W, m->st_h[n].as<float>() + (size_t)R * W, (size_t)R * W * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(states_out + (size_t)(2 * n - 1) * R * W, m->st_c[n].as<float>() + (size_t)R * W, (size_t)R * W * 4, hipMemcpyDeviceToHost));
+        }
+    if (a_out) HIPCHK(hipMemcpy(a_out, m->st_a.as<float>() + (size_t)R * T, (size_t)R * T * 4, hipMemcpyDeviceToHost));
+    return CASV_OK;
+}
+
+// Runs iterations of `body` (which launches one step reading *d_step) eagerly, or as replays of ONE
+// hipGraph captured at the first call (every pointer in a step is static; only *d_step moves).
+struct StepRunner {
+    casv_model* m; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    explicit StepRunner(casv_model* m_) : m(m_) {}
+    template <class F> int run(int n, F body) {
+        if (m->use_graph && !m->prof.on) {
+            if (!exec) {
+                HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+                body();
+                launch_advance_step(m->d_step.as<int>(), m->stream);
+                HIPCHK(hipStreamEndCapture(m->stream, &graph));
+                HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            }
+            for (int s = 0; s < n; ++s) HIPCHK(hipGraphLaunch(exec, m->stream));
+            return 0;
+        }
+        for (int s = 0; s < n; ++s) {
+            body();
+            launch_advance_step(m->d_step.as<int>(), m->stream);
+        }
+        return 0;
+    }
+    ~StepRunner() {
+        if (exec) { (void)hipStreamSynchronize(m->stream); (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); }
+    }
+};
+
+extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_t* out_idx, float* out_prob,
+                                  int32_t* out_len, float* out_align) {
+    if (!m || !out_idx || !out_prob) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->encoded) return fail(CASV_ERR_STATE, "casv_encode must run first");
+    if (mode != 0 && mode != 1) return fail(CASV_ERR_ARG, "mode must be 0 or 1");
+    if (S < 1 || S > 1024) return fail(CASV_ERR_ARG, "S=%d out of range", S);
+    HIPCHK(hipSetDevice(m->device));
+    const int B = m->B, T = m->T;
+    if (int rc = ensure_session(m, B, S)) return rc;
+    if (int rc = m->o_idx.ensure((size_t)B * S * 4)) return rc;
+    if (int rc = m->o_prob.ensure((size_t)B * S * 4)) return rc;
+    if (int rc = init_root(m, 1)) return rc;
+    HIPCHK(hipMemsetAsync(m->o_idx.p, 0, (size_t)B * S * 4, m->stream));
+    HIPCHK(hipMemsetAsync(m->o_prob.p, 0, (size_t)B * S * 4, m->stream));
+    const int* sp = m->d_step.as<int>();
+    {
+        StepRunner runner(m);
+        if (int rc = runner.run(S, [&]() {
+                launch_fill_prev(m->prev.as<int>(), B, 0, sp, m->stream);
+                launch_step(m, false, mode, nullptr, 1, m->o_idx.as<int>(), m->o_prob.as<float>(), sp, 0);
+            })) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_idx, m->o_idx.p, (size_t)B * S * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(out_prob, m->o_prob.p, (size_t)B * S * 4, hipMemcpyDeviceToHost, m->stream));
+    int nanflag = 0;
+    HIPCHK(hipMemcpyAsync(&nanflag, m->d_nan.p, 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (out_len)
+        for (int b = 0; b < B; ++b) {
+            int len = S;
+            if (mode == 1) for (int s = 0; s < S; ++s) if (out_idx[(size_t)b * S + s] == 1) { len = s + 1; break; }
+            out_len[b] = len;
+        }
+    if (out_align) {   // store_a slot s+1 row b -> (b, s, :)
+        for (int s = 0; s < S; ++s)
+            HIPCHK(hipMemcpy2DAsync(out_align + (size_t)s * T, (size_t)S * T * 4, m->st_a.as<float>() + (size_t)(s + 1) * B * T,
+                                    (size_t)T * 4, (size_t)T * 4, B, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    if (m->prof.on) m->prof.collect();
+    if (nanflag && mode == 1) return fail(CASV_ERR_NAN, "All-NaN slice encountered");
+    return CASV_OK;
+}
+
+extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32_t S, int32_t* out_idx, float* out_prob,
+                                int32_t* out_len, double* out_score, int32_t* out_rej, float* out_align,
+                                int32_t* n_found, int32_t* n_steps) {
+    if (!m || !bp || !out_idx || !out_prob || !out_len || !out_score || !n_found) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->encoded) return fail(CASV_ERR_STATE, "casv_encode must run first");
+    const int N = bp->batch_size, CM = bp->beam_width_in + 1;
+    if (N < 1 || N > 256) return fail(CASV_ERR_ARG, "batch_size (hypotheses per step) %d out of range 1..256", N);
+    if (bp->beam_width_in < 1 || bp->beam_width_in > 63) return fail(CASV_ERR_ARG, "beam_width_in %d out of range 1..63", bp->beam_width_in);
+    if ((long long)N * CM > 4096) return fail(CASV_ERR_ARG, "batch_size * (beam_width_in + 1) = %d exceeds 4096", N * CM);
+    if (bp->max_results < 1 || bp->max_results > 64) return fail(CASV_ERR_ARG, "max_results out of range 1..64");
+    if (S < 1 || S > 1024) return fail(CASV_ERR_ARG, "S=%d out of range", S);
+    HIPCHK(hipSetDevice(m->device));
+    const int B = m->B, T = m->T, R = B * N, MR = bp->max_results;
+    if (int rc = ensure_session(m, R, S)) return rc;
+    if (int rc = init_root(m, N)) return rc;
+    BeamState s{};
+    s.B = B; s.T = T; s.V = m->V; s.S = S; s.R = R;
+    s.node_cap = 1 + S * N * CM; s.q_cap = 2 * T * N; s.f_cap = 64;
+    const size_t NC = (size_t)B * s.node_cap;
+#define ENS(buf, bytes) if (int rc = (buf).ensure(bytes)) return rc;
+    ENS(m->b_parent, NC * 4) ENS(m->b_chr, NC * 4) ENS(m->b_prob, NC * 4) ENS(m->b_cum, NC * 8) ENS(m->b_len, NC * 4)
+    ENS(m->b_exp, NC * 4) ENS(m->b_k, NC * 4) ENS(m->b_rejpos, NC * 4) ENS(m->b_pos, NC * 8) ENS(m->b_is1, NC * 4)
+    ENS(m->b_count, (size_t)B * 4) ENS(m->b_created, (size_t)(S + 1) * R * CM * 2)
+    ENS(m->b_qkey, (size_t)2 * B * s.q_cap * 8) ENS(m->b_qid, (size_t)2 * B * s.q_cap * 4) ENS(m->b_qn, (size_t)2 * B * 4)
+    ENS(m->b_fkey, (size_t)B * s.f_cap * 8) ENS(m->b_fid, (size_t)B * s.f_cap * 4) ENS(m->b_fn, (size_t)B * 4) ENS(m->b_ftotal, (size_t)B * 4)
+    ENS(m->b_beamnode, (size_t)R * 4) ENS(m->b_nact, (size_t)B * 4) ENS(m->b_beam0, (size_t)B * 8) ENS(m->b_done, (size_t)B * 4)
+    ENS(m->b_steps, (size_t)B * 4) ENS(m->b_active, 16)
+    const size_t OR = (size_t)B * MR;
+    ENS(m->bo_idx, OR * S * 4) ENS(m->bo_prob, OR * S * 4) ENS(m->bo_len, OR * 4) ENS(m->bo_score, OR * 8) ENS(m->bo_rej, OR * S * 4)
+    ENS(m->bo_found, (size_t)B * 4) ENS(m->bo_nsteps, (size_t)B * 4)
+    if (out_align) ENS(m->bo_align, OR * S * T * 4)
+#undef ENS
+    s.n_parent = m->b_parent.as<int>(); s.n_chr = m->b_chr.as<int>(); s.n_prob = m->b_prob.as<float>();
+    s.n_cum = m->b_cum.as<double>(); s.n_len = m->b_len.as<int>(); s.n_exp = m->b_exp.as<int>(); s.n_k = m->b_k.as<int>();
+    s.n_rejpos = m->b_rejpos.as<int>(); s.n_pos = m->b_pos.as<double>(); s.n_is1 = m->b_is1.as<int>();
+    s.n_count = m->b_count.as<int>(); s.created = m->b_created.as<short>();
+    s.q_key = m->b_qkey.as<double>(); s.q_id = m->b_qid.as<int>(); s.q_n = m->b_qn.as<int>();
+    s.f_key = m->b_fkey.as<double>(); s.f_id = m->b_fid.as<int>(); s.f_n = m->b_fn.as<int>(); s.f_total = m->b_ftotal.as<int>();
+    s.beam_node = m->b_beamnode.as<int>(); s.nact = m->b_nact.as<int>(); s.beam0_key = m->b_beam0.as<double>();
+    s.line_done = m->b_done.as<int>(); s.line_steps = m->b_steps.as<int>(); s.active_lines = m->b_active.as<int>();
+    s.prev = m->prev.as<int>(); s.p_in = m->pin.as<float>(); s.p_base = m->st_p.as<float>();
+    s.apos = m->apos.as<double>(); s.amax1 = m->amax1.as<int>(); s.src_rej = m->d_srcrej.as<int>();
+    s.step_ptr = m->d_step.as<int>();
+    BeamParams p{};
+    p.N = N; p.width_in = bp->beam_width_in; p.width_out = bp->beam_width_out; p.max_results = MR;
+    p.threshold_in = bp->beam_threshold_in; p.rejection = bp->rejection_threshold; p.cost0 = bp->cost0;
+    if ((long long)(S + 1) * R >= (1LL << 31)) return fail(CASV_ERR_ARG, "search too large: (S+1)*B*N overflows int32");
+
+    launch_beam_init(s, p, m->stream);
+    const int* sp = m->d_step.as<int>();
+    auto body = [&]() {
+        launch_step(m, true, -1, nullptr, N, nullptr, nullptr, sp, 0);
+        hipEvent_t ev{};
+        m->prof_begin(PC_BEAM, 0.0, 4.0 * R * (2.0 * m->Vp), ev);
+        launch_beam_step(s, p, m->stream);
+        m->prof_end(PC_BEAM, ev);
+    };
+    // the host looks at the number of unfinished lines every `chunk` iterations
+    const int chunk = 16;
+    int done_steps = 0;
+    StepRunner runner(m);
+    while (done_steps < S) {
+        const int n = (S - done_steps) < chunk ? (S - done_steps) : chunk;
+        if (int rc = runner.run(n, body)) return rc;
+        done_steps += n;
+        int active = 0;
+        HIPCHK(hipMemcpyAsync(&active, m->b_active.p, 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (active <= 0) break;
+    }
+    BeamOut o{};
+    o.idx = m->bo_idx.as<int>(); o.prob = m->bo_prob.as<float>(); o.len = m->bo_len.as<int>(); o.score = m->bo_score.as<double>();
+    o.rejpos = m->bo_rej.as<int>(); o.align = out_align ? m->bo_align.as<float>() : nullptr; o.n_found = m->bo_found.as<int>();
+    o.n_steps = m->bo_nsteps.as<int>(); o.a_base = m->st_a.as<float>();
+    HIPCHK(hipMemsetAsync(m->bo_idx.p, 0, OR * S * 4, m->stream));
+    HIPCHK(hipMemsetAsync(m->bo_prob.p, 0, OR * S * 4, m->stream));
+    HIPCHK(hipMemsetAsync(m->bo_rej.p, 0xff, OR * S * 4, m->stream));
+    launch_beam_extract(s, p, o, m->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_idx, o.idx, OR * S * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(out_prob, o.prob, OR * S * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(out_len, o.len, OR * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(out_score, o.score, OR * 8, hipMemcpyDeviceToHost, m->stream));
+    if (out_rej) HIPCHK(hipMemcpyAsync(out_rej, o.rejpos, OR * S * 4, hipMemcpyDeviceToHost, m->stream));
+    if (out_align) HIPCHK(hipMemcpyAsync(out_align, o.align, OR * S * T * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(n_found, o.n_found, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    if (n_steps) HIPCHK(hipMemcpyAsync(n_steps, o.n_steps, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->prof.on) m->prof.collect();
+    return CASV_OK;
+}
+
+extern "C" int casv_profile(casv_model* m, int32_t enable) {
+    if (!m) return fail(CASV_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->prof.reset();
+    m->prof.on = enable != 0;
+    return CASV_OK;
+}
+
+extern "C" int casv_profile_read(casv_model* m, const char* name, int64_t* launches, double* total_ms, double* flops,
+                                 double* bytes) {
+    if (!m || !name) return fail(CASV_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->prof.collect();
+    for (int i = 0; i < PC_COUNT; ++i)
+        if (!strcmp(name, kProfNames[i])) {
+            if (launches) *launches = m->prof.launches[i];
+            if (total_ms) *total_ms = m->prof.ms[i];
+            if (flops) *flops = m->prof.flops[i];
+            if (bytes) *bytes = m->prof.bytes[i];
+            return CASV_OK;
+        }
+    return fail(CASV_ERR_ARG, "unknown kernel class '%s'", name);
+}
+
+extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
+    if (!m || !key) return fail(CASV_ERR_ARG, "null argument");
+    if (!strcmp(key, "graph")) { m->use_graph = value != 0; return CASV_OK; }
+    return fail(CASV_ERR_ARG, "unknown option '%s'", key);
+}
+
+extern "C" int casv_synchronize(casv_model* m) {
+    if (!m) return fail(CASV_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return CASV_OK;
+}

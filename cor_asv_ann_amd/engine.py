@@ -1,0 +1,174 @@
+"""Object wrapper over the C ABI (include/cor_asv_ann_hip.h): numpy in, numpy out.
+
+This is plumbing between the `Sequence2Sequence` facade and the HIP library; all arithmetic of
+the hot path happens in the library's kernels.
+"""
+import ctypes
+from ctypes import byref, c_double, c_int64, c_void_p
+
+import numpy as np
+
+from . import _native as nv
+
+
+def weight_shapes(depth, width, voc_size):
+    """Ordered {name: shape} of the model's tensors in Keras layout (layer creation
+    order of seq2seq.py:239-350 and attention.py:598-609)."""
+    d, W, V = depth, width, voc_size
+    C = 2 * W if d == 1 else W
+    shapes = {'E': (V, W)}
+    for direction in ('fw', 'bw'):
+        shapes['enc1_%s_K' % direction] = (W, 4 * W)
+        shapes['enc1_%s_R' % direction] = (W, 4 * W)
+        shapes['enc1_%s_b' % direction] = (4 * W,)
+    for n in range(2, d + 1):
+        shapes['enc%d_K' % n] = (2 * W if n == 2 else W, 4 * W)
+        shapes['enc%d_R' % n] = (W, 4 * W)
+        shapes['enc%d_b' % n] = (4 * W,)
+    shapes['att_U'] = (C, W)
+    for n in range(1, d):
+        shapes['dec%d_K' % n] = (W, 4 * W)
+        shapes['dec%d_R' % n] = (W, 4 * W)
+        shapes['dec%d_b' % n] = (4 * W,)
+    shapes['att_Wa'] = (W, W)
+    shapes['att_va'] = (W,)
+    shapes['att_bUW'] = (W,)
+    shapes['att_bv'] = (1,)
+    shapes['dec%d_K' % d] = (W + C, 4 * W)
+    shapes['dec%d_R' % d] = (W, 4 * W)
+    shapes['dec%d_b' % d] = (4 * W,)
+    return shapes
+
+
+class HipEngine(object):
+    """One model handle on one HIP device."""
+
+    def __init__(self, depth, width, voc_size, device=0, window_width=5, residual_connections=False,
+                 deep_bidirectional_encoder=False, bridge_dense=False, lm=False, stateful=False):
+        self.lib = nv.load()
+        self.depth, self.width, self.voc_size = int(depth), int(width), int(voc_size)
+        self.ctx_width = 2 * self.width if self.depth == 1 else self.width
+        cfg = nv.Config(self.depth, self.width, self.voc_size, int(window_width), int(bool(residual_connections)),
+                        int(bool(deep_bidirectional_encoder)), int(bool(bridge_dense)), int(bool(lm)),
+                        int(bool(stateful)))
+        handle = c_void_p()
+        nv.check(self.lib.casv_model_create(byref(cfg), int(device), byref(handle)))
+        self.handle = handle
+        self.shapes = weight_shapes(self.depth, self.width, self.voc_size)
+        self.B = self.T = 0
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.casv_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights -------------------------------------------------------------------------------
+    def set_weights(self, weights):
+        for name, shape in self.shapes.items():
+            if name not in weights:
+                raise KeyError('missing weight "%s"' % name)
+            a = nv.carray(weights[name], np.float32)
+            if tuple(a.shape) != tuple(shape) and a.size != int(np.prod(shape)):
+                raise ValueError('weight "%s" has shape %s, expected %s' % (name, a.shape, shape))
+            nv.check(self.lib.casv_set_weight(self.handle, name.encode(), nv.ptr(a), a.size))
+        nv.check(self.lib.casv_commit_weights(self.handle))
+
+    def get_weights(self):
+        out = {}
+        for name, shape in self.shapes.items():
+            a = np.empty(shape, np.float32)
+            nv.check(self.lib.casv_get_weight(self.handle, name.encode(), nv.ptr(a), a.size))
+            out[name] = a
+        return out
+
+    # -- encoder -------------------------------------------------------------------------------
+    def encode(self, idx, val=None, src_rej=None):
+        """idx int32 (B,T) or (B,T,A) with -1 for empty slots; val float32 same shape (default 1)."""
+        idx = nv.carray(idx, np.int32)
+        if idx.ndim == 2:
+            idx = idx[:, :, None]
+        idx = np.ascontiguousarray(idx)
+        B, T, A = idx.shape
+        if val is None:
+            val = np.ones(idx.shape, np.float32)
+        val = nv.carray(np.broadcast_to(np.asarray(val, np.float32).reshape(B, T, -1), idx.shape), np.float32)
+        if src_rej is None:
+            # argmax of each input row, -1 for all-zero rows (seq2seq.py:1458-1462)
+            masked = np.where(idx >= 0, val, -np.inf)
+            best = masked.max(axis=2, keepdims=True)
+            cand = np.where((masked == best) & (idx >= 0), idx, np.iinfo(np.int32).max)
+            src_rej = cand.min(axis=2)
+            anyval = ((idx >= 0) & (val != 0)).any(axis=2)
+            src_rej = np.where(anyval, src_rej, -1)
+        src_rej = nv.carray(src_rej, np.int32)
+        nv.check(self.lib.casv_encode(self.handle, B, T, A, nv.ptr(idx), nv.ptr(val), nv.ptr(src_rej)))
+        self.B, self.T = B, T
+
+    def encoder_outputs(self):
+        enc = np.empty((self.B, self.T, self.ctx_width), np.float32)
+        st = np.empty((2 * self.depth, self.B, self.width), np.float32)
+        nv.check(self.lib.casv_get_encoder_outputs(self.handle, nv.ptr(enc), nv.ptr(st)))
+        return enc, [st[i] for i in range(2 * self.depth)]
+
+    def decoder_step(self, line, p_in, states, a_in):
+        line = nv.carray(line, np.int32)
+        R = line.shape[0]
+        p_in = nv.carray(p_in, np.float32)
+        st = nv.carray(np.stack(states[:2 * self.depth]), np.float32)
+        a_in = nv.carray(a_in, np.float32)
+        probs = np.empty((R, self.voc_size), np.float32)
+        st_out = np.empty_like(st)
+        a_out = np.empty((R, self.T), np.float32)
+        nv.check(self.lib.casv_decoder_step(self.handle, R, nv.ptr(line), nv.ptr(p_in), nv.ptr(st), nv.ptr(a_in),
+                                            nv.ptr(probs), nv.ptr(st_out), nv.ptr(a_out)))
+        return probs, [st_out[i] for i in range(2 * self.depth)] + [a_out]
+
+    # -- decode loops --------------------------------------------------------------------------
+    def decode_greedy(self, mode=0, steps=None, want_align=False):
+        S = int(steps or 2 * self.T)
+        idx = np.empty((self.B, S), np.int32)
+        prob = np.empty((self.B, S), np.float32)
+        length = np.empty((self.B,), np.int32)
+        align = np.empty((self.B, S, self.T), np.float32) if want_align else None
+        nv.check(self.lib.casv_decode_greedy(self.handle, int(mode), S, nv.ptr(idx), nv.ptr(prob), nv.ptr(length),
+                                             nv.ptr(align)))
+        return idx, prob, length, align
+
+    def decode_beam(self, batch_size=8, beam_width_in=15, beam_threshold_in=0.2, beam_width_out=16,
+                    rejection_threshold=0.3, cost0=3.0, max_results=1, steps=None, want_align=False):
+        S = int(steps or 2 * self.T)
+        MR = int(max_results)
+        p = nv.BeamParams(int(batch_size), int(beam_width_in), int(beam_width_out), MR, float(beam_threshold_in),
+                          float(rejection_threshold or 0.0), float(cost0))
+        n = self.B * MR
+        out = {'idx': np.empty((n, S), np.int32), 'prob': np.empty((n, S), np.float32),
+               'len': np.empty((n,), np.int32), 'score': np.empty((n,), np.float64),
+               'rej': np.empty((n, S), np.int32),
+               'align': np.empty((n, S, self.T), np.float32) if want_align else None,
+               'n_found': np.empty((self.B,), np.int32), 'n_steps': np.empty((self.B,), np.int32)}
+        nv.check(self.lib.casv_decode_beam(self.handle, byref(p), S, nv.ptr(out['idx']), nv.ptr(out['prob']),
+                                           nv.ptr(out['len']), nv.ptr(out['score']), nv.ptr(out['rej']),
+                                           nv.ptr(out['align']), nv.ptr(out['n_found']), nv.ptr(out['n_steps'])))
+        return out
+
+    # -- measurement ---------------------------------------------------------------------------
+    def profile(self, enable=True):
+        nv.check(self.lib.casv_profile(self.handle, int(bool(enable))))
+
+    def profile_read(self, name):
+        launches, ms, fl, by = c_int64(), c_double(), c_double(), c_double()
+        nv.check(self.lib.casv_profile_read(self.handle, name.encode(), byref(launches), byref(ms), byref(fl),
+                                            byref(by)))
+        return {'launches': launches.value, 'ms': ms.value, 'flops': fl.value, 'bytes': by.value}
+
+    def set_option(self, key, value):
+        nv.check(self.lib.casv_set_option(self.handle, key.encode(), int(value)))
+
+    def synchronize(self):
+        nv.check(self.lib.casv_synchronize(self.handle))

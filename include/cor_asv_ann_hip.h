@@ -1,0 +1,128 @@
+/*
+ * cor_asv_ann_hip.h -- C ABI of the MI355X-native hot path of cor-asv-ann.
+ *
+ * The reference has no FFI: its hot path sits behind the Python class
+ * ocrd_cor_asv_ann/lib/seq2seq.py:13 `Sequence2Sequence`, which crosses into the
+ * Keras/TensorFlow runtime at `predict_on_batch` / `train_on_batch`.  This header is the
+ * boundary a maintainer binds (ctypes) in place of those crossings.
+ * Each entry point names the reference call site(s) it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative casv_status otherwise;
+ * the message is available from casv_last_error() (thread-local).  The caller owns all
+ * host buffers (C-contiguous, float32 / int32 / float64 as declared); the library owns
+ * all device memory and its HIP stream.  A handle is bound to one HIP device and is not
+ * thread-safe (the reference runs single-threaded: wrapper/transcode.py:46 max_workers=1).
+ * No C++ exceptions and no callbacks cross this boundary.
+ */
+#ifndef COR_ASV_ANN_HIP_H
+#define COR_ASV_ANN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    CASV_OK = 0,
+    CASV_ERR_ARG = -1,      /* bad argument / unsupported topology */
+    CASV_ERR_STATE = -2,    /* call order (e.g. decode before encode) */
+    CASV_ERR_HIP = -3,      /* HIP runtime failure */
+    CASV_ERR_NOMEM = -4,
+    CASV_ERR_NAN = -5       /* numpy would have raised "All-NaN slice" (seq2seq.py:1329,1335) */
+} casv_status;
+
+/* Topology of seq2seq.py:108-157.  The optional variants (residual_connections,
+ * deep_bidirectional_encoder, bridge_dense, lm_loss/lm_predict, stateful) must be 0:
+ * both published models use the default topology (wrapper/ocrd-tool.json:61-74). */
+typedef struct {
+    int32_t depth;          /* seq2seq.py:117 */
+    int32_t width;          /* seq2seq.py:115; must be a multiple of 32 */
+    int32_t voc_size;       /* seq2seq.py:123 */
+    int32_t window_width;   /* attention.py:515, seq2seq.py:347 (5) */
+    int32_t residual_connections, deep_bidirectional_encoder, bridge_dense, lm, stateful;
+} casv_config;
+
+/* Beam parameters of seq2seq.py:159-169 plus the constants of :1389-1397. */
+typedef struct {
+    int32_t batch_size;          /* N hypotheses per line per step (seq2seq.py:1414) */
+    int32_t beam_width_in;       /* seq2seq.py:164 */
+    int32_t beam_width_out;      /* seq2seq.py:169 */
+    int32_t max_results;         /* how many finished hypotheses to return per line (>=1) */
+    double  beam_threshold_in;   /* seq2seq.py:167 */
+    double  rejection_threshold; /* seq2seq.py:162 */
+    double  cost0;               /* seq2seq.py:1394 (3.0) */
+} casv_beam_params;
+
+typedef struct casv_model casv_model;
+
+const char* casv_last_error(void);
+int casv_device_count(void);
+const char* casv_version(void);
+
+/* Sequence2Sequence.configure() (seq2seq.py:190-489): allocate the weight set on a device. */
+int casv_model_create(const casv_config* cfg, int device_id, casv_model** out);
+void casv_model_destroy(casv_model* m);
+
+/* Keras set_weights/get_weights per tensor (seq2seq.py:1172, 509-523).  Names and shapes are
+ * those of SURVEY.md A.2: "E" (V,W); "enc1_fw_K|R|b", "enc1_bw_K|R|b"; "enc<n>_K|R|b";
+ * "att_U" (C,W); "dec<n>_K|R|b"; "att_Wa" (W,W), "att_va" (W), "att_bUW" (W), "att_bv" (1).
+ * Layout is Keras': kernels (in,4W) with gate blocks i,f,c,o; row-major float32. */
+int casv_set_weight(casv_model* m, const char* name, const float* data, int64_t count);
+int casv_get_weight(casv_model* m, const char* name, float* out, int64_t capacity);
+/* _resync_decoder() (seq2seq.py:526-528): repack the named tensors into the kernel layouts. */
+int casv_commit_weights(casv_model* m);
+
+/* encoder_model.predict_on_batch (seq2seq.py:403-406, 811, 1231).
+ * Input is the sparse form of vectorize_lines' (B,T,V) array (seq2seq.py:1059-1093): per
+ * position up to A (index, value) pairs, index < 0 = empty slot; a position with no pairs
+ * is true-zero padding.  src_rej[b*T+t] = argmax of that input row or -1 if it is all zero
+ * (what seq2seq.py:1458-1462 reads back during the beam search).
+ * Leaves enc_out, u = attention_dense(enc_out) and the initial decoder states on the device. */
+int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A,
+                const int32_t* idx, const float* val, const int32_t* src_rej);
+/* Copy the encoder outputs back (parity tests; mirrors the list encoder_model returns):
+ * enc_out (B,T,C); states (2*depth, B, W) ordered h1,c1,...,hd,cd.  Either may be NULL. */
+int casv_get_encoder_outputs(casv_model* m, float* enc_out, float* states);
+
+/* One decoder_model.predict_on_batch (seq2seq.py:477-480, 1245, 1321, 1428) on explicit
+ * inputs, for parity tests: R rows, `line[r]` selects the encoded line each row attends to.
+ * p_in (R,V); states_in (2*depth, R, W) + a_in (R,T)  ->  probs (R,V), states_out, a_out. */
+int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line,
+                      const float* p_in, const float* states_in, const float* a_in,
+                      float* probs, float* states_out, float* a_out);
+
+/* decode_batch_greedy (seq2seq.py:1215-1286; mode 0: argmax without index 0, S = 2T steps for
+ * all lines) and decode_sequence_greedy for every line at once (seq2seq.py:1288-1354; mode 1:
+ * argmax over all V with the index-0 NaN write-back, a line's steps after its '\n' are not
+ * reported).  out_idx/out_prob (B,S); out_len (B) = reported steps per line (mode 0: S);
+ * out_align (B,S,T) or NULL. */
+int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S,
+                       int32_t* out_idx, float* out_prob, int32_t* out_len, float* out_align);
+
+/* decode_sequence_beam (seq2seq.py:1356-1544) for all encoded lines at once.
+ * For result k < max_results of line b: out_idx/out_prob ((B*max_results), S) characters and
+ * probabilities, out_len length (incl. the final '\n'), out_score = cum_cost/(length-1)
+ * (seq2seq.py:1543), out_rej ((B*max_results), S) = source position if that step was a
+ * rejection candidate (one-hot alignment row, seq2seq.py:1495) else -1, out_align
+ * ((B*max_results), S, T) or NULL.  n_found (B) = finished hypotheses per line (0 = the
+ * generator would raise StopIteration, seq2seq.py:826); n_steps (B) = search iterations run. */
+int casv_decode_beam(casv_model* m, const casv_beam_params* p, int32_t S,
+                     int32_t* out_idx, float* out_prob, int32_t* out_len, double* out_score,
+                     int32_t* out_rej, float* out_align, int32_t* n_found, int32_t* n_steps);
+
+/* Measurement support for bench.py: per-kernel HIP-event timing on the library's stream.
+ * casv_profile(m, 1) starts recording, casv_profile_read returns, for kernel class `name`
+ * ("lstm_gemm", "gemm", "attention", "softmax", "beam", "embed"), the number of launches, their
+ * summed duration (ms) and their summed algorithmic FLOPs and bytes. */
+int casv_profile(casv_model* m, int32_t enable);
+int casv_profile_read(casv_model* m, const char* name, int64_t* launches, double* total_ms,
+                      double* flops, double* bytes);
+/* Replay the decode step through a captured hipGraph (1) or launch kernels eagerly (0). */
+int casv_set_option(casv_model* m, const char* key, int64_t value);
+int casv_synchronize(casv_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
