@@ -1,0 +1,638 @@
+"""`Sequence2Sequence` facade: the reference's Python API (ocrd_cor_asv_ann/lib/seq2seq.py:13-1544)
+on top of the HIP hot path.
+
+Same attributes, method names, argument meaning, return types and error behaviour as the reference
+class, so `cor-asv-ann-proc`, `cor-asv-ann-train`, `cor-asv-ann-repl` and the OCR-D processor
+(`wrapper/transcode.py:56-115`) keep working.  What differs is underneath: where the reference calls
+`encoder_model.predict_on_batch` / `decoder_model.predict_on_batch` once per character
+(seq2seq.py:1231,1245,1321,1428), this class hands index tensors to the C ABI once per batch and reads
+back finished strings.  There is no CPU fallback: without the HIP library every compute call raises.
+"""
+import logging
+import math
+import pickle
+import unicodedata
+
+import numpy as np
+
+from . import GAP
+from . import _native as nv
+from .engine import HipEngine, weight_shapes
+
+_UNSUPPORTED = ('residual_connections', 'deep_bidirectional_encoder', 'bridge_dense', 'lm_loss',
+                'lm_predict', 'scheduled_sampling', 'stateful')
+
+
+class Sequence2Sequence(object):
+    """Character-level encoder-attention-decoder corrector (API of seq2seq.py:13)."""
+
+    def __init__(self, logger=None, progbars=True, device=0):
+        # model parameters (seq2seq.py:108-132)
+        self.batch_size = 256
+        self.stateful = False
+        self.width = 512
+        self.depth = 2
+        self.mapping = ({'': 0}, {0: ''})
+        self.voc_size = 1
+        self.residual_connections = False
+        self.deep_bidirectional_encoder = False
+        self.bridge_dense = False
+        # training parameters (seq2seq.py:134-157)
+        self.epochs = 100
+        self.lm_loss = False
+        self.lm_predict = False
+        self.scheduled_sampling = None
+        self.dropout = 0.2
+        # beam decoder parameters (seq2seq.py:159-169)
+        self.rejection_threshold = 0.3
+        self.beam_width_in = 15
+        self.beam_threshold_in = 0.2
+        self.beam_width_out = 16
+        # runtime
+        self.logger = logger or logging.getLogger(__name__)
+        self.progbars = progbars
+        self.device = device
+        self.engine = None
+        self.status = 0   # empty / configured / trained (seq2seq.py:179)
+        self._weights = None
+        self.frozen_prefixes = []
+        self._dirty = True
+        self._rng = np.random.default_rng()
+
+    def __repr__(self):
+        return (__name__ + " (width: %d)" % self.width + " (depth: %d)" % self.depth +
+                " (chars: %d)" % self.voc_size + " (attention)" +
+                (" (stateful)" if self.stateful else " (stateless)") +
+                " status: %s" % ("empty" if self.status < 1 else "configured" if self.status < 2 else "trained"))
+
+    # ------------------------------------------------------------------------------------------
+    # configuration and weights
+    # ------------------------------------------------------------------------------------------
+    def configure(self, batch_size=None):
+        """Allocate the model for the current width/depth/voc_size with freshly initialised weights
+        (seq2seq.py:190-489).  Non-default topology variants are refused, not ignored."""
+        if batch_size:
+            self.batch_size = batch_size
+        for flag in _UNSUPPORTED:
+            if getattr(self, flag):
+                raise NotImplementedError('%s is not implemented in the MI355X hot path (only the default '
+                                          'topology of the published models is)' % flag)
+        self.logger.info('using HIP/gfx950 implementation to compile %s model of depth %d width %d size %d '
+                         'with attention', 'stateless', self.depth, self.width, self.voc_size)
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+        self._weights = self._initial_weights()
+        self._dirty = True      # the device copy is created / refreshed at the first compute call
+        self.status = 1
+
+    def _initial_weights(self):
+        """Keras default initialisers of the reference's layers: embedding N(0, 0.001^2)
+        (seq2seq.py:240), glorot_uniform kernels, orthogonal recurrent kernels, zero biases with
+        unit forget gate, glorot_uniform / zeros in the attention cell (attention.py:509-510)."""
+        rng = self._rng
+        W = self.width
+        out = {}
+        for name, shape in weight_shapes(self.depth, W, max(self.voc_size, 1)).items():
+            if name == 'E':
+                w = rng.standard_normal(shape) * 0.001
+            elif name.endswith('_R'):
+                a = rng.standard_normal(shape)
+                u, _, vt = np.linalg.svd(a, full_matrices=False)
+                w = u if u.shape == shape else vt
+            elif name.endswith('_b'):
+                w = np.zeros(shape)
+                w[W:2 * W] = 1.0
+            elif name in ('att_bUW', 'att_bv'):
+                w = np.zeros(shape)
+            else:
+                fan = (shape[0] + shape[1]) if len(shape) == 2 else (shape[0] + 1)
+                lim = math.sqrt(6.0 / fan)
+                w = rng.uniform(-lim, lim, shape)
+            out[name] = np.asarray(w, np.float32)
+        return out
+
+    def get_weights(self):
+        assert self.status >= 1
+        return {k: v.copy() for k, v in self._weights.items()}
+
+    def set_weights(self, weights):
+        """Install all tensors (Keras layout, names of engine.weight_shapes) and resync the device."""
+        assert self.status >= 1
+        shapes = weight_shapes(self.depth, self.width, self.voc_size)
+        new = {}
+        for name, shape in shapes.items():
+            a = np.asarray(weights[name], np.float32).reshape(shape)
+            new[name] = np.ascontiguousarray(a)
+        self._weights = new
+        self._dirty = True
+
+    def reset_encoder(self):
+        """Re-initialise the encoder tensors, keeping the decoder (the `--reset-encoder` option,
+        scripts/train.py:84-93)."""
+        fresh = self._initial_weights()
+        w = self.get_weights()
+        for name in w:
+            if name.startswith('enc') or name == 'att_U':
+                w[name] = fresh[name]
+        self.set_weights(w)
+
+    def _reconfigure_for_mapping(self):
+        """Grow the embedding after the vocabulary grew, keeping the rows already trained
+        (seq2seq.py:499-525)."""
+        assert self.status >= 1
+        old = self._weights
+        old_voc = old['E'].shape[0] if old is not None else 0
+        if old_voc < self.voc_size:
+            keep = self.status >= 2
+            status = self.status
+            self.configure()
+            if keep:
+                self.logger.warning('transferring weights from previous model with only %d character types', old_voc)
+                new = self.get_weights()
+                for name in new:
+                    if name == 'E':
+                        new['E'][:old_voc] = old['E']
+                    else:
+                        new[name] = old[name]
+                self.set_weights(new)
+                self.status = status
+
+    def save(self, filename):
+        """Store weights + configuration (seq2seq.py:1121-1141).  Container: numpy .npz with the
+        tensor names of SURVEY.md A.2 plus `config/*` entries (h5py is not available here; reading
+        the published Keras HDF5 files is the next item of SURVEY.md section 8f)."""
+        assert self.status > 1
+        self.logger.info('Saving model under "%s"', filename)
+        data = {k: v for k, v in self._weights.items()}
+        data['config/width'] = np.array(self.width)
+        data['config/depth'] = np.array(self.depth)
+        data['config/stateful'] = np.array(self.stateful)
+        data['config/residual_connections'] = np.array(self.residual_connections)
+        data['config/deep_bidirectional_encoder'] = np.array(self.deep_bidirectional_encoder)
+        data['config/bridge_dense'] = np.array(self.bridge_dense)
+        data['config/mapping'] = np.fromiter(
+            (ord(self.mapping[1][i]) if i in self.mapping[1] and self.mapping[1][i] else 0
+             for i in range(self.voc_size)), dtype=np.uint32)
+        with open(filename, 'wb') as f:
+            np.savez(f, **data)
+
+    def load_config(self, filename):
+        """seq2seq.py:1143-1162."""
+        with np.load(filename) as data:
+            self.width = int(data['config/width'])
+            self.depth = int(data['config/depth'])
+            self.stateful = bool(data['config/stateful'])
+            self.residual_connections = bool(data['config/residual_connections']) \
+                if 'config/residual_connections' in data else False
+            self.deep_bidirectional_encoder = bool(data['config/deep_bidirectional_encoder']) \
+                if 'config/deep_bidirectional_encoder' in data else False
+            self.bridge_dense = bool(data['config/bridge_dense']) if 'config/bridge_dense' in data else False
+            codes = data['config/mapping']
+        c_i = dict((chr(c), i) if c > 0 else ('', 0) for i, c in enumerate(codes))
+        i_c = dict((i, chr(c)) if c > 0 else (0, '') for i, c in enumerate(codes))
+        self.mapping = (c_i, i_c)
+        self.voc_size = len(c_i)
+
+    def load_weights(self, filename):
+        """seq2seq.py:1164-1174."""
+        assert self.status > 0
+        self.logger.info('Loading model from "%s"', filename)
+        with np.load(filename) as data:
+            self.set_weights({k: data[k] for k in weight_shapes(self.depth, self.width, self.voc_size)})
+        self.status = 2
+
+    def load_transfer_weights(self, filename):
+        """Initialise matching tensors from another (possibly shallower) model (seq2seq.py:1176-1213)."""
+        assert self.status > 0
+        assert self.depth > 1
+        with np.load(filename) as data:
+            src = {k: data[k] for k in data.files}
+        if 'config/mapping' in src:
+            codes = src['config/mapping']
+            self.mapping = (dict((chr(c), i) if c > 0 else ('', 0) for i, c in enumerate(codes)),
+                            dict((i, chr(c)) if c > 0 else (0, '') for i, c in enumerate(codes)))
+            self.voc_size = len(self.mapping[0])
+            self._reconfigure_for_mapping()
+        self.logger.info('Transferring model from "%s"', filename)
+        w = self.get_weights()
+        for name, arr in w.items():
+            if name in src and src[name].shape == arr.shape:
+                w[name] = src[name]
+        self.set_weights(w)
+        self.frozen_prefixes = []
+        if 'config/depth' in src and int(src['config/depth']) == self.depth - 1:
+            # layers taken over from a model one layer shallower stay fixed (seq2seq.py:1206-1211)
+            self.logger.info('fixing weights from shallower model')
+            self.frozen_prefixes = ['enc%d_' % i for i in range(1, self.depth)] + \
+                                   ['dec%d_' % i for i in range(1, self.depth)]
+        self.status = 1
+
+    # ------------------------------------------------------------------------------------------
+    # input layouts
+    # ------------------------------------------------------------------------------------------
+    def _index(self, char, what, i):
+        idx = self.mapping[0].get(char)
+        if idx is None:
+            if char != GAP:
+                self.logger.error('unmapped character "%s" at %s sequence %d', char, what, i)
+            return 0   # underspecification
+        return idx
+
+    def vectorize_lines(self, encoder_input_sequences, decoder_input_sequences, encoder_conf_sequences=None):
+        """Strings (or confidence lines / confusion networks) -> dense arrays, exactly the layouts of
+        seq2seq.py:1020-1119: (enc (B,T,V), dec_in (B,Tt+1,V), dec_out (B,Tt+1,V), weights (B,Tt+1))."""
+        assert len(encoder_input_sequences) == len(decoder_input_sequences)
+        idx, val, conf = self._sparse_lines(encoder_input_sequences, encoder_conf_sequences)
+        B, T, A = idx.shape
+        enc = np.zeros((B, T, self.voc_size), dtype=np.float32 if conf else np.uint32)
+        b, t, a = np.nonzero(idx >= 0)
+        enc[b, t, idx[b, t, a]] = val[b, t, a]       # later alternatives overwrite, as the reference's loop does
+        Tt = max(map(len, decoder_input_sequences))
+        dec_in = np.zeros((B, Tt + 1, self.voc_size), dtype=np.uint32)
+        dec_out = np.zeros((B, Tt + 1, self.voc_size), dtype=np.uint32)
+        for i, seq in enumerate(decoder_input_sequences):
+            for j, char in enumerate(seq):
+                k = self._index(char, 'decoder input', i)
+                dec_in[i, j + 1, k] = 1
+                dec_out[i, j, k] = 1
+        weights = np.ones(dec_out.shape[:-1], dtype=np.float32)
+        weights[np.all(dec_out == 0, axis=2)] = 0.
+        return enc, dec_in, dec_out, weights
+
+    def _sparse_lines(self, lines, conf=None):
+        """The same three input forms as index/value tensors (B,T,A), -1 = empty slot: this is what the
+        device consumes (the dense one-hot array of the reference is 4*V bytes per character)."""
+        B = len(lines)
+        with_confmat = bool(conf) and type(conf[0][0]) is list
+        if with_confmat:
+            seqs = conf
+            T = max(sum(max(len(x[0]) for x in chunk) if chunk else 0 for chunk in seq) for seq in seqs)
+            A = max([len(chunk) for seq in seqs for chunk in seq] + [1])
+        else:
+            T = max(map(len, lines))
+            A = 1
+        idx = np.full((B, T, A), -1, np.int32)
+        val = np.zeros((B, T, A), np.float32)
+        if with_confmat:
+            for i, seq in enumerate(seqs):
+                j = 0
+                for chunk in seq:
+                    width = max(len(x[0]) for x in chunk) if chunk else 0
+                    for a, (chars, p) in enumerate(chunk):
+                        for k, char in enumerate(chars):
+                            ci = self._index(char, 'encoder input', i)
+                            # a later alternative with the same index replaces the earlier one, as the
+                            # dense assignment of seq2seq.py:1079 does
+                            same = np.nonzero(idx[i, j + k, :a] == ci)[0]
+                            slot = int(same[0]) if len(same) else a
+                            idx[i, j + k, slot] = ci
+                            val[i, j + k, slot] = p
+                    j += width
+        else:
+            for i, line in enumerate(lines):
+                for j, char in enumerate(line):
+                    idx[i, j, 0] = self._index(char, 'encoder input', i)
+                    val[i, j, 0] = conf[i][j] if conf else 1.0
+        return idx, val, conf
+
+    @staticmethod
+    def _dense_to_sparse(data):
+        """(B,T,V) rows -> (idx, val) with A = the largest number of non-zeros of any row."""
+        data = np.asarray(data)
+        nz = data != 0
+        A = max(1, int(nz.sum(axis=2).max()) if data.size else 1)
+        order = np.argsort(~nz, axis=2, kind='stable')[:, :, :A]
+        picked = np.take_along_axis(nz, order, axis=2)
+        idx = np.where(picked, order, -1).astype(np.int32)
+        val = np.where(picked, np.take_along_axis(data, order, axis=2), 0).astype(np.float32)
+        return idx, val
+
+    # ------------------------------------------------------------------------------------------
+    # decoding
+    # ------------------------------------------------------------------------------------------
+    def _require_engine(self):
+        """The device model, created on first use and re-synchronised after weight changes
+        (the reference's `_resync_decoder`, seq2seq.py:526-528).  Raises if the HIP library or a
+        GPU is missing: there is no CPU fallback."""
+        assert self.status >= 1, 'configure() first'
+        if self.voc_size < 2:
+            raise RuntimeError('model has no vocabulary yet (load or train a model first)')
+        if self.engine is None:
+            self.engine = HipEngine(self.depth, self.width, self.voc_size, device=self.device)
+            self._dirty = True
+        if self._dirty:
+            self.engine.set_weights(self._weights)
+            self._dirty = False
+        return self.engine
+
+    def _chars(self, indexes):
+        i_c = self.mapping[1]
+        return ''.join(i_c[int(i)] for i in indexes)
+
+    def _greedy_results(self, idx, prob, align, nonpad):
+        """Per-line bookkeeping of seq2seq.py:1254-1263 on the index/probability matrices."""
+        B, S = idx.shape
+        lines, probs, scores, aligns = [], [], [], []
+        for j in range(B):
+            if not nonpad[j]:
+                lines.append(''); probs.append([]); scores.append(0.); aligns.append([])
+                continue
+            eos = np.nonzero(idx[j] == 1)[0]
+            n = int(eos[0]) + 1 if len(eos) else S
+            p = prob[j, :n]
+            lines.append(self._chars(idx[j, :n]))
+            probs.append(list(p))
+            with np.errstate(divide='ignore'):
+                scores.append(float(np.sum(-np.log(p), dtype=np.float64)) / n)
+            aligns.append([align[j, k] for k in range(n)] if align is not None else [])
+        return lines, probs, scores, aligns
+
+    def decode_batch_greedy(self, encoder_input_data):
+        """seq2seq.py:1215-1286: all lines at once, 2T steps, argmax without index 0, soft feedback.
+        Returns (decoder_output_data, strings, probability lists, scores, alignments)."""
+        eng = self._require_engine()
+        encoder_input_data = np.asarray(encoder_input_data)
+        idx, val = self._dense_to_sparse(encoder_input_data)
+        eng.encode(idx, val)
+        gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=True)
+        nonpad = (idx >= 0).any(axis=(1, 2))
+        lines, probs, scores, aligns = self._greedy_results(gi, gp, ga, nonpad)
+        B, T = encoder_input_data.shape[:2]
+        # the reference stores the fed-back softmax in a uint32 array (seq2seq.py:1237,1244): all zeros
+        decoder_output_data = np.zeros((B, 2 * T, self.voc_size), dtype=np.uint32)
+        return decoder_output_data, lines, probs, scores, aligns
+
+    def decode_sequence_greedy(self, source_seq=None, encoder_outputs=None):
+        """seq2seq.py:1288-1354 for one line given as a (T,V) array."""
+        eng = self._require_engine()
+        if source_seq is None:
+            raise ValueError('decode_sequence_greedy needs source_seq (device-resident encoder outputs '
+                             'are not exchangeable as arrays)')
+        idx, val = self._dense_to_sparse(np.asarray(source_seq)[None])
+        eng.encode(idx, val)
+        return self._sequence_greedy_results(eng, 1)[0]
+
+    def _sequence_greedy_results(self, eng, B):
+        try:
+            gi, gp, gl, ga = eng.decode_greedy(mode=1, want_align=True)
+        except nv.NativeError as err:
+            if err.code == nv.CASV_ERR_NAN:
+                raise ValueError('All-NaN slice encountered')   # what np.nanargmax raises, seq2seq.py:1335
+            raise
+        out = []
+        for j in range(B):
+            n = int(gl[j])
+            p = gp[j, :n]
+            with np.errstate(divide='ignore', invalid='ignore'):
+                score = float(np.sum(-np.log(p), dtype=np.float64)) / n
+            out.append((self._chars(gi[j, :n]), list(p), score, [ga[j, k] for k in range(n)]))
+        return out
+
+    def _beam_results(self, res, j, max_results, T):
+        for k in range(max_results):
+            r = j * max_results + k
+            n = int(res['len'][r])
+            if n == 0:
+                return
+            aligns = []
+            for s in range(n):
+                rp = int(res['rej'][r, s])
+                if res['align'] is not None:
+                    aligns.append(res['align'][r, s])
+                elif rp >= 0:
+                    aligns.append(np.eye(T, dtype=np.float32)[rp])
+                else:
+                    aligns.append(None)
+            yield (self._chars(res['idx'][r, :n]), list(res['prob'][r, :n]), float(res['score'][r]), aligns)
+
+    def _beam_kwargs(self):
+        return dict(batch_size=self.batch_size, beam_width_in=self.beam_width_in,
+                    beam_threshold_in=self.beam_threshold_in, beam_width_out=self.beam_width_out,
+                    rejection_threshold=self.rejection_threshold)
+
+    def decode_sequence_beam(self, source_seq=None, encoder_outputs=None):
+        """seq2seq.py:1356-1544: generator of (string, probabilities, score, alignments), best first.
+        The search itself runs on the device when the first result is requested."""
+        eng = self._require_engine()
+        if source_seq is None:
+            raise ValueError('decode_sequence_beam needs source_seq')
+        source_seq = np.asarray(source_seq)
+        idx, val = self._dense_to_sparse(source_seq[None])
+        eng.encode(idx, val)
+        res = eng.decode_beam(max_results=64, want_align=True, **self._beam_kwargs())
+        for item in self._beam_results(res, 0, 64, source_seq.shape[0]):
+            yield item
+
+    def correct_lines(self, lines, conf=None, fast=True, greedy=True, alignments=True):
+        """seq2seq.py:782-842.  Each line must end in a newline.  Returns (lines, probability lists,
+        scores, alignments).  `alignments=False` (an extension) skips copying the soft alignments."""
+        assert not fast or greedy, "cannot decode in fast mode with beam search enabled"
+        if not lines:
+            return [], [], [], []
+        eng = self._require_engine()
+        idx, val, _ = self._sparse_lines(lines, conf)
+        eng.encode(idx, val)
+        B, T = idx.shape[:2]
+        if fast:
+            gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=alignments)
+            nonpad = (idx >= 0).any(axis=(1, 2))
+            return self._greedy_results(gi, gp, ga, nonpad)
+        if greedy:
+            results = self._sequence_greedy_results(eng, B)
+            return self._finish(lines, [r if lines[j] else ('', [], 0, []) for j, r in enumerate(results)])
+        res = eng.decode_beam(max_results=1, want_align=alignments, **self._beam_kwargs())
+        results = []
+        for j, input_line in enumerate(lines):
+            if not input_line:
+                results.append(('', [], 0, []))
+                continue
+            item = next(self._beam_results(res, j, 1, T), None)
+            if item is None:
+                # the generator of the reference raises StopIteration here (seq2seq.py:826-836)
+                self.logger.error('cannot beam-decode input line %d: "%s"', j, input_line)
+                if isinstance(input_line[0], tuple):
+                    line = ''.join(chunk[0] for chunk in input_line)
+                if isinstance(input_line[0], list):
+                    line = ''.join(chunk[0][0] if chunk else '' for chunk in input_line)
+                else:
+                    line = input_line
+                item = (line, [1.0] * len(line), 0, np.eye(len(line)).tolist())
+            results.append(item)
+        return self._finish(lines, results)
+
+    @staticmethod
+    def _finish(lines, results):
+        out = ([], [], [], [])
+        for line, probs, score, alignment in results:
+            out[0].append(line.replace(GAP, ''))   # seq2seq.py:837
+            out[1].append(probs)
+            out[2].append(score)
+            out[3].append(alignment)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # file level
+    # ------------------------------------------------------------------------------------------
+    def predict(self, filenames, fast=False, greedy=False, charmap=None):
+        """seq2seq.py:756-780: generator of (filenames, lines, scores) per batch."""
+        assert self.status == 2
+        for batch in self.gen_lines(filenames, repeat=False, unsupervised=True, charmap=charmap):
+            lines_source, lines_sourceconf, _, lines_filename = batch
+            lines_result, _, scores_result, _ = self.correct_lines(
+                lines_source, lines_sourceconf, fast=fast, greedy=greedy, alignments=False)
+            yield (lines_filename, lines_result, scores_result)
+
+    def map_files(self, filenames):
+        """Collect the character set of the files and grow the mapping (seq2seq.py:555-588)."""
+        num_lines = 0
+        chars = set(self.mapping[0].keys())
+        for filename in filenames:
+            for source_text, source_conf, target_text in self._read_file(filename, unsupervised=False, keep_raw=True):
+                text = unicodedata.normalize('NFC', source_text + target_text)
+                chars.update(text)
+                if GAP in chars:
+                    self.logger.warning('ignoring gap character "%s" in input file "%s"', GAP, filename)
+                    chars.remove(GAP)
+                num_lines += 1
+        chars = sorted(chars)
+        if len(chars) > self.voc_size:
+            self.mapping = ({c: i for i, c in enumerate(chars)}, {i: c for i, c in enumerate(chars)})
+            self.voc_size = len(chars)
+            self._reconfigure_for_mapping()
+        return num_lines
+
+    @staticmethod
+    def _read_file(filename, unsupervised, keep_raw=False):
+        """Yield (source_text, source_conf or None, target_text) per line of a TSV or pickle file
+        (formats of seq2seq.py:936-972)."""
+        if filename.endswith('.pkl'):
+            with open(filename, 'rb') as f:
+                records = pickle.load(f)
+            for source, target_text in records:
+                if not source:
+                    source_text, source_conf = '', []
+                elif type(source[0]) is tuple:       # prob line
+                    chars, probs = zip(*source)
+                    source_text, source_conf = ''.join(chars), list(probs)
+                else:                                # confmat
+                    source_conf = source
+                    if keep_raw:
+                        source_text = ''.join(c for chunk in source for c, _ in chunk)
+                    else:
+                        source_text = ''.join(chunk[0][0] if chunk else '' for chunk in source)
+                if not keep_raw and not source_text.endswith('\n'):
+                    source_conf, source_text = [[('\n', 1.0)]], '\n'
+                yield source_text, source_conf, target_text
+        else:
+            with open(filename, 'r') as f:
+                for line in f:
+                    if keep_raw:
+                        yield line, None, ''
+                    elif unsupervised and '\t' not in line:
+                        yield line, None, line
+                    else:
+                        source_text, target_text = line.split('\t')
+                        yield source_text + '\n', None, target_text
+
+    def gen_lines(self, filenames, repeat=True, split=None, train=False, unsupervised=False, charmap=None):
+        """Batches of (source lines, source confidences or None, target lines, filenames)
+        (seq2seq.py:919-1018).  `repeat` loops over the files yielding False after every pass;
+        otherwise the last partial batch is padded with '' / None."""
+        split_ratio = 0.2
+        table = str.maketrans(charmap) if charmap else None
+        epoch = 0
+        while True:
+            src, cnf, tgt, names = [], [], [], []
+            with_confidence = False
+            for filename in filenames:
+                with_confidence = filename.endswith('.pkl')
+                for line_no, (s, c, t) in enumerate(self._read_file(filename, unsupervised)):
+                    if isinstance(split, np.ndarray) and (split[line_no] < split_ratio) == train:
+                        continue      # this line belongs to the other (train/validation) generator
+                    if unsupervised:
+                        t = s
+                    if table:
+                        s, t = s.translate(table), t.translate(table)
+                    s = unicodedata.normalize('NFC', s)
+                    t = unicodedata.normalize('NFC', t)
+                    if train and self._is_bad_pair(s, t):
+                        if epoch == 0:
+                            self.logger.debug('ignoring bad line "%s\t%s"', s.rstrip(), t.rstrip())
+                        continue
+                    src.append(s); tgt.append(t); names.append(filename)
+                    if with_confidence:
+                        cnf.append(c)
+                    if len(src) == self.batch_size:
+                        yield (src, cnf if with_confidence else None, tgt, names)
+                        src, cnf, tgt, names = [], [], [], []
+            epoch += 1
+            if repeat:
+                yield False
+            else:
+                if src:
+                    pad = self.batch_size - len(src)
+                    src.extend(pad * ['']); tgt.extend(pad * [''])
+                    if with_confidence:
+                        cnf.extend(pad * [[]])
+                    names.extend(pad * [None])
+                    yield (src, cnf if with_confidence else None, tgt, names)
+                break
+
+    @staticmethod
+    def _is_bad_pair(source_text, target_text):
+        """Training filter for hopeless OCR lines.  The reference delegates to
+        `Alignment.is_bad()` (lib/alignment.py:160-163, out of scope here); this stand-in uses the
+        standard-library matcher ratio with the same intent."""
+        import difflib
+        if not source_text or not target_text:
+            return True
+        return difflib.SequenceMatcher(a=source_text, b=target_text, autojunk=False).ratio() < 0.5
+
+    def evaluate(self, filenames, fast=False, normalization='historic_latin', charmap=None, gt_level=1,
+                 confusion=10, histogram=True):
+        raise NotImplementedError('evaluate() depends on lib/alignment.py (CER/WER metrics), which is outside the '
+                                  'hot path this package replaces; feed correct_lines() output to the reference\'s '
+                                  'Alignment/Edits classes instead')
+
+    def train(self, filenames, val_filenames=None):
+        from .training import train_files
+        return train_files(self, filenames, val_filenames)
+
+
+class Node(object):
+    """Host-side view of one beam hypothesis (seq2seq.py:1546-1608).  The search itself keeps its
+    trie on the device; this class exists for API compatibility of `lib/__init__.py:8`."""
+
+    def __init__(self, state, value, scores, cost, parent=None, prob=1.0, alignment=None, length0=None, cost0=None):
+        self.value = value
+        self.parent = parent
+        self.state = state
+        self.cum_cost = parent.cum_cost + cost if parent else cost
+        self.length = 1 if parent is None else parent.length + 1
+        self.length0 = length0 or (parent.length0 if parent else 1)
+        self.cost0 = cost0 or (parent.cost0 if parent else 0)
+        self.prob = prob
+        self.scores = scores
+        self.alignment = (parent.alignment if parent else []) if alignment is None else alignment
+
+    def to_sequence(self):
+        seq, cur = [], self
+        while cur:
+            seq.insert(0, cur)
+            cur = cur.parent
+        return seq
+
+    def __str__(self):
+        return ''.join(n.value for n in self.to_sequence()[1:])
+
+    def pro_cost(self):
+        return - (self.cum_cost + self.cost0 * abs(self.length - self.length0))
+
+    def __lt__(self, other): return self.pro_cost() < other.pro_cost()
+    def __le__(self, other): return self.pro_cost() <= other.pro_cost()
+    def __eq__(self, other): return self.pro_cost() == other.pro_cost()
+    def __ne__(self, other): return self.pro_cost() != other.pro_cost()
+    def __gt__(self, other): return self.pro_cost() > other.pro_cost()
+    def __ge__(self, other): return self.pro_cost() >= other.pro_cost()
+    __hash__ = object.__hash__

@@ -1,0 +1,68 @@
+"""Line sharding across the GPUs of one node.
+
+Lines are independent at inference (no cross-line state, seq2seq.py:113 `stateful=False`), so the
+path shards with no data-path collective: every rank holds a replica of the weights, decodes a
+contiguous range of lines on its own GPU, and one all-gather of fixed-width result records
+(RCCL over xGMI when the backend is "nccl") makes the decoded lines available everywhere.
+"""
+import numpy as np
+
+
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous [lo, hi) of rank's share; the first `n_items % world_size` ranks get one more."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def record_width(steps):
+    return 2 * steps + 4
+
+
+def pack_records(idx, prob, length, score, found=None):
+    """(n,S) int32 characters, (n,S) float32 probabilities, (n,) lengths, (n,) float64 scores
+    -> (n, 2S+4) int32 records (floats travel as their bit patterns)."""
+    idx = np.ascontiguousarray(idx, np.int32)
+    n, S = idx.shape
+    rec = np.zeros((n, record_width(S)), np.int32)
+    rec[:, :S] = idx
+    rec[:, S:2 * S] = np.ascontiguousarray(prob, np.float32).view(np.int32)
+    rec[:, 2 * S] = np.asarray(length, np.int32)
+    rec[:, 2 * S + 1:2 * S + 3] = np.ascontiguousarray(score, np.float64).reshape(n, 1).view(np.int32)
+    rec[:, 2 * S + 3] = 1 if found is None else np.asarray(found, np.int32)
+    return rec
+
+
+def unpack_records(rec):
+    rec = np.ascontiguousarray(rec, np.int32)
+    S = (rec.shape[1] - 4) // 2
+    idx = rec[:, :S].copy()
+    prob = rec[:, S:2 * S].copy().view(np.float32)
+    length = rec[:, 2 * S].copy()
+    score = rec[:, 2 * S + 1:2 * S + 3].copy().view(np.float64).reshape(-1)
+    found = rec[:, 2 * S + 3].copy()
+    return idx, prob, length, score, found
+
+
+def all_gather_records(rec, n_total, device=None, group=None):
+    """All-gather every rank's records into the (n_total, width) array in line order.  Shards are
+    padded to the size of the largest one because all_gather needs equal shapes."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = -(-n_total // world)
+    width = rec.shape[1]
+    mine = torch.zeros((per, width), dtype=torch.int32, device=device or 'cpu')
+    mine[:rec.shape[0]] = torch.from_numpy(np.ascontiguousarray(rec)).to(mine.device)
+    out = torch.empty((world * per, width), dtype=torch.int32, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    out = out.cpu().numpy().reshape(world, per, width)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, world, r)
+        parts.append(out[r, :hi - lo])
+    return np.concatenate(parts, axis=0)
+
+
+def records_to_strings(idx, length, i_c):
+    return [''.join(i_c[int(c)] for c in idx[j, :int(length[j])]) for j in range(idx.shape[0])]

@@ -1,0 +1,151 @@
+"""Host-side logic and the C-ABI surface, without a GPU: the library loads and exports every symbol
+the header declares, and the facade's input layouts / file readers / containers behave like the
+reference's (seq2seq.py:555-588, 919-1119, 1121-1162)."""
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from cor_asv_ann_amd import _native as nv
+from cor_asv_ann_amd.seq2seq import Sequence2Sequence, Node
+from cor_asv_ann_amd.engine import weight_shapes
+from oracle import ModelConfig, make_vocabulary, weight_names
+from oracle.decode import OracleModel, vectorize_lines
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'cor_asv_ann_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(casv_[a-z_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nv.load()
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), name
+        assert name in nv.SIGNATURES, 'no ctypes signature for %s' % name
+    assert lib.casv_version().startswith(b'cor_asv_ann_amd')
+
+
+def test_no_gpu_means_loud_failure():
+    lib = nv.load()
+    if lib.casv_device_count() > 0:
+        pytest.skip('a GPU is present')
+    s2s = _small_model()
+    with pytest.raises(nv.NativeError):
+        s2s.correct_lines(['ab\n'])
+
+
+def test_weight_inventory_matches_oracle():
+    for d in (1, 2, 4):
+        cfg = ModelConfig(depth=d, width=64, voc_size=50)
+        assert list(weight_shapes(d, 64, 50).items()) == [(n, tuple(s)) for n, s in weight_names(cfg)]
+
+
+def _small_model(voc=12):
+    s2s = Sequence2Sequence()
+    s2s.depth, s2s.width = 2, 32
+    chars = ['', '\n'] + [chr(ord('a') + i) for i in range(voc - 2)]
+    s2s.mapping = ({c: i for i, c in enumerate(chars)}, {i: c for i, c in enumerate(chars)})
+    s2s.voc_size = voc
+    s2s.configure()
+    return s2s
+
+
+def test_vectorize_lines_equals_oracle_layouts():
+    s2s = _small_model()
+    om = OracleModel(ModelConfig(depth=2, width=32, voc_size=12), {}, mapping=s2s.mapping)
+    plain = (['abc\n', 'b\n', ''], ['abd\n', 'bb\n', ''], None)
+    prob = (['ab\n', 'c\n'], ['', ''], [[0.5, 0.25, 1.0], [0.75, 1.0]])
+    cm = [[[('a', 0.6), ('bc', 0.4)], [], [('\n', 1.0)]], [[('zz', 0.9), ('a\a', 0.1)], [('\n', 1.0)]]]
+    confmat = (cm, ['', ''], cm)
+    for enc_seqs, dec_seqs, conf in (plain, prob, confmat):
+        want = vectorize_lines(om, enc_seqs, dec_seqs, conf)
+        got = s2s.vectorize_lines(enc_seqs, dec_seqs, conf)
+        for a, b in zip(got, want):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+        # the sparse form the device consumes describes the same dense rows
+        idx, val = s2s._dense_to_sparse(want[0])
+        dense = np.zeros(want[0].shape, np.float32)
+        b_, t_, a_ = np.nonzero(idx >= 0)
+        dense[b_, t_, idx[b_, t_, a_]] = val[b_, t_, a_]
+        assert np.array_equal(dense, want[0].astype(np.float32))
+        idx2, val2, _ = s2s._sparse_lines(enc_seqs, conf)
+        dense2 = np.zeros(want[0].shape, np.float32)
+        b_, t_, a_ = np.nonzero(idx2 >= 0)
+        np.add.at(dense2, (b_, t_, idx2[b_, t_, a_]), val2[b_, t_, a_])
+        assert np.array_equal(dense2, want[0].astype(np.float32))
+
+
+def test_unsupported_topology_is_refused():
+    for flag in ('residual_connections', 'deep_bidirectional_encoder', 'bridge_dense', 'lm_loss', 'lm_predict',
+                 'stateful'):
+        s2s = Sequence2Sequence()
+        setattr(s2s, flag, True)
+        with pytest.raises(NotImplementedError):
+            s2s.configure()
+    s2s = Sequence2Sequence()
+    s2s.scheduled_sampling = 'linear'
+    with pytest.raises(NotImplementedError):
+        s2s.configure()
+
+
+def test_correct_lines_contract_without_device():
+    s2s = _small_model()
+    assert s2s.correct_lines([]) == ([], [], [], [])
+    with pytest.raises(AssertionError):
+        s2s.correct_lines(['a\n'], fast=True, greedy=False)
+
+
+def test_save_load_roundtrip(tmp_path):
+    s2s = _small_model()
+    s2s.status = 2
+    path = str(tmp_path / 'model.npz')
+    s2s.save(path)
+    other = Sequence2Sequence()
+    other.load_config(path)
+    assert (other.width, other.depth, other.voc_size) == (32, 2, 12) and other.mapping == s2s.mapping
+    other.configure()
+    other.load_weights(path)
+    assert other.status == 2
+    for k, v in s2s.get_weights().items():
+        assert np.array_equal(other.get_weights()[k], v)
+
+
+def test_gen_lines_and_map_files(tmp_path):
+    tsv = tmp_path / 'a.tsv'
+    tsv.write_text('abc\tabd\nb\tbb\ncab\tcab\n')
+    s2s = Sequence2Sequence()
+    s2s.depth, s2s.width, s2s.batch_size = 1, 32, 2
+    s2s.configure()
+    assert s2s.map_files([str(tsv)]) == 3
+    assert s2s.mapping[0][''] == 0 and s2s.voc_size == len(set('abcd\t\n')) + 1
+    batches = list(s2s.gen_lines([str(tsv)], repeat=False))
+    assert batches[0][0] == ['abc\n', 'b\n'] and batches[0][2] == ['abd\n', 'bb\n'] and batches[0][1] is None
+    assert batches[1][0] == ['cab\n', ''] and batches[1][3] == [str(tsv), None]      # padded last batch
+    gen = s2s.gen_lines([str(tsv)], repeat=True)
+    assert next(gen)[0] == ['abc\n', 'b\n'] and next(gen) is False                   # end-of-epoch signal
+    # unsupervised text without tabs: source == target
+    txt = tmp_path / 'b.txt'
+    txt.write_text('hello\n')
+    (src, conf, tgt, names), = list(s2s.gen_lines([str(txt)], repeat=False, unsupervised=True))
+    assert src[0] == tgt[0] == 'hello\n'
+    # pickled probability lines and confusion networks
+    pkl = tmp_path / 'c.pkl'
+    recs = [([('a', 0.9), ('b', 0.8), ('\n', 1.0)], 'ab\n'),
+            ([[('a', 0.6), ('bc', 0.4)], [('\n', 1.0)]], 'a\n')]
+    pkl.write_bytes(pickle.dumps(recs))
+    (src, conf, tgt, names), = list(s2s.gen_lines([str(pkl)], repeat=False))
+    assert src == ['ab\n', 'a\n'] and conf[0] == [0.9, 0.8, 1.0] and conf[1] == recs[1][0] and tgt == ['ab\n', 'a\n']
+
+
+def test_node_api():
+    root = Node(state=None, value='', scores=None, cost=0.0, length0=5, cost0=3.0)
+    child = Node(state=None, value='x', scores=None, cost=0.5, parent=root)
+    assert str(child) == 'x' and child.pro_cost() == -(0.5 + 3.0 * 3) and child > root
