@@ -290,10 +290,19 @@ class Sequence2Sequence(object):
                             val[i, j + k, slot] = p
                     j += width
         else:
+            # plain strings: one table lookup over all code points of the batch
+            keys, values = self._codepoint_table()
             for i, line in enumerate(lines):
-                for j, char in enumerate(line):
-                    idx[i, j, 0] = self._index(char, 'encoder input', i)
-                    val[i, j, 0] = conf[i][j] if conf else 1.0
+                if not line:
+                    continue
+                cps = np.frombuffer(line.encode('utf-32-le', 'surrogatepass'), dtype=np.uint32)
+                pos = np.minimum(np.searchsorted(keys, cps), len(keys) - 1)
+                hit = keys[pos] == cps
+                if not hit.all():
+                    for j in np.nonzero(~hit)[0]:
+                        self._index(line[int(j)], 'encoder input', i)      # logs like the reference
+                idx[i, :len(cps), 0] = np.where(hit, values[pos], 0)
+                val[i, :len(cps), 0] = conf[i] if conf else 1.0
         return idx, val, conf
 
     @staticmethod
@@ -326,9 +335,26 @@ class Sequence2Sequence(object):
             self._dirty = False
         return self.engine
 
+    def _codepoint_table(self):
+        """Sorted code points of the single-character vocabulary entries and their indices."""
+        mapping = self.mapping[0]
+        cached = getattr(self, '_cp_cache', None)
+        if cached is None or cached[0] is not mapping or cached[1] != len(mapping):
+            items = sorted((ord(c), i) for c, i in mapping.items() if len(c) == 1)
+            keys = np.array([k for k, _ in items] or [0], np.uint32)
+            values = np.array([v for _, v in items] or [0], np.int32)
+            out = np.zeros(max(self.voc_size, 1), np.uint32)
+            for i, c in self.mapping[1].items():
+                if len(c) == 1 and i < len(out):
+                    out[i] = ord(c)
+            self._cp_cache = (mapping, len(mapping), keys, values, out)
+            cached = self._cp_cache
+        return cached[2], cached[3]
+
     def _chars(self, indexes):
-        i_c = self.mapping[1]
-        return ''.join(i_c[int(i)] for i in indexes)
+        self._codepoint_table()
+        cps = self._cp_cache[4][np.asarray(indexes, np.int64)]
+        return cps[cps != 0].astype('<u4').tobytes().decode('utf-32-le', 'surrogatepass')
 
     def _greedy_results(self, idx, prob, align, nonpad):
         """Per-line bookkeeping of seq2seq.py:1254-1263 on the index/probability matrices."""
@@ -395,15 +421,7 @@ class Sequence2Sequence(object):
             n = int(res['len'][r])
             if n == 0:
                 return
-            aligns = []
-            for s in range(n):
-                rp = int(res['rej'][r, s])
-                if res['align'] is not None:
-                    aligns.append(res['align'][r, s])
-                elif rp >= 0:
-                    aligns.append(np.eye(T, dtype=np.float32)[rp])
-                else:
-                    aligns.append(None)
+            aligns = [res['align'][r, s] for s in range(n)] if res['align'] is not None else []
             yield (self._chars(res['idx'][r, :n]), list(res['prob'][r, :n]), float(res['score'][r]), aligns)
 
     def _beam_kwargs(self):
@@ -457,7 +475,7 @@ class Sequence2Sequence(object):
                     line = ''.join(chunk[0][0] if chunk else '' for chunk in input_line)
                 else:
                     line = input_line
-                item = (line, [1.0] * len(line), 0, np.eye(len(line)).tolist())
+                item = (line, [1.0] * len(line), 0, np.eye(len(line)).tolist() if alignments else [])
             results.append(item)
         return self._finish(lines, results)
 
