@@ -49,6 +49,7 @@ SIGNATURES = {
     'casv_profile': (c_int, [c_void_p, c_int32]),
     'casv_profile_read': (c_int, [c_void_p, c_char_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double),
                                   POINTER(c_double)]),
+    'casv_debug_gemm': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_double)]),
     'casv_set_option': (c_int, [c_void_p, c_char_p, c_int64]),
     'casv_synchronize': (c_int, [c_void_p]),
 }

@@ -45,7 +45,16 @@ struct GemmArgs {
 
 enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
 
+// Up to four independent GEMMs in one launch (blockIdx.y selects the job): the two directions of the
+// bidirectional encoder layer, or the (layer, time) cells on one anti-diagonal of the stacked encoder.
+constexpr int GEMM_MAX_JOBS = 4;
+struct GemmBatch {
+    GemmArgs g[GEMM_MAX_JOBS];
+    int count;
+};
+
 void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream);
+void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream);
 
 // ---- small kernels (decode_kernels.hip) ----
 struct AttnArgs {

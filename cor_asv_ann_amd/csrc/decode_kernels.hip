@@ -31,10 +31,23 @@ __device__ __forceinline__ float wave_max(float v) {
 //   ctx = sum_s a'[s] * enc[s]
 // ---------------------------------------------------------------------------------------------
 constexpr int MAXWIN = 11;
+constexpr int ATT_ROWS = 8;      // rows (waves) per workgroup: the N=8 hypotheses of one line share u/enc rows in L1
 
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+// tanh on the transcendental units (v_exp_f32 + v_rcp_f32): |error| <= ~2e-7 absolute.  The energies
+// need 11*W tanh per decoder row; libm's tanhf made this kernel VALU-bound at 5x the time.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    if (ax < 0.25f) {
+        const float x2 = x * x;
+        return x * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * (-0.0539682540f + x2 * 0.0218694885f))));
+    }
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ax * 2.88539008177792681472f));
+    return copysignf(t, x);
+}
+
+__global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wave;
+    const int r = blockIdx.x * ATT_ROWS + wave;
     const int nrows = a.nrows ? *a.nrows : a.R;
     if (r >= nrows) return;
     const int step = a.step_ptr ? *a.step_ptr : a.step_imm;
@@ -59,21 +72,38 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
     const int cnt = s_hi - s_lo + 1;            // <= MAXWIN
 
-    const float* wq = a.wq + (long long)r * W;
+    const float4* wq4 = reinterpret_cast<const float4*>(a.wq + (long long)r * W);
+    const float4* va4 = reinterpret_cast<const float4*>(a.va);
     const float* ub = a.u + ((long long)ln * T) * W;
     const float bv = a.bv[0];
+    const int W4 = W >> 2;
+    // The kernel is latency-bound (one decoder row per wave slot), so all window rows are requested
+    // together: loads are unconditional on clamped row indices, positions past the window get weight 0.
     float e[MAXWIN];
+#pragma unroll
+    for (int i = 0; i < MAXWIN; ++i) e[i] = 0.0f;
+    for (int j = lane; j < W4; j += 64) {
+        float4 uu[MAXWIN];
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i) {
+            int sidx = s_lo + i; sidx = sidx < T ? sidx : T - 1;
+            uu[i] = reinterpret_cast<const float4*>(ub + (long long)sidx * W)[j];
+        }
+        const float4 q = wq4[j], v = va4[j];
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i) {
+            e[i] += fast_tanh(q.x + uu[i].x) * v.x;
+            e[i] += fast_tanh(q.y + uu[i].y) * v.y;
+            e[i] += fast_tanh(q.z + uu[i].z) * v.z;
+            e[i] += fast_tanh(q.w + uu[i].w) * v.w;
+        }
+    }
     float denom = 0.0f;
 #pragma unroll
     for (int i = 0; i < MAXWIN; ++i) {
-        e[i] = 0.0f;
-        if (i < cnt) {
-            const float* us = ub + (long long)(s_lo + i) * W;
-            float part = 0.0f;
-            for (int j = lane; j < W; j += 64) part += tanhf(wq[j] + us[j]) * a.va[j];
-            e[i] = expf(wave_sum(part) + bv);
-            denom += e[i];
-        }
+        const float sc = wave_sum(e[i]) + bv;
+        e[i] = i < cnt ? expf(sc) : 0.0f;
+        denom += e[i];
     }
     const float nanv = __builtin_nanf("");
     float amax = 0.0f;
@@ -95,13 +125,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         aout[s] = v;
     }
     const float* eb = a.enc + ((long long)ln * T) * C;
-    float* ctx = a.ctx + (long long)r * C;
-    for (int c = lane; c < C; c += 64) {
-        float v = cnt <= 0 ? nanv : 0.0f;
+    float4* ctx4 = reinterpret_cast<float4*>(a.ctx + (long long)r * C);
+    const int C4 = C >> 2;
+    for (int c = lane; c < C4; c += 64) {
+        float4 x[MAXWIN];
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i) {
+            int sidx = s_lo + i; sidx = sidx < T ? sidx : T - 1;
+            x[i] = reinterpret_cast<const float4*>(eb + (long long)sidx * C)[c];
+        }
+        float4 v = cnt <= 0 ? make_float4(nanv, nanv, nanv, nanv) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < MAXWIN; ++i)
-            if (i < cnt) v += e[i] * eb[(long long)(s_lo + i) * C + c];
-        ctx[c] = v;
+            if (i < cnt) { v.x += e[i] * x[i].x; v.y += e[i] * x[i].y; v.z += e[i] * x[i].z; v.w += e[i] * x[i].w; }
+        ctx4[c] = v;
     }
     if (lane == 0) {
         if (a.apos) a.apos[r] = cnt <= 0 ? (double)nanv : pos;
@@ -110,7 +147,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 }
 
 void launch_attention(const AttnArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(attention_kernel, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(attention_kernel, dim3((a.R + ATT_ROWS - 1) / ATT_ROWS), dim3(64 * ATT_ROWS), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 using namespace casv;
 
@@ -82,7 +83,7 @@ struct casv_model {
     // encoder session
     int B = 0, T = 0, A = 0;
     bool encoded = false;
-    DevBuf d_idx, d_val, d_srcrej, x0, H1, Ha, Hb, cfin, hfin, u;
+    DevBuf d_idx, d_val, d_srcrej, x0, H1, Ha, Hb, Hc, cfin, hfin, u;
     float* enc_out = nullptr;
     // decode session
     int R = 0, S = 0;
@@ -166,7 +167,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
     DevBuf* bufs[] = {&m->E, &m->ETp, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
-        &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->cfin,
+        &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->Hc, &m->cfin,
         &m->hfin, &m->u, &m->st_a, &m->st_p, &m->y0, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
         &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->b_parent, &m->b_chr, &m->b_prob,
         &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos, &m->b_pos, &m->b_is1, &m->b_count, &m->b_created,
@@ -266,6 +267,22 @@ static SlotPtr mkslot(float* base, int ld, long long slot_stride = 0, int mul = 
     SlotPtr s; s.base = base; s.slot_stride = slot_stride; s.step_mul = mul; s.step_add = add; s.ld = ld; return s;
 }
 
+static void run_gemm_batch(casv_model* m, int epi, GemmBatch& b) {
+    hipEvent_t a{};
+    const int cls = epi == EPI_LSTM ? PC_LSTM : PC_GEMM;
+    double fl = 0, by = 0;
+    for (int j = 0; j < b.count; ++j) {
+        const GemmArgs& g = b.g[j];
+        int kact = 0;
+        for (int i = 0; i < g.nseg; ++i) kact += g.a[i].width;
+        fl += 2.0 * g.M * (double)g.N * kact;
+        by += 4.0 * ((double)g.M * kact + (double)g.N * kact + (double)g.M * g.N);
+    }
+    m->prof_begin(cls, fl, by, a);
+    launch_gemm_batch(epi, b, m->stream);
+    m->prof_end(cls, a);
+}
+
 static void run_gemm(casv_model* m, int epi, GemmArgs& g) {
     hipEvent_t a{};
     const int cls = epi == EPI_LSTM ? PC_LSTM : PC_GEMM;
@@ -292,8 +309,8 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
     if (int rc = m->d_srcrej.ensure(BT * 4)) return rc;
     if (int rc = m->x0.ensure(BT * W * 4)) return rc;
     if (int rc = m->H1.ensure(BT * 2 * W * 4)) return rc;
-    if (D >= 2) { if (int rc = m->Ha.ensure(BT * W * 4)) return rc; }
-    if (D >= 3) { if (int rc = m->Hb.ensure(BT * W * 4)) return rc; }
+    if (D == 2 || D == 3) { if (int rc = m->Ha.ensure(BT * W * 4)) return rc; }
+    if (D == 3) { if (int rc = m->Hb.ensure(BT * W * 4)) return rc; }
     if (int rc = m->cfin.ensure((size_t)(D + 1) * B * W * 4)) return rc;     // slot D: forward c of layer 1 (unused later)
     if (int rc = m->hfin.ensure((size_t)D * B * W * 4)) return rc;
     if (int rc = m->u.ensure(BT * W * 4)) return rc;
@@ -311,50 +328,72 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
 
     float* x0 = m->x0.as<float>(); float* H1 = m->H1.as<float>();
     float* cfin = m->cfin.as<float>();
-    // layer 1, both directions (seq2seq.py:272-281)
+    // layer 1 (seq2seq.py:272-281): the forward step at time t and the backward step at time T-1-t are
+    // independent -> one launch of two jobs
+    auto layer1_job = [&](int dir, int t) {
+        GemmArgs g{};
+        const LstmW& w = dir == 0 ? m->enc_fw : m->enc_bw;
+        const int mul = dir == 0 ? 1 : -1;
+        const int addx = dir == 0 ? 0 : T - 1, addh = dir == 0 ? -1 : T;
+        g.nseg = 2;
+        g.a[0] = mkseg(x0, T * W, W, 0, nullptr, W, mul, addx);
+        g.a[1] = mkseg(H1 + dir * W, T * 2 * W, W, W, nullptr, 2 * W, mul, addh, 1);
+        g.Bt = w.wt.as<float>(); g.bias = w.bias.as<float>();
+        g.M = B; g.N = 4 * W; g.Ktot = 2 * W;
+        g.out = mkslot(H1 + dir * W, T * 2 * W, 2 * W, mul, addx);
+        float* cb = cfin + (size_t)(dir == 0 ? D : 0) * B * W;
+        g.c_in = mkseg(cb, W, W, 0, nullptr, 0, 0, 0, 1);
+        g.c_out = mkslot(cb, W);
+        g.step_imm = t; g.step_ptr = nullptr;
+        return g;
+    };
     for (int t = 0; t < T; ++t) {
-        for (int dir = 0; dir < 2; ++dir) {
-            GemmArgs g{};
-            const LstmW& w = dir == 0 ? m->enc_fw : m->enc_bw;
-            const int mul = dir == 0 ? 1 : -1;
-            const int addx = dir == 0 ? 0 : T - 1, addh = dir == 0 ? -1 : T;
-            g.nseg = 2;
-            g.a[0] = mkseg(x0, T * W, W, 0, nullptr, W, mul, addx);
-            g.a[1] = mkseg(H1 + dir * W, T * 2 * W, W, W, nullptr, 2 * W, mul, addh, 1);
-            g.Bt = w.wt.as<float>(); g.bias = w.bias.as<float>();
-            g.M = B; g.N = 4 * W; g.Ktot = 2 * W;
-            g.out = mkslot(H1 + dir * W, T * 2 * W, 2 * W, mul, addx);
-            float* cb = cfin + (size_t)(dir == 0 ? D : 0) * B * W;
-            g.c_in = mkseg(cb, W, W, 0, nullptr, 0, 0, 0, 1);
-            g.c_out = mkslot(cb, W);
-            g.step_imm = t; g.step_ptr = nullptr;
-            run_gemm(m, EPI_LSTM, g);
-        }
+        GemmBatch b{};
+        b.g[0] = layer1_job(0, t); b.g[1] = layer1_job(1, t); b.count = 2;
+        run_gemm_batch(m, EPI_LSTM, b);
     }
     // backward final h = output at time 0 (seq2seq.py:280)
     launch_scatter_rows(H1 + W, T * 2 * W, m->hfin.as<float>(), W, B, W, 1, m->stream);
-    float* in = H1; int win = 2 * W;
-    float* outb = nullptr;
-    for (int n = 2; n <= D; ++n) {
-        outb = (n % 2 == 0) ? m->Ha.as<float>() : m->Hb.as<float>();
-        for (int t = 0; t < T; ++t) {
-            GemmArgs g{};
-            g.nseg = 2;
-            g.a[0] = mkseg(in, T * win, win, 0, nullptr, win, 1, 0);
-            g.a[1] = mkseg(outb, T * W, W, win, nullptr, W, 1, -1, 1);
-            g.Bt = m->enc[n].wt.as<float>(); g.bias = m->enc[n].bias.as<float>();
-            g.M = B; g.N = 4 * W; g.Ktot = win + W;
-            g.out = mkslot(outb, T * W, W, 1, 0);
-            float* cb = cfin + (size_t)(n - 1) * B * W;
-            g.c_in = mkseg(cb, W, W, 0, nullptr, 0, 0, 0, 1);
-            g.c_out = mkslot(cb, W);
-            g.step_imm = t;
-            run_gemm(m, EPI_LSTM, g);
-        }
-        launch_scatter_rows(outb + (size_t)(T - 1) * W, T * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1,
-                            m->stream);
-        in = outb; win = W;
+    // layers 2..D (seq2seq.py:283): cell (n, t) needs (n-1, t) and (n, t-1); the cells of one
+    // anti-diagonal k = t + (n-2) are independent -> one launch per diagonal (<= GEMM_MAX_JOBS cells,
+    // deeper stacks are cut into groups of GEMM_MAX_JOBS layers)
+    std::vector<float*> lout(D + 1, nullptr);
+    lout[1] = H1;
+    for (int n = 2; n <= D; ++n) lout[n] = (n % 2 == 0) ? m->Ha.as<float>() : m->Hb.as<float>();
+    if (D >= 4) {   // layers alternate between two buffers only when they run strictly one after another
+        if (int rc = m->Hc.ensure((size_t)(D - 1) * BT * W * 4)) return rc;
+        for (int n = 2; n <= D; ++n) lout[n] = m->Hc.as<float>() + (size_t)(n - 2) * BT * W;
     }
+    auto layer_job = [&](int n, int t) {
+        GemmArgs g{};
+        const int win = n == 2 ? 2 * W : W;
+        g.nseg = 2;
+        g.a[0] = mkseg(lout[n - 1], T * win, win, 0, nullptr, win, 1, 0);
+        g.a[1] = mkseg(lout[n], T * W, W, win, nullptr, W, 1, -1, 1);
+        g.Bt = m->enc[n].wt.as<float>(); g.bias = m->enc[n].bias.as<float>();
+        g.M = B; g.N = 4 * W; g.Ktot = win + W;
+        g.out = mkslot(lout[n], T * W, W, 1, 0);
+        float* cb = cfin + (size_t)(n - 1) * B * W;
+        g.c_in = mkseg(cb, W, W, 0, nullptr, 0, 0, 0, 1);
+        g.c_out = mkslot(cb, W);
+        g.step_imm = t;
+        return g;
+    };
+    for (int n0 = 2; n0 <= D; n0 += GEMM_MAX_JOBS) {
+        const int n1 = std::min(D, n0 + GEMM_MAX_JOBS - 1);
+        for (int k = 0; k < T + (n1 - n0); ++k) {
+            GemmBatch b{};
+            for (int n = n0; n <= n1; ++n) {
+                const int t = k - (n - n0);
+                if (t >= 0 && t < T) b.g[b.count++] = layer_job(n, t);
+            }
+            run_gemm_batch(m, EPI_LSTM, b);
+        }
+    }
+    for (int n = 2; n <= D; ++n)
+        launch_scatter_rows(lout[n] + (size_t)(T - 1) * W, T * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1,
+                            m->stream);
+    float* outb = lout[D];
     m->enc_out = D == 1 ? H1 : outb;
     // u = attention_dense(enc_out) once per line (seq2seq.py:313; the reference redoes it every step)
     {
@@ -732,6 +771,48 @@ extern "C" int casv_profile_read(casv_model* m, const char* name, int64_t* launc
             return CASV_OK;
         }
     return fail(CASV_ERR_ARG, "unknown kernel class '%s'", name);
+}
+
+// Measurement aid: time `iters` launches of one GEMM shape in isolation (random operands).
+extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K, int32_t gather,
+                               int32_t iters, double* ms_per_launch) {
+    if (!m || !ms_per_launch) return fail(CASV_ERR_ARG, "null argument");
+    if (K % 32 || (lstm && N % 128)) return fail(CASV_ERR_ARG, "K must be a multiple of 32 (and N of 128 for lstm)");
+    HIPCHK(hipSetDevice(m->device));
+    DevBuf A, Bt, bias, C, cst, rows;
+    if (int rc = A.ensure((size_t)M * K * 4)) return rc;
+    if (int rc = Bt.ensure((size_t)N * K * 4)) return rc;
+    if (int rc = bias.ensure((size_t)N * 4)) return rc;
+    if (int rc = C.ensure((size_t)M * N * 4)) return rc;
+    if (int rc = cst.ensure((size_t)M * N * 4)) return rc;
+    if (int rc = rows.ensure((size_t)M * 4)) return rc;
+    std::vector<float> h((size_t)std::max((size_t)M, (size_t)N) * K);
+    unsigned s = 12345u;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+    HIPCHK(hipMemcpy(A.p, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(Bt.p, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(bias.p, 0, (size_t)N * 4));
+    HIPCHK(hipMemset(cst.p, 0, (size_t)M * N * 4));
+    std::vector<int> hr(M);
+    for (int i = 0; i < M; ++i) hr[i] = gather ? (int)(((long long)i * 7919) % M) : i;
+    HIPCHK(hipMemcpy(rows.p, hr.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+    GemmArgs g{};
+    g.nseg = 1; g.a[0] = mkseg(A.as<float>(), K, K, 0, rows.as<int>());
+    g.Bt = Bt.as<float>(); g.bias = bias.as<float>(); g.M = M; g.N = N; g.Ktot = K;
+    g.out = mkslot(C.as<float>(), lstm ? N / 4 : N);
+    if (lstm) { g.c_in = mkseg(cst.as<float>(), N / 4, N / 4, 0, rows.as<int>()); g.c_out = mkslot(cst.as<float>() + (size_t)M * N / 2, N / 4); }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_gemm(lstm ? EPI_LSTM : EPI_PLAIN, g, m->stream);
+    HIPCHK(hipEventRecord(e0, m->stream));
+    for (int i = 0; i < iters; ++i) launch_gemm(lstm ? EPI_LSTM : EPI_PLAIN, g, m->stream);
+    HIPCHK(hipEventRecord(e1, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    *ms_per_launch = t / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    A.release(); Bt.release(); bias.release(); C.release(); cst.release(); rows.release();
+    return CASV_OK;
 }
 
 extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {

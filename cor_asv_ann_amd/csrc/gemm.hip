@@ -22,84 +22,110 @@ namespace casv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDW = BK + 4;
+constexpr int BM = 128, BN = 128, BK = 16, LDW = BK + 4;   // 80-B LDS rows: ds_read_b128 conflict-free
 constexpr int TILE_FLOATS = 128 * LDW;               // one operand tile
 constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each):
+// absolute error <= 2e-7, far inside the parity tolerance.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float ax = fabsf(x);
+    if (ax < 0.25f) {          // odd Taylor region: avoids the cancellation of 1 - 2/(1+e^2x)
+        const float x2 = x * x;
+        return x * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * (-0.0539682540f + x2 * 0.0218694885f))));
+    }
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp(2.0f * ax));
+    return copysignf(t, x);
+}
 
+// Software pipeline (per wave, so that ONE wave keeps its SIMD's matrix pipe busy and the two waves
+// of a SIMD do not have to be out of phase to cover each other):
+//   while the 32 MFMAs of tile kt run from fragment registers F[kt&1],
+//     F[(kt+1)&1] <- LDS[(kt+1)&1]   (10 ds_read_b128; that buffer was filled during kt-1)
+//     LDS[kt&1]   <- G               (tile kt+2, global loads issued during kt-1; the buffer's old
+//                                     content, tile kt, already sits in F[kt&1])
+//     G           <- global tile kt+3
+//   one barrier per tile.
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GemmArgs& g = batch.g[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int step = g.step_ptr ? *g.step_ptr : g.step_imm;
     const int nbn = (g.N + BN - 1) / BN;
     const int bn = blockIdx.x % nbn, bm = blockIdx.x / nbn;
     const int m0 = bm * BM, n0 = bn * BN;
-    if (m0 >= g.M) return;
+    if (m0 >= g.M || bm * nbn + bn >= ((g.M + BM - 1) / BM) * nbn) return;
 
-    const int r0 = tid >> 3, kc = tid & 7;
+    const int r0 = tid >> 2, kc = tid & 3;     // staging: rows r0, r0+64; floats [4kc, 4kc+4)
 
-    // per-segment row pointers of the four rows this thread stages (statically indexed: no scratch)
-    const float* ap0[4]; const float* ap1[4]; const float* ap2[4];
+    const float* ap0[2]; const float* ap1[2]; const float* ap2[2];
     int tiles0 = 0, tiles1 = 0, tiles2 = 0;
 #define CASV_SETUP_SEG(S, AP, TILES)                                                             \
     if (g.nseg > S && !(g.a[S].skip_first && step == 0)) {                                       \
         const Seg& sg = g.a[S];                                                                  \
         const float* base = sg.base + (long long)(step * sg.step_mul + sg.step_add) * sg.slot_stride; \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
-            int m = m0 + r0 + 32 * i; m = m < g.M ? m : g.M - 1;                                 \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                          \
+            int m = m0 + r0 + 64 * i; m = m < g.M ? m : g.M - 1;                                 \
             const int rid = sg.rows ? sg.rows[m] : m;                                            \
             AP[i] = base + (long long)rid * sg.ld + 4 * kc;                                      \
         }                                                                                        \
         TILES = sg.width / BK;                                                                   \
     } else {                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) AP[i] = nullptr;                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) AP[i] = nullptr;                           \
     }
     CASV_SETUP_SEG(0, ap0, tiles0)
     CASV_SETUP_SEG(1, ap1, tiles1)
     CASV_SETUP_SEG(2, ap2, tiles2)
 #undef CASV_SETUP_SEG
     const int c0 = tiles0, c1 = c0 + tiles1, ntiles = c1 + tiles2;
+    const int koff0 = g.a[0].koff, koff1 = g.a[1].koff, koff2 = g.a[2].koff;
 
-    const float* bp[4];
+    const float* bp[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int n = n0 + r0 + 32 * i; n = n < g.N ? n : g.N - 1;
+    for (int i = 0; i < 2; ++i) {
+        int n = n0 + r0 + 64 * i; n = n < g.N ? n : g.N - 1;
         bp[i] = g.Bt + (long long)n * g.Ktot + 4 * kc;
     }
 
-    f32x4 ra[4], rb[4];
+    f32x4 ga[2], gb[2];
     auto load_tile = [&](int kt) {
         int kb;
         if (kt < c0) {
             const int ko = kt * BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap0[i] + ko);
-            kb = g.a[0].koff + ko;
+            ga[0] = *reinterpret_cast<const f32x4*>(ap0[0] + ko); ga[1] = *reinterpret_cast<const f32x4*>(ap0[1] + ko);
+            kb = koff0 + ko;
         } else if (kt < c1) {
             const int ko = (kt - c0) * BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap1[i] + ko);
-            kb = g.a[1].koff + ko;
+            ga[0] = *reinterpret_cast<const f32x4*>(ap1[0] + ko); ga[1] = *reinterpret_cast<const f32x4*>(ap1[1] + ko);
+            kb = koff1 + ko;
         } else {
             const int ko = (kt - c1) * BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap2[i] + ko);
-            kb = g.a[2].koff + ko;
+            ga[0] = *reinterpret_cast<const f32x4*>(ap2[0] + ko); ga[1] = *reinterpret_cast<const f32x4*>(ap2[1] + ko);
+            kb = koff2 + ko;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i] + kb);
+        gb[0] = *reinterpret_cast<const f32x4*>(bp[0] + kb); gb[1] = *reinterpret_cast<const f32x4*>(bp[1] + kb);
     };
     auto store_tile = [&](int buf) {
         float* sa = smem + buf * 2 * TILE_FLOATS + r0 * LDW + 4 * kc;
         float* sb = sa + TILE_FLOATS;
+        *reinterpret_cast<f32x4*>(sa) = ga[0]; *reinterpret_cast<f32x4*>(sa + 64 * LDW) = ga[1];
+        *reinterpret_cast<f32x4*>(sb) = gb[0]; *reinterpret_cast<f32x4*>(sb + 64 * LDW) = gb[1];
+    };
+    const int a_off = (wave * 32 + l31) * LDW + 4 * lh;
+    const int b_off = TILE_FLOATS + l31 * LDW + 4 * lh;
+    struct Frag { f32x4 a[2]; f32x4 b[4][2]; };
+    auto read_frags = [&](Frag& f, int buf) {
+        const float* base = smem + buf * 2 * TILE_FLOATS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(sa + 32 * i * LDW) = ra[i];
-            *reinterpret_cast<f32x4*>(sb + 32 * i * LDW) = rb[i];
-        }
+        for (int j = 0; j < 2; ++j) f.a[j] = *reinterpret_cast<const f32x4*>(base + a_off + 8 * j);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) f.b[c][j] = *reinterpret_cast<const f32x4*>(base + b_off + c * 32 * LDW + 8 * j);
     };
 
     f32x16 acc[4];
@@ -107,35 +133,63 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j][i], f.b[c][j][i], acc[c], 0, 0, 0);
+    };
 
-    if (ntiles > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const bool more = kt + 1 < ntiles;
-        if (more) load_tile(kt + 1);
-        const float* As = smem + buf * 2 * TILE_FLOATS + (wave * 32 + l31) * LDW + 4 * lh;
-        const float* Bs = smem + buf * 2 * TILE_FLOATS + TILE_FLOATS + l31 * LDW + 4 * lh;
-        f32x4 af[4];
+    // LSTM: previous cell state of this lane's 16 (row, unit) elements, fetched under the main loop
+    float cpv[16];
+    if (EPI == EPI_LSTM) {
+        const bool czero = g.c_in.skip_first && step == 0;
+        const float* cin = g.c_in.base + (long long)(step * g.c_in.step_mul + g.c_in.step_add) * g.c_in.slot_stride;
+        const int u = bn * 32 + l31;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(As + 8 * j);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 bf = *reinterpret_cast<const f32x4*>(Bs + c * 32 * LDW + 8 * j);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][i], bf[i], acc[c], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            m = m < g.M ? m : g.M - 1;
+            cpv[r] = 0.0f;
+            if (!czero) {
+                const int rid = g.c_in.rows ? g.c_in.rows[m] : m;
+                cpv[r] = cin[(long long)rid * g.c_in.ld + u];
             }
         }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
     }
+
+    Frag f0, f1;
+    // prologue: LDS[0] <- tile 0, F0 <- LDS[0], LDS[1] <- tile 1, G <- tile 2
+    if (ntiles > 0) { load_tile(0); store_tile(0); }
+    if (ntiles > 1) load_tile(1);
+    __syncthreads();
+    if (ntiles > 0) read_frags(f0, 0);
+    if (ntiles > 1) store_tile(1);
+    if (ntiles > 2) load_tile(2);
+    __syncthreads();
+
+    // one pipelined tile step; FC = fragments of tile kt, FN = to be filled with tile kt+1
+#ifndef CASV_EXP
+#define CASV_EXP 0
+#endif
+#define CASV_TILE_STEP(FC, FN, KT)                                   \
+    {                                                                \
+        if (!(CASV_EXP & 4)) if ((KT) + 1 < ntiles) read_frags(FN, ((KT) + 1) & 1);       \
+        mma(FC);                                                     \
+        if (!(CASV_EXP & 8)) if ((KT) + 2 < ntiles) store_tile((KT) & 1);                 \
+        if (!(CASV_EXP & 1)) if ((KT) + 3 < ntiles) load_tile((KT) + 3);                  \
+        if (!(CASV_EXP & 2)) __syncthreads();                                             \
+    }
+    int kt = 0;
+    for (; kt + 1 < ntiles; kt += 2) {
+        CASV_TILE_STEP(f0, f1, kt)
+        CASV_TILE_STEP(f1, f0, kt + 1)
+    }
+    if (kt < ntiles) CASV_TILE_STEP(f0, f1, kt)
+#undef CASV_TILE_STEP
 
     // ---- epilogue ----
     if (EPI == EPI_PLAIN) {
@@ -156,25 +210,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const int u = bn * 32 + l31;     // hidden unit of this lane
         const float bi = g.bias[n0 + l31], bf_ = g.bias[n0 + 32 + l31];
         const float bg = g.bias[n0 + 64 + l31], bo = g.bias[n0 + 96 + l31];
-        const bool czero = g.c_in.skip_first && step == 0;
-        const float* cin = g.c_in.base + (long long)(step * g.c_in.step_mul + g.c_in.step_add) * g.c_in.slot_stride;
         float* cout = g.c_out.base + (long long)(step * g.c_out.step_mul + g.c_out.step_add) * g.c_out.slot_stride;
         float* hout = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m < g.M) {
-                float cprev = 0.0f;
-                if (!czero) {
-                    const int rid = g.c_in.rows ? g.c_in.rows[m] : m;
-                    cprev = cin[(long long)rid * g.c_in.ld + u];
-                }
+                const float cprev = cpv[r];
                 const float ig = sigmoidf_(acc[0][r] + bi);
                 const float fg = sigmoidf_(acc[1][r] + bf_);
-                const float gg = tanhf(acc[2][r] + bg);
+                const float gg = tanhf_(acc[2][r] + bg);
                 const float og = sigmoidf_(acc[3][r] + bo);
                 const float c2 = fg * cprev + ig * gg;
-                const float h2 = og * tanhf(c2);
+                const float h2 = og * tanhf_(c2);
                 cout[(long long)m * g.c_out.ld + u] = c2;
                 hout[(long long)m * g.out.ld + u] = h2;
             }
@@ -182,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 }
 
-void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream) {
+void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI_PLAIN>),
@@ -191,12 +239,23 @@ void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         attr_set = true;
     }
-    const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
-    const dim3 grid(nbm * nbn), block(256);
+    int blocks = 0;
+    for (int j = 0; j < b.count; ++j) {
+        const int nb = ((b.g[j].M + BM - 1) / BM) * ((b.g[j].N + BN - 1) / BN);
+        blocks = nb > blocks ? nb : blocks;
+    }
+    const dim3 grid(blocks, b.count), block(256);
     if (epi == EPI_LSTM)
-        hipLaunchKernelGGL(gemm_kernel<EPI_LSTM>, grid, block, GEMM_LDS_BYTES, stream, g);
+        hipLaunchKernelGGL(gemm_kernel<EPI_LSTM>, grid, block, GEMM_LDS_BYTES, stream, b);
     else
-        hipLaunchKernelGGL(gemm_kernel<EPI_PLAIN>, grid, block, GEMM_LDS_BYTES, stream, g);
+        hipLaunchKernelGGL(gemm_kernel<EPI_PLAIN>, grid, block, GEMM_LDS_BYTES, stream, b);
+}
+
+void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream) {
+    GemmBatch b;
+    b.g[0] = g;
+    b.count = 1;
+    launch_gemm_batch(epi, b, stream);
 }
 
 }  // namespace casv

@@ -118,6 +118,10 @@ int casv_decode_beam(casv_model* m, const casv_beam_params* p, int32_t S,
 int casv_profile(casv_model* m, int32_t enable);
 int casv_profile_read(casv_model* m, const char* name, int64_t* launches, double* total_ms,
                       double* flops, double* bytes);
+/* Measurement aid: average duration (ms) of `iters` isolated launches of the GEMM kernel on random
+ * operands; lstm=1 selects the fused LSTM-cell epilogue (N = 4*units), gather=1 a permuted row index. */
+int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K, int32_t gather,
+                    int32_t iters, double* ms_per_launch);
 /* Replay the decode step through a captured hipGraph (1) or launch kernels eagerly (0). */
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 int casv_synchronize(casv_model* m);
