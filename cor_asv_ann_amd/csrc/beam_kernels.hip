@@ -51,18 +51,26 @@ void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t strea
 }
 
 __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const BeamParams p) {
-    __shared__ double s_key[NEWMAX];
-    __shared__ int s_id[NEWMAX];
+    // dynamic LDS: [npow2 new keys (f64)] [q_stage old keys (f64)] [npow2 new ids] [q_stage old ids]
+    extern __shared__ __attribute__((aligned(16))) unsigned char beam_smem[];
     __shared__ int r_count[ROWMAX], r_off[ROWMAX + 1], r_beampos[ROWMAX], r_rej[ROWMAX], r_srcpos[ROWMAX];
     __shared__ int r_nan[ROWMAX], r_rejlate[ROWMAX];
-    __shared__ int sh_nnew, sh_npop, sh_nb, sh_done;
+    __shared__ int sh_nnew, sh_nb, sh_done;
     __shared__ int pop_id[64], pop_chr[64];
+    __shared__ double pop_key[64];
 
     const int line = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int step = *s.step_ptr;
     if (s.line_done[line]) return;
     const int N = p.N, V = s.V, Vp = (V + 31) & ~31, T = s.T, R = s.R;
     const int CMAX = p.width_in + 1;
+    int npow_max = 1;
+    while (npow_max < N * CMAX) npow_max <<= 1;
+    const int q_stage = p.q_stage;                 // entries of the old queue staged in LDS (0: search in HBM)
+    double* s_key = reinterpret_cast<double*>(beam_smem);
+    double* o_key = s_key + npow_max;
+    int* s_id = reinterpret_cast<int*>(o_key + q_stage);
+    int* o_id = s_id + npow_max;
     const int nact = s.nact[line];
     const long long nbase = (long long)line * s.node_cap;
     if (tid == 0) s.line_steps[line] = step + 1;
@@ -249,19 +257,30 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
     double* nkey = s.q_key + (par ^ 1) * qstride + (long long)line * s.q_cap;
     int* nid = s.q_id + (par ^ 1) * qstride + (long long)line * s.q_cap;
     const int qcap = 2 * T * N;                   // max_batches * batch_size (s2s:1531)
+    const bool staged = qn_old <= q_stage;
+    if (staged) {                                 // one coalesced pass instead of log2(n) dependent HBM probes
+        for (int i = tid; i < qn_old; i += 256) { o_key[i] = okey[i]; o_id[i] = oid[i]; }
+        __syncthreads();
+    }
     for (int i = tid; i < qn_old; i += 256) {     // old element i moves behind the new ones before it
-        const double k = okey[i]; const int id = oid[i];
+        const double k = staged ? o_key[i] : okey[i]; const int id = staged ? o_id[i] : oid[i];
         int lo = 0, hi = nnew;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(s_key[mid], s_id[mid], k, id)) lo = mid + 1; else hi = mid; }
         const int pos = i + lo;
         if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
+        if (pos < 64) { pop_key[pos] = k; pop_id[pos] = id; }
     }
     for (int j = tid; j < nnew; j += 256) {
         const double k = s_key[j]; const int id = s_id[j];
         int lo = 0, hi = qn_old;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(okey[mid], oid[mid], k, id)) lo = mid + 1; else hi = mid; }
+        if (staged) {
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(o_key[mid], o_id[mid], k, id)) lo = mid + 1; else hi = mid; }
+        } else {
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(okey[mid], oid[mid], k, id)) lo = mid + 1; else hi = mid; }
+        }
         const int pos = j + lo;
         if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
+        if (pos < 64) { pop_key[pos] = k; pop_id[pos] = id; }
     }
     __threadfence_block();
     __syncthreads();
@@ -269,7 +288,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
 
     // ---------------- C: pop the next beam ----------------
     const int pre = qn < 64 ? qn : 64;
-    if (tid < pre) { const int id = nid[tid]; pop_id[tid] = id; pop_chr[tid] = s.n_chr[nbase + id]; }
+    if (tid < pre) pop_chr[tid] = s.n_chr[nbase + pop_id[tid]];
     __syncthreads();
     if (tid == 0) {
         int nb = 0, h = 0;
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
         while (h < qn && nb < N) {
             const int id = h < 64 ? pop_id[h] : nid[h];
             const int chr = h < 64 ? pop_chr[h] : s.n_chr[nbase + id];
-            const double key = nkey[h];
+            const double key = h < 64 ? pop_key[h] : nkey[h];
             if (chr == 1) {                        // '\n': finished hypothesis -> final_beam (s2s:1402)
                 ++ftot;
                 int ppos = fn;
@@ -294,48 +313,56 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
             } else {
                 if (nb == 0) b0 = key;
                 s.beam_node[line * N + nb] = id;
+                if (nb < ROWMAX) r_count[nb] = id;      // r_count is free now: ids of the popped nodes
                 ++nb;
             }
             ++h;
         }
-        s.f_n[line] = fn; s.f_total[line] = ftot;
         int done = 0;
         if (nb == 0) done = 1;                                             // s2s:1416
-        else if (ftot > p.width_out && fkey[0] > b0) done = 1;            // s2s:1418-1420
+        else if (ftot > p.width_out && (fn > 0 ? fkey[0] : 0.0) > b0) done = 1;   // s2s:1418-1420
+        if (ftot != s.f_total[line]) { s.f_n[line] = fn; s.f_total[line] = ftot; }
         s.q_n[line] = qn - h; s.q_n[s.B + line] = h;
-        sh_nb = nb; sh_npop = h; sh_done = done;
+        sh_nb = nb; sh_done = done;
         if (done) { s.line_done[line] = 1; s.nact[line] = 0; atomicSub(s.active_lines, 1); }
         else s.nact[line] = nb;
     }
     __syncthreads();
     if (sh_done) return;
     const int nb = sh_nb;
-    // next step's inputs: fed-back scores with the better siblings reset (s2s:1515-1520)
-    for (int j = 0; j < N; ++j) {
+    // next step's inputs: fed-back scores with the better siblings reset (s2s:1515-1520); one wave per row
+    for (int j = wave; j < N; j += 4) {
         const int r = line * N + j;
         float* pin = s.p_in + (long long)r * Vp;
         if (j < nb) {
-            const int id = s.beam_node[r];
+            const int id = r_count[j];
             const int exp = s.n_exp[nbase + id];
+            const int k = s.n_k[nbase + id];
             const float* src = s.p_base + (long long)exp * Vp;
-            for (int v = tid; v < Vp; v += 256) pin[v] = src[v];
-            if (tid == 0) s.prev[r] = exp;
+            const short* cr = s.created + (long long)exp * CMAX;
+            const int zi = lane < k ? (int)cr[lane] : -1;
+            for (int v = lane; v < Vp; v += 64) pin[v] = src[v];
+            if (zi >= 0) pin[zi] = 0.f;
+            if (lane == 0) s.prev[r] = exp;
         } else {
-            for (int v = tid; v < Vp; v += 256) pin[v] = 0.f;
-            if (tid == 0) s.prev[r] = line * N;
+            for (int v = lane; v < Vp; v += 64) pin[v] = 0.f;
+            if (lane == 0) s.prev[r] = line * N;
         }
     }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        const int r = line * N + j;
-        const int id = s.beam_node[r];
-        const int k = s.n_k[nbase + id];
-        const long long exp = s.n_exp[nbase + id];
-        if (tid < k) s.p_in[(long long)r * Vp + s.created[exp * CMAX + tid]] = 0.f;
-    }
+}
+size_t beam_lds_bytes(int N, int width_in, int q_cap, int* q_stage) {
+    int npow = 1;
+    while (npow < N * (width_in + 1)) npow <<= 1;
+    const size_t base = (size_t)npow * 12;
+    *q_stage = ((size_t)q_cap * 12 + base <= 56 * 1024) ? q_cap : 0;
+    return base + (size_t)(*q_stage) * 12 + 16;
 }
 void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(beam_step_kernel, dim3(s.B), dim3(256), 0, stream, s, p);
+    int q_stage = 0;
+    const size_t lds = beam_lds_bytes(p.N, p.width_in, s.q_cap, &q_stage);
+    BeamParams pp = p;
+    pp.q_stage = q_stage;
+    hipLaunchKernelGGL(beam_step_kernel, dim3(s.B), dim3(256), lds, stream, s, pp);
 }
 
 // Results, best first (seq2seq.py:1538-1544): walk the trie from each finished node to the root.

@@ -101,6 +101,7 @@ void launch_scatter_rows(const float* src, int src_ld, float* dst, int dst_ld, i
 struct BeamParams {
     int N, width_in, width_out, max_results;
     double threshold_in, rejection, cost0;
+    int q_stage;   // set by launch_beam_step
 };
 
 struct BeamState {

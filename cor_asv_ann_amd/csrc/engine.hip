@@ -228,6 +228,37 @@ static int pack_lstm(casv_model* m, LstmW& dst, const std::string& prefix, int k
     return upload(dst.bias, bias);
 }
 
+// Decoder layer 1 with the input embedding folded in: (p.E).K = p.(E.K) (seq2seq.py:319 feeds the layer
+// with char_input_proj(p)), so the step needs no separate embedding GEMM and the layer's contraction
+// shrinks from W+W to Vp+W.  E.K is formed in float64 and rounded once.  Rows [0,Vp) of the fused weight
+// take the fed-back distribution, then (top cell only) the context rows, then the recurrent rows.
+static int pack_dec1(casv_model* m, LstmW& dst, const std::string& prefix, int kextra) {
+    const int W = m->W, V = m->V, Vp = m->Vp, Kt = Vp + kextra + W;
+    const auto& E = m->host["E"];
+    const auto& K = m->host[prefix + "_K"]; const auto& R = m->host[prefix + "_R"]; const auto& b = m->host[prefix + "_b"];
+    std::vector<double> ek((size_t)V * 4 * W, 0.0);
+    for (int v = 0; v < V; ++v)
+        for (int k = 0; k < W; ++k) {
+            const double e = E[(size_t)v * W + k];
+            const float* krow = &K[(size_t)k * 4 * W];
+            double* out = &ek[(size_t)v * 4 * W];
+            for (int c = 0; c < 4 * W; ++c) out[c] += e * (double)krow[c];
+        }
+    std::vector<float> wt((size_t)4 * W * Kt, 0.f), bias(4 * W);
+    for (int u = 0; u < W; ++u)
+        for (int g = 0; g < 4; ++g) {
+            const int n = (u / 32) * 128 + g * 32 + (u % 32), col = g * W + u;
+            float* row = &wt[(size_t)n * Kt];
+            for (int v = 0; v < V; ++v) row[v] = (float)ek[(size_t)v * 4 * W + col];
+            for (int k = 0; k < kextra; ++k) row[Vp + k] = K[(size_t)(W + k) * 4 * W + col];
+            for (int k = 0; k < W; ++k) row[Vp + kextra + k] = R[(size_t)k * 4 * W + col];
+            bias[n] = b[col];
+        }
+    dst.kin = Vp + kextra;
+    if (int rc = upload(dst.wt, wt)) return rc;
+    return upload(dst.bias, bias);
+}
+
 extern "C" int casv_commit_weights(casv_model* m) {
     if (!m) return fail(CASV_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(m->device));
@@ -242,8 +273,13 @@ extern "C" int casv_commit_weights(casv_model* m) {
     if (int rc = pack_lstm(m, m->enc_fw, "enc1_fw", W)) return rc;
     if (int rc = pack_lstm(m, m->enc_bw, "enc1_bw", W)) return rc;
     for (int n = 2; n <= D; ++n) if (int rc = pack_lstm(m, m->enc[n], "enc" + std::to_string(n), n == 2 ? 2 * W : W)) return rc;
-    for (int n = 1; n < D; ++n) if (int rc = pack_lstm(m, m->dec[n], "dec" + std::to_string(n), W)) return rc;
-    if (int rc = pack_lstm(m, m->dec[D], "dec" + std::to_string(D), W + C)) return rc;
+    if (D == 1) {
+        if (int rc = pack_dec1(m, m->dec[1], "dec1", C)) return rc;
+    } else {
+        if (int rc = pack_dec1(m, m->dec[1], "dec1", 0)) return rc;
+        for (int n = 2; n < D; ++n) if (int rc = pack_lstm(m, m->dec[n], "dec" + std::to_string(n), W)) return rc;
+        if (int rc = pack_lstm(m, m->dec[D], "dec" + std::to_string(D), W + C)) return rc;
+    }
     const auto& Wa = m->host["att_Wa"]; const auto& U = m->host["att_U"];
     std::vector<float> wat((size_t)W * W), ut((size_t)W * C);
     for (int j = 0; j < W; ++j) for (int k = 0; k < W; ++k) wat[(size_t)j * W + k] = Wa[(size_t)k * W + j];
@@ -469,25 +505,22 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
     const long long RW = (long long)R * W;
     const int* prev = m->prev.as<int>();
-    {   // char_input_proj (seq2seq.py:319,418): y0 = p_in . E
-        GemmArgs g{};
-        g.nseg = 1;
-        g.a[0] = beam ? mkseg(m->pin.as<float>(), Vp, Vp, 0) : mkseg(m->st_p.as<float>(), Vp, Vp, 0, nullptr, (long long)R * Vp, 1, 0);
-        g.Bt = m->ETp.as<float>(); g.M = R; g.N = W; g.Ktot = Vp;
-        g.out = mkslot(m->y0.as<float>(), W);
-        g.step_ptr = step_ptr; g.step_imm = step_imm;
-        run_gemm(m, EPI_PLAIN, g);
-    }
-    auto xseg = [&](int n) {   // input of layer n = output of layer n-1 at this step
-        return n == 1 ? mkseg(m->y0.as<float>(), W, W, 0) : mkseg(m->st_h[n - 1].as<float>(), W, W, 0, nullptr, RW, 1, 1);
+    // layer input: layer 1 takes the fed-back distribution itself (embedding folded into its weights,
+    // pack_dec1), layer n > 1 the output of layer n-1 at this step
+    auto xseg = [&](int n) {
+        if (n == 1)
+            return beam ? mkseg(m->pin.as<float>(), Vp, Vp, 0)
+                        : mkseg(m->st_p.as<float>(), Vp, Vp, 0, nullptr, (long long)R * Vp, 1, 0);
+        return mkseg(m->st_h[n - 1].as<float>(), W, W, 0, nullptr, RW, 1, 1);
     };
+    auto xwidth = [&](int n) { return n == 1 ? Vp : W; };
     for (int n = 1; n < D; ++n) {
         GemmArgs g{};
         g.nseg = 2;
         g.a[0] = xseg(n);
-        g.a[1] = mkseg(m->st_h[n].as<float>(), W, W, W, prev);
+        g.a[1] = mkseg(m->st_h[n].as<float>(), W, W, xwidth(n), prev);
         g.Bt = m->dec[n].wt.as<float>(); g.bias = m->dec[n].bias.as<float>();
-        g.M = R; g.N = 4 * W; g.Ktot = 2 * W;
+        g.M = R; g.N = 4 * W; g.Ktot = xwidth(n) + W;
         g.out = mkslot(m->st_h[n].as<float>(), W, RW, 1, 1);
         g.c_in = mkseg(m->st_c[n].as<float>(), W, W, 0, prev);
         g.c_out = mkslot(m->st_c[n].as<float>(), W, RW, 1, 1);
@@ -518,10 +551,10 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         GemmArgs g{};
         g.nseg = 3;
         g.a[0] = xseg(D);
-        g.a[1] = mkseg(m->ctx.as<float>(), C, C, W);
-        g.a[2] = mkseg(m->st_h[D].as<float>(), W, W, W + C, prev);
+        g.a[1] = mkseg(m->ctx.as<float>(), C, C, xwidth(D));
+        g.a[2] = mkseg(m->st_h[D].as<float>(), W, W, xwidth(D) + C, prev);
         g.Bt = m->dec[D].wt.as<float>(); g.bias = m->dec[D].bias.as<float>();
-        g.M = R; g.N = 4 * W; g.Ktot = 2 * W + C;
+        g.M = R; g.N = 4 * W; g.Ktot = xwidth(D) + C + W;
         g.out = mkslot(m->st_h[D].as<float>(), W, RW, 1, 1);
         g.c_in = mkseg(m->st_c[D].as<float>(), W, W, 0, prev);
         g.c_out = mkslot(m->st_c[D].as<float>(), W, RW, 1, 1);
