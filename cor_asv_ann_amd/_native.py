@@ -25,6 +25,10 @@ class Config(Structure):
                 ('bridge_dense', c_int32), ('lm', c_int32), ('stateful', c_int32)]
 
 
+class AdamParams(Structure):
+    _fields_ = [('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('epsilon', c_float), ('clipnorm', c_float)]
+
+
 class BeamParams(Structure):
     _fields_ = [('batch_size', c_int32), ('beam_width_in', c_int32), ('beam_width_out', c_int32),
                 ('max_results', c_int32), ('beam_threshold_in', c_double), ('rejection_threshold', c_double),
@@ -46,6 +50,10 @@ SIGNATURES = {
     'casv_decoder_step': (c_int, [c_void_p, c_int32] + [c_void_p] * 7),
     'casv_decode_greedy': (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     'casv_decode_beam': (c_int, [c_void_p, POINTER(BeamParams), c_int32] + [c_void_p] * 8),
+    'casv_train_begin': (c_int, [c_void_p, POINTER(AdamParams), c_char_p]),
+    'casv_train_step': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8 + [POINTER(c_double), POINTER(c_double)]),
+    'casv_train_get_gradient': (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    'casv_train_end': (c_int, [c_void_p]),
     'casv_profile': (c_int, [c_void_p, c_int32]),
     'casv_profile_read': (c_int, [c_void_p, c_char_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double),
                                   POINTER(c_double)]),

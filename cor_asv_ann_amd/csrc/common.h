@@ -18,6 +18,7 @@ struct Seg {
     int width;
     int skip_first;
     int koff;   // offset of this segment in the fused weight's K dimension
+    const float* first_base;   // if set: at step 0 the rows come from first_base + m * ld (initial LSTM state)
 };
 
 // Output / state pointer that moves with the step the same way.
@@ -38,6 +39,9 @@ struct GemmArgs {
     // LSTM epilogue only
     Seg c_in;             // previous cell state rows (width = units), skip_first = zero state
     SlotPtr c_out;
+    SlotPtr zinit;        // LSTM: pre-activation term added to the contraction, [M][4U] interleaved (x.K + b of all steps, precomputed)
+    SlotPtr gates_out;    // training: activated gates i,f,g,o, [M][4U] in the interleaved column order (or null)
+    int accumulate;       // PLAIN: C += A.B^T instead of C = (weight-gradient sums)
     // step source
     int step_imm;
     const int* step_ptr;
@@ -73,6 +77,8 @@ struct AttnArgs {
     double* apos;           // [R] sum_s a'[s]*s
     int* amax1;             // [R] max(a') == 1.0
     const int* nrows;       // optional device row count (rows >= *nrows are skipped)
+    long long u_line, u_time, enc_line, enc_time;   // element strides of u / enc by line and by position
+    int* win_out;           // optional [R]: window of this step, s_lo | cnt << 16 (train step backward)
 };
 void launch_attention(const AttnArgs& a, hipStream_t stream);
 

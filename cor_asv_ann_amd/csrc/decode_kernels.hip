@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs
 
     const float4* wq4 = reinterpret_cast<const float4*>(a.wq + (long long)r * W);
     const float4* va4 = reinterpret_cast<const float4*>(a.va);
-    const float* ub = a.u + ((long long)ln * T) * W;
+    const float* ub = a.u + (long long)ln * a.u_line;
     const float bv = a.bv[0];
     const int W4 = W >> 2;
     // The kernel is latency-bound (one decoder row per wave slot), so all window rows are requested
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs
 #pragma unroll
         for (int i = 0; i < MAXWIN; ++i) {
             int sidx = s_lo + i; sidx = sidx < T ? sidx : T - 1;
-            uu[i] = reinterpret_cast<const float4*>(ub + (long long)sidx * W)[j];
+            uu[i] = reinterpret_cast<const float4*>(ub + (long long)sidx * a.u_time)[j];
         }
         const float4 q = wq4[j], v = va4[j];
 #pragma unroll
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs
             if (i < cnt && s == s_lo + i) v = e[i];
         aout[s] = v;
     }
-    const float* eb = a.enc + ((long long)ln * T) * C;
+    const float* eb = a.enc + (long long)ln * a.enc_line;
     float4* ctx4 = reinterpret_cast<float4*>(a.ctx + (long long)r * C);
     const int C4 = C >> 2;
     for (int c = lane; c < C4; c += 64) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs
 #pragma unroll
         for (int i = 0; i < MAXWIN; ++i) {
             int sidx = s_lo + i; sidx = sidx < T ? sidx : T - 1;
-            x[i] = reinterpret_cast<const float4*>(eb + (long long)sidx * C)[c];
+            x[i] = reinterpret_cast<const float4*>(eb + (long long)sidx * a.enc_time)[c];
         }
         float4 v = cnt <= 0 ? make_float4(nanv, nanv, nanv, nanv) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs
     if (lane == 0) {
         if (a.apos) a.apos[r] = cnt <= 0 ? (double)nanv : pos;
         if (a.amax1) a.amax1[r] = (amax == 1.0f) ? 1 : 0;
+        if (a.win_out) a.win_out[r] = cnt > 0 ? (s_lo | (cnt << 16)) : 0;
     }
 }
 

@@ -1,0 +1,161 @@
+// Shared host-side declarations of the engine (model handle, device buffers, launch helpers).
+// Host side of the C ABI (include/cor_asv_ann_hip.h): weight repacking, device buffers, and the launch
+// sequences of the encoder (seq2seq.py:237-314), the decoder step (seq2seq.py:416-480) and the
+// greedy / beam decode loops (seq2seq.py:1215-1544).  All device memory and the HIP stream belong to
+// the handle; callers pass plain host pointers.
+#pragma once
+#include "common.h"
+#include "../../include/cor_asv_ann_hip.h"
+
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+using namespace casv;
+
+inline thread_local char g_err[512] = "";
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail(e_ == hipErrorOutOfMemory ? CASV_ERR_NOMEM : CASV_ERR_HIP, "%s failed: %s (%s:%d)", #x, \
+                hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(CASV_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum ProfClass { PC_LSTM = 0, PC_GEMM, PC_ATTN, PC_SOFTMAX, PC_BEAM, PC_EMBED, PC_COUNT };
+inline const char* kProfNames[PC_COUNT] = {"lstm_gemm", "gemm", "attention", "softmax", "beam", "embed"};
+
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    struct Rec { hipEvent_t a, b; int cls; };
+    std::vector<Rec> recs;
+    double flops[PC_COUNT] = {0}, bytes[PC_COUNT] = {0};
+    long long launches[PC_COUNT] = {0};
+    double ms[PC_COUNT] = {0};
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+        return pool[used++];
+    }
+    void reset() { used = 0; recs.clear(); for (int i = 0; i < PC_COUNT; ++i) { flops[i] = bytes[i] = ms[i] = 0; launches[i] = 0; } }
+    void collect() {
+        for (auto& r : recs) { float t = 0; if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t; }
+        recs.clear(); used = 0;
+    }
+};
+
+struct LstmW { DevBuf wt, bias; int kin = 0; };   // packed [4W][kin + W], gate-interleaved
+
+struct TrainState;
+
+struct casv_model {
+    casv_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int W = 0, V = 0, Vp = 0, C = 0, D = 0;
+    std::map<std::string, std::vector<float>> host;      // Keras-layout tensors
+    std::map<std::string, size_t> expect;                // name -> element count
+    bool committed = false;
+    // packed device weights
+    DevBuf E, ETp, WaT, bUW, va, bv, UT;
+    LstmW enc_fw, enc_bw;
+    std::vector<LstmW> enc, dec;                         // enc[n] for layer n>=2 at index n; dec[n] n=1..D
+    // encoder session
+    int B = 0, T = 0, A = 0;
+    bool encoded = false;
+    DevBuf d_idx, d_val, d_srcrej, x0, H1, Ha, Hb, Hc, cfin, hfin, u;
+    float* enc_out = nullptr;
+    // decode session
+    int R = 0, S = 0;
+    std::vector<DevBuf> st_h, st_c;
+    DevBuf st_a, st_p, y0, ctx, wq, logits, prev, pin, apos, amax1, d_step, d_line, d_nan;
+    DevBuf o_idx, o_prob, o_align;
+    // beam
+    DevBuf b_parent, b_chr, b_prob, b_cum, b_len, b_exp, b_k, b_rejpos, b_pos, b_is1, b_count, b_created;
+    DevBuf b_qkey, b_qid, b_qn, b_fkey, b_fid, b_fn, b_ftotal, b_beamnode, b_nact, b_beam0, b_done, b_steps, b_active;
+    DevBuf bo_idx, bo_prob, bo_len, bo_score, bo_rej, bo_align, bo_found, bo_nsteps;
+    // training session (train.hip)
+    TrainState* train = nullptr;
+    // options
+    bool use_graph = false;
+    Prof prof;
+
+    void prof_begin(int cls, double fl, double by, hipEvent_t& a) {
+        if (!prof.on) return;
+        a = prof.get(); (void)hipEventRecord(a, stream);
+        prof.flops[cls] += fl; prof.bytes[cls] += by; prof.launches[cls] += 1;
+    }
+    void prof_end(int cls, hipEvent_t a) {
+        if (!prof.on) return;
+        hipEvent_t b = prof.get(); (void)hipEventRecord(b, stream);
+        prof.recs.push_back({a, b, cls});
+    }
+};
+
+
+inline int upload(DevBuf& b, const std::vector<float>& v) {
+    if (int rc = b.ensure(v.size() * sizeof(float))) return rc;
+    HIPCHK(hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+
+inline Seg mkseg(const float* base, int ld, int width, int koff, const int* rows = nullptr,
+                 long long slot_stride = 0, int mul = 0, int add = 0, int skip_first = 0) {
+    Seg s{}; s.base = base; s.rows = rows; s.slot_stride = slot_stride; s.step_mul = mul; s.step_add = add;
+    s.ld = ld; s.width = width; s.skip_first = skip_first; s.koff = koff; return s;
+}
+inline SlotPtr mkslot(float* base, int ld, long long slot_stride = 0, int mul = 0, int add = 0) {
+    SlotPtr s{}; s.base = base; s.slot_stride = slot_stride; s.step_mul = mul; s.step_add = add; s.ld = ld; return s;
+}
+
+inline void run_gemm_batch(casv_model* m, int epi, GemmBatch& b) {
+    hipEvent_t a{};
+    const int cls = epi == EPI_LSTM ? PC_LSTM : PC_GEMM;
+    double fl = 0, by = 0;
+    for (int j = 0; j < b.count; ++j) {
+        const GemmArgs& g = b.g[j];
+        int kact = 0;
+        for (int i = 0; i < g.nseg; ++i) kact += g.a[i].width;
+        fl += 2.0 * g.M * (double)g.N * kact;
+        by += 4.0 * ((double)g.M * kact + (double)g.N * kact + (double)g.M * g.N);
+    }
+    m->prof_begin(cls, fl, by, a);
+    launch_gemm_batch(epi, b, m->stream);
+    m->prof_end(cls, a);
+}
+
+inline void run_gemm(casv_model* m, int epi, GemmArgs& g) {
+    hipEvent_t a{};
+    const int cls = epi == EPI_LSTM ? PC_LSTM : PC_GEMM;
+    int kact = 0;
+    for (int i = 0; i < g.nseg; ++i) kact += g.a[i].width;
+    const double fl = 2.0 * g.M * (double)g.N * kact;
+    const double by = 4.0 * ((double)g.M * kact + (double)g.N * kact + (double)g.M * g.N);
+    m->prof_begin(cls, fl, by, a);
+    launch_gemm(epi, g, m->stream);
+    m->prof_end(cls, a);
+}
+
+
+int casv_train_release(casv_model* m);

@@ -65,12 +65,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     const float* ap0[2]; const float* ap1[2]; const float* ap2[2];
     int tiles0 = 0, tiles1 = 0, tiles2 = 0;
 #define CASV_SETUP_SEG(S, AP, TILES)                                                             \
-    if (g.nseg > S && !(g.a[S].skip_first && step == 0)) {                                       \
+    if (g.nseg > S && !(g.a[S].skip_first && step == 0 && !g.a[S].first_base)) {                 \
         const Seg& sg = g.a[S];                                                                  \
-        const float* base = sg.base + (long long)(step * sg.step_mul + sg.step_add) * sg.slot_stride; \
+        const bool first = sg.first_base && step == 0;                                           \
+        const float* base = first ? sg.first_base                                                \
+            : sg.base + (long long)(step * sg.step_mul + sg.step_add) * sg.slot_stride;          \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                          \
             int m = m0 + r0 + 64 * i; m = m < g.M ? m : g.M - 1;                                 \
-            const int rid = sg.rows ? sg.rows[m] : m;                                            \
+            const int rid = (sg.rows && !first) ? sg.rows[m] : m;                                \
             AP[i] = base + (long long)rid * sg.ld + 4 * kc;                                      \
         }                                                                                        \
         TILES = sg.width / BK;                                                                   \
@@ -146,8 +148,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     // LSTM: previous cell state of this lane's 16 (row, unit) elements, fetched under the main loop
     float cpv[16];
     if (EPI == EPI_LSTM) {
-        const bool czero = g.c_in.skip_first && step == 0;
-        const float* cin = g.c_in.base + (long long)(step * g.c_in.step_mul + g.c_in.step_add) * g.c_in.slot_stride;
+        const bool cfirst = g.c_in.first_base && step == 0;
+        const bool czero = g.c_in.skip_first && step == 0 && !cfirst;
+        const float* cin = cfirst ? g.c_in.first_base
+            : g.c_in.base + (long long)(step * g.c_in.step_mul + g.c_in.step_add) * g.c_in.slot_stride;
         const int u = bn * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
             m = m < g.M ? m : g.M - 1;
             cpv[r] = 0.0f;
             if (!czero) {
-                const int rid = g.c_in.rows ? g.c_in.rows[m] : m;
+                const int rid = (g.c_in.rows && !cfirst) ? g.c_in.rows[m] : m;
                 cpv[r] = cin[(long long)rid * g.c_in.ld + u];
             }
         }
@@ -202,29 +206,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < g.M) cbase[(long long)m * g.out.ld + n] = acc[c][r] + b;
+                    if (m < g.M) {
+                        float* dst = cbase + (long long)m * g.out.ld + n;
+                        *dst = g.accumulate ? (*dst + acc[c][r] + b) : (acc[c][r] + b);
+                    }
                 }
             }
         }
     } else {
         const int u = bn * 32 + l31;     // hidden unit of this lane
-        const float bi = g.bias[n0 + l31], bf_ = g.bias[n0 + 32 + l31];
-        const float bg = g.bias[n0 + 64 + l31], bo = g.bias[n0 + 96 + l31];
+        const float bi = g.bias ? g.bias[n0 + l31] : 0.f, bf_ = g.bias ? g.bias[n0 + 32 + l31] : 0.f;
+        const float bg = g.bias ? g.bias[n0 + 64 + l31] : 0.f, bo = g.bias ? g.bias[n0 + 96 + l31] : 0.f;
+        const float* zin = g.zinit.base
+            ? g.zinit.base + (long long)(step * g.zinit.step_mul + g.zinit.step_add) * g.zinit.slot_stride : nullptr;
         float* cout = g.c_out.base + (long long)(step * g.c_out.step_mul + g.c_out.step_add) * g.c_out.slot_stride;
         float* hout = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
+        float* gout = g.gates_out.base
+            ? g.gates_out.base + (long long)(step * g.gates_out.step_mul + g.gates_out.step_add) * g.gates_out.slot_stride
+            : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m < g.M) {
                 const float cprev = cpv[r];
-                const float ig = sigmoidf_(acc[0][r] + bi);
-                const float fg = sigmoidf_(acc[1][r] + bf_);
-                const float gg = tanhf_(acc[2][r] + bg);
-                const float og = sigmoidf_(acc[3][r] + bo);
+                float zi = acc[0][r] + bi, zf = acc[1][r] + bf_, zg = acc[2][r] + bg, zo = acc[3][r] + bo;
+                if (zin) {
+                    const float* zr = zin + (long long)m * g.zinit.ld + n0 + l31;
+                    zi += zr[0]; zf += zr[32]; zg += zr[64]; zo += zr[96];
+                }
+                const float ig = sigmoidf_(zi);
+                const float fg = sigmoidf_(zf);
+                const float gg = tanhf_(zg);
+                const float og = sigmoidf_(zo);
                 const float c2 = fg * cprev + ig * gg;
                 const float h2 = og * tanhf_(c2);
                 cout[(long long)m * g.c_out.ld + u] = c2;
                 hout[(long long)m * g.out.ld + u] = h2;
+                if (gout) {
+                    float* gr = gout + (long long)m * g.gates_out.ld + n0 + l31;
+                    gr[0] = ig; gr[32] = fg; gr[64] = gg; gr[96] = og;
+                }
             }
         }
     }

@@ -1,0 +1,625 @@
+// Teacher-forced train step on the device: kt:195 `model.train_on_batch` / kt:407 `test_on_batch` of the
+// graph `encoder_decoder_model` (seq2seq.py:237-390) compiled with weighted categorical cross-entropy and
+// Adam(clipnorm=5) (seq2seq.py:494-497), plus the embedding regulariser (seq2seq.py:530-553).
+//
+// Layout: every sequence tensor is time-major [t][b][f].  Per LSTM layer the parameters are split into
+//   Wx [4W][kx]  input part   -> ONE GEMM over all time steps gives the input pre-activations (+ bias)
+//   Wr [4W][kr]  recurrent part (attention cell: [context | h]) -> one fused LSTM-cell GEMM per step
+// rows in the gate-interleaved order of gemm.hip.  Backward per step = pointwise cell backward + one
+// data GEMM through the recurrent part; input gradients and all weight gradients are big GEMMs over
+// the whole sequence (operands transposed by a bandwidth-bound kernel).  Adam and the global-norm clip
+// run on these packed tensors; Keras layouts exist only at set/get time.
+#include "engine.h"
+#include "train_kernels.h"
+
+namespace {
+
+struct TTensor { std::string name; DevBuf w, g, m, v; size_t n = 0; bool frozen = false; };
+
+struct TLayer {
+    std::string name;
+    int kx = 0, kr = 0, len = 0;
+    bool reverse = false;
+    int iwx = -1, iwr = -1, ib = -1;
+    DevBuf wxT, wrT;                       // derived: [kx][4W], [kr][4W]
+    DevBuf Hown, Cs, Gt, Z, dRec;
+    float* hs = nullptr; long long hs_ld = 0;
+};
+
+}  // namespace
+
+struct TrainState {
+    casv_adam_params ap{};
+    long step = 0;
+    std::vector<TTensor> tens;
+    std::vector<TLayer> layers;            // enc1_fw, enc1_bw, enc2.., dec1..decD
+    int iE = -1, iUT = -1, iWaT = -1, ibUW = -1, iva = -1, ibv = -1;
+    DevBuf ETp, WaN, UaN;                  // derived: E^T padded [W][Vp], W_a [W][W], U_a [C][W]
+    int B = 0, T = 0, U = 0, A = 0;
+    DevBuf e_idx, e_val, d_in, d_out, d_w, m_enc, m_dec, m_cell;
+    DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, CTX, RecIn, prev, logits, dG, d_enc, du, DWQ, dhatt, dfin, dcbuf, HP, dX0, dXtop, dXl;
+    std::vector<DevBuf> O, DO;             // masked layer outputs (encoder O[n], decoder DO[n])
+    DevBuf T1, T2, T3;                     // transposition scratch
+    DevBuf loss, normsq;
+    int find(const std::string& n) const { for (size_t i = 0; i < tens.size(); ++i) if (tens[i].name == n) return (int)i; return -1; }
+    float* W_(int i) { return tens[i].w.as<float>(); }
+    float* G_(int i) { return tens[i].g.as<float>(); }
+};
+
+static int gate_row(int W, int u, int g) { return (u / 32) * 128 + g * 32 + (u % 32); }
+
+// Keras (K (kin,4W), R (W,4W), b) -> Wx [4W][kx], Wr [4W][kr], bias [4W]; top: K rows [W, W+C) join the recurrent part
+static void pack_train_lstm(int W, int kx, int kctx, const std::vector<float>& K, const std::vector<float>& R,
+                            const std::vector<float>& b, std::vector<float>& wx, std::vector<float>& wr, std::vector<float>& bias) {
+    const int kr = kctx + W;
+    wx.assign((size_t)4 * W * kx, 0.f); wr.assign((size_t)4 * W * kr, 0.f); bias.assign(4 * W, 0.f);
+    for (int u = 0; u < W; ++u)
+        for (int g = 0; g < 4; ++g) {
+            const int n = gate_row(W, u, g), col = g * W + u;
+            for (int k = 0; k < kx; ++k) wx[(size_t)n * kx + k] = K[(size_t)k * 4 * W + col];
+            for (int k = 0; k < kctx; ++k) wr[(size_t)n * kr + k] = K[(size_t)(kx + k) * 4 * W + col];
+            for (int k = 0; k < W; ++k) wr[(size_t)n * kr + kctx + k] = R[(size_t)k * 4 * W + col];
+            bias[n] = b[col];
+        }
+}
+static void unpack_train_lstm(int W, int kx, int kctx, const std::vector<float>& wx, const std::vector<float>& wr,
+                              const std::vector<float>& bias, std::vector<float>& K, std::vector<float>& R, std::vector<float>& b) {
+    const int kr = kctx + W;
+    K.assign((size_t)(kx + kctx) * 4 * W, 0.f); R.assign((size_t)W * 4 * W, 0.f); b.assign(4 * W, 0.f);
+    for (int u = 0; u < W; ++u)
+        for (int g = 0; g < 4; ++g) {
+            const int n = gate_row(W, u, g), col = g * W + u;
+            for (int k = 0; k < kx; ++k) K[(size_t)k * 4 * W + col] = wx[(size_t)n * kx + k];
+            for (int k = 0; k < kctx; ++k) K[(size_t)(kx + k) * 4 * W + col] = wr[(size_t)n * kr + k];
+            for (int k = 0; k < W; ++k) R[(size_t)k * 4 * W + col] = wr[(size_t)n * kr + kctx + k];
+            b[col] = bias[n];
+        }
+}
+
+static int add_tensor(TrainState* ts, const std::string& name, const std::vector<float>& host, bool frozen) {
+    ts->tens.emplace_back();
+    TTensor& t = ts->tens.back();
+    t.name = name; t.n = host.size(); t.frozen = frozen;
+    const size_t bytes = host.size() * 4;
+    if (t.w.ensure(bytes) || t.g.ensure(bytes) || t.m.ensure(bytes) || t.v.ensure(bytes)) return -1;
+    if (hipMemcpy(t.w.p, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    (void)hipMemset(t.m.p, 0, bytes); (void)hipMemset(t.v.p, 0, bytes); (void)hipMemset(t.g.p, 0, bytes);
+    return (int)ts->tens.size() - 1;
+}
+
+static bool is_frozen(const std::string& name, const std::string& csv) {
+    size_t pos = 0;
+    while (pos < csv.size()) {
+        size_t e = csv.find(',', pos);
+        if (e == std::string::npos) e = csv.size();
+        const std::string p = csv.substr(pos, e - pos);
+        if (!p.empty() && name.compare(0, p.size(), p) == 0) return true;
+        pos = e + 1;
+    }
+    return false;
+}
+
+int casv_train_release(casv_model* m) {
+    if (!m || !m->train) return 0;
+    TrainState* ts = m->train;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    for (auto& t : ts->tens) { t.w.release(); t.g.release(); t.m.release(); t.v.release(); }
+    for (auto& l : ts->layers) { l.wxT.release(); l.wrT.release(); l.Hown.release(); l.Cs.release(); l.Gt.release(); l.Z.release(); l.dRec.release(); }
+    DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
+        &ts->m_cell, &ts->X0, &ts->H1, &ts->u, &ts->Y0, &ts->Ym, &ts->WQ, &ts->Ast, &ts->WIN, &ts->CTX, &ts->RecIn, &ts->prev,
+        &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl,
+        &ts->T1, &ts->T2, &ts->T3, &ts->loss, &ts->normsq};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& b : ts->O) b.release();
+    for (auto& b : ts->DO) b.release();
+    delete ts;
+    m->train = nullptr;
+    return 0;
+}
+
+// Refresh the layouts derived from the master tensors (after set-up and after every update).
+static void refresh_derived(casv_model* m) {
+    TrainState* ts = m->train;
+    const int W = m->W, V = m->V, Vp = m->Vp, C = m->C;
+    for (auto& l : ts->layers) {
+        launch_transpose(ts->W_(l.iwx), 4 * W, l.kx, l.kx, l.wxT.as<float>(), 4 * W, m->stream);
+        launch_transpose(ts->W_(l.iwr), 4 * W, l.kr, l.kr, l.wrT.as<float>(), 4 * W, m->stream);
+    }
+    launch_transpose(ts->W_(ts->iE), V, W, W, ts->ETp.as<float>(), Vp, m->stream);
+    launch_transpose(ts->W_(ts->iWaT), W, W, W, ts->WaN.as<float>(), W, m->stream);
+    launch_transpose(ts->W_(ts->iUT), W, C, C, ts->UaN.as<float>(), W, m->stream);
+}
+
+extern "C" int casv_train_begin(casv_model* m, const casv_adam_params* ap, const char* frozen_csv) {
+    if (!m || !ap) return fail(CASV_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->device));
+    for (auto& kv : m->expect)
+        if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());
+    casv_train_release(m);
+    TrainState* ts = new TrainState();
+    m->train = ts;
+    ts->ap = *ap;
+    const int W = m->W, D = m->D, C = m->C, Vp = m->Vp;
+    const std::string fz = frozen_csv ? frozen_csv : "";
+    auto add_lstm = [&](const std::string& prefix, int kx, int kctx, bool reverse) -> int {
+        std::vector<float> wx, wr, bias;
+        pack_train_lstm(W, kx, kctx, m->host[prefix + "_K"], m->host[prefix + "_R"], m->host[prefix + "_b"], wx, wr, bias);
+        TLayer l;
+        l.name = prefix; l.kx = kx; l.kr = kctx + W; l.reverse = reverse;
+        const bool frozen = is_frozen(prefix + "_", fz);
+        l.iwx = add_tensor(ts, prefix + "_Wx", wx, frozen);
+        l.iwr = add_tensor(ts, prefix + "_Wr", wr, frozen);
+        l.ib = add_tensor(ts, prefix + "_b", bias, frozen);
+        if (l.iwx < 0 || l.iwr < 0 || l.ib < 0) return -1;
+        if (l.wxT.ensure((size_t)kx * 4 * W * 4) || l.wrT.ensure((size_t)l.kr * 4 * W * 4)) return -1;
+        ts->layers.push_back(std::move(l));
+        return 0;
+    };
+    ts->iE = add_tensor(ts, "E", m->host["E"], false);
+    int rc = add_lstm("enc1_fw", W, 0, false) | add_lstm("enc1_bw", W, 0, true);
+    for (int n = 2; n <= D; ++n) rc |= add_lstm("enc" + std::to_string(n), n == 2 ? 2 * W : W, 0, false);
+    for (int n = 1; n < D; ++n) rc |= add_lstm("dec" + std::to_string(n), W, 0, false);
+    rc |= add_lstm("dec" + std::to_string(D), W, C, false);
+    std::vector<float> ut((size_t)W * C), wat((size_t)W * W);
+    const auto& Uk = m->host["att_U"]; const auto& Wa = m->host["att_Wa"];
+    for (int j = 0; j < W; ++j) for (int c = 0; c < C; ++c) ut[(size_t)j * C + c] = Uk[(size_t)c * W + j];
+    for (int j = 0; j < W; ++j) for (int k = 0; k < W; ++k) wat[(size_t)j * W + k] = Wa[(size_t)k * W + j];
+    ts->iUT = add_tensor(ts, "att_UT", ut, false);
+    ts->iWaT = add_tensor(ts, "att_WaT", wat, false);
+    ts->ibUW = add_tensor(ts, "att_bUW", m->host["att_bUW"], false);
+    ts->iva = add_tensor(ts, "att_va", m->host["att_va"], false);
+    ts->ibv = add_tensor(ts, "att_bv", m->host["att_bv"], false);
+    if (rc || ts->iE < 0 || ts->iUT < 0 || ts->iWaT < 0 || ts->ibUW < 0 || ts->iva < 0 || ts->ibv < 0) {
+        casv_train_release(m);
+        return fail(CASV_ERR_NOMEM, "could not allocate the training tensors");
+    }
+    if (ts->ETp.ensure((size_t)W * Vp * 4) || ts->WaN.ensure((size_t)W * W * 4) || ts->UaN.ensure((size_t)C * W * 4) ||
+        ts->loss.ensure(16) || ts->normsq.ensure(16)) { casv_train_release(m); return fail(CASV_ERR_NOMEM, "out of memory"); }
+    HIPCHK(hipMemset(ts->ETp.p, 0, (size_t)W * Vp * 4));
+    ts->O.resize(D + 1); ts->DO.resize(D + 1);
+    refresh_derived(m);
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return CASV_OK;
+}
+
+static GemmArgs plain_gemm(const float* A, long long lda, int M, int K, const float* Bt, int N, const float* bias, float* C_, long long ldc,
+                           int accumulate = 0) {
+    GemmArgs g{};
+    g.nseg = 1; g.a[0] = mkseg(A, (int)lda, K, 0);
+    g.Bt = Bt; g.bias = bias; g.M = M; g.N = N; g.Ktot = K;
+    g.out = mkslot(C_, (int)ldc); g.accumulate = accumulate;
+    return g;
+}
+
+// One recurrent step of a layer as a GEMM job; k = processing index (time t = k, or len-1-k when reversed).
+static GemmArgs layer_step_job(casv_model* m, TLayer& l, int k, const float* h0, const float* c0, const float* rec_in /*top cell*/) {
+    TrainState* ts = m->train;
+    const int W = m->W, B = ts->B;
+    const int mul = l.reverse ? -1 : 1, add_t = l.reverse ? l.len - 1 : 0, add_p = l.reverse ? l.len : -1;
+    GemmArgs g{};
+    g.nseg = 1;
+    if (rec_in) g.a[0] = mkseg(rec_in, l.kr, l.kr, 0, nullptr, (long long)B * l.kr, 1, 0);
+    else {
+        g.a[0] = mkseg(l.hs, (int)l.hs_ld, W, 0, nullptr, (long long)B * l.hs_ld, mul, add_p, 1);
+        g.a[0].first_base = h0;
+    }
+    g.Bt = ts->W_(l.iwr); g.bias = nullptr; g.M = B; g.N = 4 * W; g.Ktot = l.kr;
+    g.zinit = mkslot(l.Z.as<float>(), 4 * W, (long long)B * 4 * W, mul, add_t);
+    g.out = mkslot(l.hs, (int)l.hs_ld, (long long)B * l.hs_ld, mul, add_t);
+    g.c_in = mkseg(l.Cs.as<float>(), W, W, 0, nullptr, (long long)B * W, mul, add_p, 1);
+    g.c_in.first_base = c0;
+    g.c_out = mkslot(l.Cs.as<float>(), W, (long long)B * W, mul, add_t);
+    g.gates_out = mkslot(l.Gt.as<float>(), 4 * W, (long long)B * 4 * W, mul, add_t);
+    g.step_imm = k; g.step_ptr = nullptr;
+    return g;
+}
+
+static int time_of(const TLayer& l, int k) { return l.reverse ? l.len - 1 - k : k; }
+
+// Z = x . Wx^T + b for every time step (one GEMM)
+static void layer_input_gemm(casv_model* m, TLayer& l, const float* x, long long ldx) {
+    TrainState* ts = m->train;
+    GemmArgs g = plain_gemm(x, ldx, l.len * ts->B, l.kx, ts->W_(l.iwx), 4 * m->W, ts->W_(l.ib), l.Z.as<float>(), 4 * m->W);
+    run_gemm(m, EPI_PLAIN, g);
+}
+
+// weight gradients of one layer from dZ (in l.Z), its inputs x and its recurrent-side inputs rec [len*B][kr]
+static int layer_weight_grads(casv_model* m, TLayer& l, const float* x, long long ldx, const float* rec, long long ldrec) {
+    TrainState* ts = m->train;
+    const int W = m->W;
+    const long long rows = (long long)l.len * ts->B;
+    const long long ldT = (rows + 15) & ~15LL;
+    if (ts->tens[l.iwx].frozen) return 0;
+    HIPCHK(hipMemsetAsync(ts->T1.p, 0, (size_t)4 * W * ldT * 4, m->stream));
+    launch_transpose(l.Z.as<float>(), (int)rows, 4 * W, 4 * W, ts->T1.as<float>(), ldT, m->stream);
+    HIPCHK(hipMemsetAsync(ts->T2.p, 0, (size_t)l.kx * ldT * 4, m->stream));
+    launch_transpose(x, (int)rows, l.kx, ldx, ts->T2.as<float>(), ldT, m->stream);
+    GemmArgs g1 = plain_gemm(ts->T1.as<float>(), ldT, 4 * W, (int)ldT, ts->T2.as<float>(), l.kx, nullptr, ts->G_(l.iwx), l.kx, 1);
+    run_gemm(m, EPI_PLAIN, g1);
+    HIPCHK(hipMemsetAsync(ts->T3.p, 0, (size_t)l.kr * ldT * 4, m->stream));
+    launch_transpose(rec, (int)rows, l.kr, ldrec, ts->T3.as<float>(), ldT, m->stream);
+    GemmArgs g2 = plain_gemm(ts->T1.as<float>(), ldT, 4 * W, (int)ldT, ts->T3.as<float>(), l.kr, nullptr, ts->G_(l.iwr), l.kr, 1);
+    run_gemm(m, EPI_PLAIN, g2);
+    launch_colsum(l.Z.as<float>(), rows, 4 * W, 4 * W, ts->G_(l.ib), m->stream);
+    return 0;
+}
+
+// Backward of a plain LSTM layer.  dOut (+mask) = gradient w.r.t. its output sequence; dh_fin/dc_fin w.r.t. its
+// final state; h0/c0 its initial state (nullptr = zero).  Leaves dL/dh0 in dRec slot(first step) and dL/dc0 in dc.
+static int layer_backward(casv_model* m, TLayer& l, const float* dOut, long long ld_out, const float* mask,
+                          const float* dh_fin, const float* dc_fin, const float* h0, const float* c0, float* dc,
+                          const float* x, long long ldx, float* dX, long long ld_dx, int dx_accumulate) {
+    TrainState* ts = m->train;
+    const int W = m->W, B = ts->B;
+    if (dc_fin) HIPCHK(hipMemcpyAsync(dc, dc_fin, (size_t)B * W * 4, hipMemcpyDeviceToDevice, m->stream));
+    else HIPCHK(hipMemsetAsync(dc, 0, (size_t)B * W * 4, m->stream));
+    for (int k = l.len - 1; k >= 0; --k) {
+        const int t = time_of(l, k);
+        LstmBwdArgs p{};
+        p.a = dOut ? dOut + (long long)t * B * ld_out : nullptr; p.lda = ld_out; p.mask_a = mask;
+        if (k < l.len - 1) { p.b = l.dRec.as<float>() + (long long)time_of(l, k + 1) * B * W; p.ldb = W; }
+        else if (dh_fin) { p.b = dh_fin; p.ldb = W; }
+        p.gates = l.Gt.as<float>() + (long long)t * B * 4 * W;
+        p.cell = l.Cs.as<float>() + (long long)t * B * W;
+        if (k > 0) { p.c_prev = l.Cs.as<float>() + (long long)time_of(l, k - 1) * B * W; p.ld_cprev = W; }
+        else { p.c_prev = c0; p.ld_cprev = W; }
+        p.dc = dc; p.dz = l.Z.as<float>() + (long long)t * B * 4 * W; p.rows = B; p.W = W;
+        launch_lstm_bwd(p, m->stream);
+        GemmArgs g = plain_gemm(p.dz, 4 * W, B, 4 * W, l.wrT.as<float>(), l.kr, nullptr, l.dRec.as<float>() + (long long)t * B * W, W);
+        run_gemm(m, EPI_PLAIN, g);
+    }
+    const long long rows = (long long)l.len * B;
+    if (dX) {
+        GemmArgs g = plain_gemm(l.Z.as<float>(), 4 * W, (int)rows, 4 * W, l.wxT.as<float>(), l.kx, nullptr, dX, ld_dx, dx_accumulate);
+        run_gemm(m, EPI_PLAIN, g);
+    }
+    // recurrent-side inputs of every step: HP[t] = h of the previously processed step (h0 / zero at the first)
+    float* HP = ts->HP.as<float>();
+    const int t0 = time_of(l, 0);
+    if (h0) HIPCHK(hipMemcpyAsync(HP + (long long)t0 * B * W, h0, (size_t)B * W * 4, hipMemcpyDeviceToDevice, m->stream));
+    else HIPCHK(hipMemsetAsync(HP + (long long)t0 * B * W, 0, (size_t)B * W * 4, m->stream));
+    if (l.len > 1) {
+        // forward layer: HP[1..] = H[0..len-2]; reversed layer: HP[0..len-2] = H[1..]
+        const float* src = l.hs + (l.reverse ? (long long)B * l.hs_ld : 0);
+        float* dst = HP + (l.reverse ? 0 : (long long)B * W);
+        HIPCHK(hipMemcpy2DAsync(dst, (size_t)W * 4, src, (size_t)l.hs_ld * 4, (size_t)W * 4, (size_t)(l.len - 1) * B,
+                                hipMemcpyDeviceToDevice, m->stream));
+    }
+    return layer_weight_grads(m, l, x, ldx, HP, W);
+}
+
+extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T, int32_t U, int32_t A,
+                               const int32_t* enc_idx, const float* enc_val, const int32_t* dec_in, const int32_t* dec_out,
+                               const float* weights, const float* mask_enc, const float* mask_dec, const float* mask_cell,
+                               double* loss_out, double* norm_out) {
+    if (!m || !enc_idx || !dec_in || !dec_out || !weights || !loss_out) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->train) return fail(CASV_ERR_STATE, "casv_train_begin must run first");
+    if (B < 1 || T < 1 || U < 1 || A < 1) return fail(CASV_ERR_ARG, "bad shape");
+    if (mode < 0 || mode > 2) return fail(CASV_ERR_ARG, "mode must be 0 (evaluate), 1 (train) or 2 (gradients only)");
+    HIPCHK(hipSetDevice(m->device));
+    TrainState* ts = m->train;
+    hipStream_t st = m->stream;
+    const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, D = m->D;
+    const int L = std::max(T, U);
+    const long long TB = (long long)T * B, UB = (long long)U * B, LB = (long long)L * B;
+    ts->B = B; ts->T = T; ts->U = U; ts->A = A;
+    const bool training = mode != 0;
+
+    // ---- buffers ----
+#define ENS(buf, bytes) if (int rc_ = (buf).ensure(bytes)) return rc_;
+    ENS(ts->e_idx, TB * A * 4) ENS(ts->e_val, TB * A * 4) ENS(ts->d_in, UB * 4) ENS(ts->d_out, UB * 4) ENS(ts->d_w, UB * 4)
+    ENS(ts->m_enc, (size_t)(D + 1) * W * 4) ENS(ts->m_dec, (size_t)D * W * 4) ENS(ts->m_cell, (size_t)B * (W + C) * 4)
+    ENS(ts->X0, TB * W * 4) ENS(ts->H1, TB * 2 * W * 4) ENS(ts->u, TB * W * 4) ENS(ts->Y0, UB * W * 4) ENS(ts->Ym, UB * W * 4)
+    ENS(ts->WQ, UB * W * 4) ENS(ts->Ast, (size_t)(U + 1) * B * T * 4) ENS(ts->WIN, UB * 4) ENS(ts->CTX, (size_t)B * C * 4)
+    ENS(ts->RecIn, UB * (C + W) * 4) ENS(ts->prev, (size_t)B * 4) ENS(ts->logits, UB * Vp * 4)
+    ENS(ts->dG, UB * W * 4) ENS(ts->d_enc, TB * C * 4) ENS(ts->du, TB * W * 4) ENS(ts->DWQ, UB * W * 4) ENS(ts->dhatt, (size_t)B * W * 4)
+    ENS(ts->dfin, (size_t)2 * D * B * W * 4) ENS(ts->dcbuf, (size_t)B * W * 4) ENS(ts->HP, LB * W * 4)
+    ENS(ts->dX0, TB * W * 4) ENS(ts->dXtop, std::max(UB * W, TB * 2 * W) * 4) ENS(ts->dXl, LB * 2 * W * 4)
+    const long long ldTmax = (LB + 15) & ~15LL;
+    ENS(ts->T1, (size_t)4 * W * ldTmax * 4) ENS(ts->T2, (size_t)std::max(2 * W, Vp) * ldTmax * 4) ENS(ts->T3, (size_t)(C + W) * ldTmax * 4)
+    for (auto& l : ts->layers) {
+        const bool enc = l.name.compare(0, 3, "enc") == 0;
+        l.len = enc ? T : U;
+        const long long rows = (long long)l.len * B;
+        ENS(l.Cs, rows * W * 4) ENS(l.Gt, rows * 4 * W * 4) ENS(l.Z, rows * 4 * W * 4) ENS(l.dRec, rows * l.kr * 4)
+        if (l.name == "enc1_fw") { l.hs = ts->H1.as<float>(); l.hs_ld = 2 * W; }
+        else if (l.name == "enc1_bw") { l.hs = ts->H1.as<float>() + W; l.hs_ld = 2 * W; }
+        else { ENS(l.Hown, rows * W * 4) l.hs = l.Hown.as<float>(); l.hs_ld = W; }
+    }
+    for (int n = 1; n <= D; ++n) ENS(ts->O[n], TB * (n == 1 ? 2 * W : W) * 4)
+    for (int n = 1; n < D; ++n) ENS(ts->DO[n], UB * W * 4)
+#undef ENS
+    // ---- inputs ----
+    HIPCHK(hipMemcpyAsync(ts->e_idx.p, enc_idx, TB * A * 4, hipMemcpyHostToDevice, st));
+    if (enc_val) HIPCHK(hipMemcpyAsync(ts->e_val.p, enc_val, TB * A * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ts->d_in.p, dec_in, UB * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ts->d_out.p, dec_out, UB * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ts->d_w.p, weights, UB * 4, hipMemcpyHostToDevice, st));
+    // masks: enc = 2W + (D-1)*W floats, dec = (D-1)*W floats, cell = B*(W+C)
+    const float* menc = nullptr; const float* mdec = nullptr; const float* mcell = nullptr;
+    if (mask_enc) { HIPCHK(hipMemcpyAsync(ts->m_enc.p, mask_enc, (size_t)(D + 1) * W * 4, hipMemcpyHostToDevice, st)); menc = ts->m_enc.as<float>(); }
+    if (mask_dec && D > 1) { HIPCHK(hipMemcpyAsync(ts->m_dec.p, mask_dec, (size_t)(D - 1) * W * 4, hipMemcpyHostToDevice, st)); mdec = ts->m_dec.as<float>(); }
+    if (mask_cell) { HIPCHK(hipMemcpyAsync(ts->m_cell.p, mask_cell, (size_t)B * (W + C) * 4, hipMemcpyHostToDevice, st)); mcell = ts->m_cell.as<float>(); }
+    auto menc_n = [&](int n) { return menc ? menc + (n == 1 ? 0 : 2 * W + (n - 2) * W) : nullptr; };   // layer n (1-based)
+    auto mdec_n = [&](int n) { return mdec ? mdec + (n - 1) * W : nullptr; };
+    long cnt = 0;
+    for (long long i = 0; i < UB; ++i) cnt += weights[i] != 0.f;
+    const float inv_count = 1.0f / (float)std::max(cnt, 1L);
+    HIPCHK(hipMemsetAsync(ts->loss.p, 0, 16, st));
+    HIPCHK(hipMemsetAsync(ts->normsq.p, 0, 16, st));
+    if (training) for (auto& t : ts->tens) HIPCHK(hipMemsetAsync(t.g.p, 0, t.n * 4, st));
+
+    TLayer* Lfw = &ts->layers[0]; TLayer* Lbw = &ts->layers[1];
+    auto enc_layer = [&](int n) -> TLayer& { return ts->layers[n]; };            // n >= 2 -> index n
+    auto dec_layer = [&](int n) -> TLayer& { return ts->layers[D + n]; };        // n = 1..D -> index D+n
+    float* hfin = m->hfin.as<float>(); float* cfin = m->cfin.as<float>();
+    if (int rc = m->hfin.ensure((size_t)D * B * W * 4)) return rc;
+    if (int rc = m->cfin.ensure((size_t)(D + 1) * B * W * 4)) return rc;
+    hfin = m->hfin.as<float>(); cfin = m->cfin.as<float>();
+
+    // ================= forward: encoder =================
+    launch_embed_tm(ts->W_(ts->iE), ts->e_idx.as<int>(), enc_val ? ts->e_val.as<float>() : nullptr, ts->X0.as<float>(), B, T, A, V, W, st);
+    layer_input_gemm(m, *Lfw, ts->X0.as<float>(), W);
+    layer_input_gemm(m, *Lbw, ts->X0.as<float>(), W);
+    for (int k = 0; k < T; ++k) {
+        GemmBatch b{};
+        b.g[0] = layer_step_job(m, *Lfw, k, nullptr, nullptr, nullptr);
+        b.g[1] = layer_step_job(m, *Lbw, k, nullptr, nullptr, nullptr);
+        b.count = 2;
+        run_gemm_batch(m, EPI_LSTM, b);
+    }
+    // final states handed to the decoder: layer 1 = backward direction after t = 0 (seq2seq.py:280)
+    HIPCHK(hipMemcpy2DAsync(hfin, (size_t)W * 4, Lbw->hs, (size_t)2 * W * 4, (size_t)W * 4, B, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(cfin, Lbw->Cs.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+    launch_mul_mask(ts->H1.as<float>(), 2 * W, menc_n(1), ts->O[1].as<float>(), 2 * W, TB, 2 * W, st);
+    for (int n = 2; n <= D; ++n) {
+        TLayer& l = enc_layer(n);
+        layer_input_gemm(m, l, ts->O[n - 1].as<float>(), l.kx);
+        for (int k = 0; k < T; ++k) { GemmArgs g = layer_step_job(m, l, k, nullptr, nullptr, nullptr); run_gemm(m, EPI_LSTM, g); }
+        HIPCHK(hipMemcpyAsync(hfin + (size_t)(n - 1) * B * W, l.hs + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(cfin + (size_t)(n - 1) * B * W, l.Cs.as<float>() + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+        launch_mul_mask(l.hs, W, menc_n(n), ts->O[n].as<float>(), W, TB, W, st);
+    }
+    const float* enc_out = ts->O[D].as<float>();
+    { GemmArgs g = plain_gemm(enc_out, C, (int)TB, C, ts->W_(ts->iUT), W, nullptr, ts->u.as<float>(), W); run_gemm(m, EPI_PLAIN, g); }
+
+    // ================= forward: decoder =================
+    launch_embed_tm(ts->W_(ts->iE), ts->d_in.as<int>(), nullptr, ts->Y0.as<float>(), B, U, 1, V, W, st);
+    const float* y = ts->Y0.as<float>();
+    for (int n = 1; n < D; ++n) {
+        TLayer& l = dec_layer(n);
+        layer_input_gemm(m, l, y, W);
+        const float* h0 = hfin + (size_t)(n - 1) * B * W; const float* c0 = cfin + (size_t)(n - 1) * B * W;
+        for (int k = 0; k < U; ++k) { GemmArgs g = layer_step_job(m, l, k, h0, c0, nullptr); run_gemm(m, EPI_LSTM, g); }
+        launch_mul_mask(l.hs, W, mdec_n(n), ts->DO[n].as<float>(), W, UB, W, st);
+        y = ts->DO[n].as<float>();
+    }
+    TLayer& top = dec_layer(D);
+    launch_mul_rowmask(y, W, mcell, W + C, ts->Ym.as<float>(), W, UB, B, W, st);
+    layer_input_gemm(m, top, ts->Ym.as<float>(), W);
+    const float* h0t = hfin + (size_t)(D - 1) * B * W; const float* c0t = cfin + (size_t)(D - 1) * B * W;
+    HIPCHK(hipMemsetAsync(ts->Ast.p, 0, (size_t)B * T * 4, st));
+    for (int t = 0; t < U; ++t) {
+        const float* hprev = t == 0 ? h0t : top.hs + (long long)(t - 1) * B * W;
+        float* wq = ts->WQ.as<float>() + (long long)t * B * W;
+        { GemmArgs g = plain_gemm(hprev, W, B, W, ts->W_(ts->iWaT), W, ts->W_(ts->ibUW), wq, W); run_gemm(m, EPI_PLAIN, g); }
+        launch_fill_prev(ts->prev.as<int>(), B, t, nullptr, st);
+        AttnArgs a{};
+        a.wq = wq; a.u = ts->u.as<float>(); a.enc = enc_out; a.va = ts->W_(ts->iva); a.bv = ts->W_(ts->ibv);
+        a.a_base = ts->Ast.as<float>(); a.prev = ts->prev.as<int>(); a.line = nullptr; a.rows_per_line = 1;
+        a.ctx = ts->CTX.as<float>(); a.R = B; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
+        a.step_imm = t; a.step_ptr = nullptr; a.apos = nullptr; a.amax1 = nullptr; a.nrows = nullptr;
+        a.u_line = W; a.u_time = (long long)B * W; a.enc_line = C; a.enc_time = (long long)B * C;
+        a.win_out = ts->WIN.as<int>() + (long long)t * B;
+        launch_attention(a, st);
+        float* rec = ts->RecIn.as<float>() + (long long)t * B * (C + W);
+        launch_build_recin(ts->CTX.as<float>(), mcell, W + C, W, hprev, W, rec, B, C, W, st);
+        GemmArgs g = layer_step_job(m, top, t, nullptr, c0t, ts->RecIn.as<float>());
+        g.c_in.skip_first = 0;
+        run_gemm(m, EPI_LSTM, g);
+    }
+    // ================= loss =================
+    { GemmArgs g = plain_gemm(top.hs, W, (int)UB, W, ts->W_(ts->iE), V, nullptr, ts->logits.as<float>(), Vp); run_gemm(m, EPI_PLAIN, g); }
+    launch_softmax_ce(ts->logits.as<float>(), ts->d_out.as<int>(), ts->d_w.as<float>(), B, U, V, Vp, inv_count, ts->loss.as<double>(),
+                      training ? 1 : 0, st);
+    if (!training) {                       // K.in_train_phase: the regulariser counts only in the train phase
+        HIPCHK(hipMemcpyAsync(loss_out, ts->loss.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (norm_out) *norm_out = 0.0;
+        return CASV_OK;
+    }
+
+    // ================= backward =================
+    float* dlog = ts->logits.as<float>();
+    // tied projection: dE += dlogits^T . G ; dG = dlogits . E
+    {
+        const long long ldT = (UB + 15) & ~15LL;
+        HIPCHK(hipMemsetAsync(ts->T2.p, 0, (size_t)Vp * ldT * 4, st));
+        launch_transpose(dlog, (int)UB, Vp, Vp, ts->T2.as<float>(), ldT, st);
+        HIPCHK(hipMemsetAsync(ts->T3.p, 0, (size_t)W * ldT * 4, st));
+        launch_transpose(top.hs, (int)UB, W, W, ts->T3.as<float>(), ldT, st);
+        GemmArgs g = plain_gemm(ts->T2.as<float>(), ldT, V, (int)ldT, ts->T3.as<float>(), W, nullptr, ts->G_(ts->iE), W, 1);
+        run_gemm(m, EPI_PLAIN, g);
+        GemmArgs g2 = plain_gemm(dlog, Vp, (int)UB, Vp, ts->ETp.as<float>(), W, nullptr, ts->dG.as<float>(), W);
+        run_gemm(m, EPI_PLAIN, g2);
+    }
+    HIPCHK(hipMemsetAsync(ts->d_enc.p, 0, TB * C * 4, st));
+    HIPCHK(hipMemsetAsync(ts->du.p, 0, TB * W * 4, st));
+    float* dfin = ts->dfin.as<float>();          // [n-1][0|1][B][W]
+    auto dfin_h = [&](int n) { return dfin + (size_t)(2 * (n - 1)) * B * W; };
+    auto dfin_c = [&](int n) { return dfin + (size_t)(2 * (n - 1) + 1) * B * W; };
+    // ---- attention cell (top decoder layer) ----
+    {
+        float* dc = dfin_c(D);
+        HIPCHK(hipMemsetAsync(dc, 0, (size_t)B * W * 4, st));
+        const int kr = C + W;
+        for (int t = U - 1; t >= 0; --t) {
+            LstmBwdArgs p{};
+            p.a = ts->dG.as<float>() + (long long)t * B * W; p.lda = W;
+            if (t < U - 1) {
+                p.b = top.dRec.as<float>() + (long long)(t + 1) * B * kr + C; p.ldb = kr;
+                p.c = ts->dhatt.as<float>(); p.ldc = W;
+            }
+            p.gates = top.Gt.as<float>() + (long long)t * B * 4 * W;
+            p.cell = top.Cs.as<float>() + (long long)t * B * W;
+            p.c_prev = t > 0 ? top.Cs.as<float>() + (long long)(t - 1) * B * W : c0t; p.ld_cprev = W;
+            p.dc = dc; p.dz = top.Z.as<float>() + (long long)t * B * 4 * W; p.rows = B; p.W = W;
+            launch_lstm_bwd(p, st);
+            float* drec = top.dRec.as<float>() + (long long)t * B * kr;
+            { GemmArgs g = plain_gemm(p.dz, 4 * W, B, 4 * W, top.wrT.as<float>(), kr, nullptr, drec, kr); run_gemm(m, EPI_PLAIN, g); }
+            AttnBwdArgs ab{};
+            ab.dxh = drec; ab.ld_dxh = kr; ab.ctx_off = 0; ab.mcell = mcell; ab.ld_mcell = W + C; ab.mc_off = W;
+            ab.a = ts->Ast.as<float>() + (long long)(t + 1) * B * T; ab.win = ts->WIN.as<int>() + (long long)t * B;
+            ab.wq = ts->WQ.as<float>() + (long long)t * B * W; ab.va = ts->W_(ts->iva);
+            ab.u = ts->u.as<float>(); ab.u_line = W; ab.u_time = (long long)B * W;
+            ab.enc = enc_out; ab.enc_line = C; ab.enc_time = (long long)B * C;
+            ab.d_enc = ts->d_enc.as<float>(); ab.du = ts->du.as<float>(); ab.dwq = ts->DWQ.as<float>() + (long long)t * B * W;
+            ab.dva = ts->G_(ts->iva); ab.dbv = ts->G_(ts->ibv); ab.B = B; ab.T = T; ab.W = W; ab.C = C;
+            launch_attention_bwd(ab, st);
+            GemmArgs g = plain_gemm(ab.dwq, W, B, W, ts->WaN.as<float>(), W, nullptr, ts->dhatt.as<float>(), W);
+            run_gemm(m, EPI_PLAIN, g);
+        }
+        // dL/dh0 of the cell = recurrent part of step 0 + the query path of step 0
+        launch_mul_mask(top.dRec.as<float>() + C, kr, nullptr, dfin_h(D), W, B, W, st);
+        launch_axpy(dfin_h(D), ts->dhatt.as<float>(), (long long)B * W, st);
+        // y-part gradient for all steps, weight grads
+        GemmArgs g = plain_gemm(top.Z.as<float>(), 4 * W, (int)UB, 4 * W, top.wxT.as<float>(), W, nullptr, ts->dXtop.as<float>(), W);
+        run_gemm(m, EPI_PLAIN, g);
+        launch_mul_rowmask(ts->dXtop.as<float>(), W, mcell, W + C, ts->dXtop.as<float>(), W, UB, B, W, st);
+        if (int rc = layer_weight_grads(m, top, ts->Ym.as<float>(), W, ts->RecIn.as<float>(), kr)) return rc;
+        // attention parameters: dWaT = DWQ^T . Hprev ; dbUW = colsum(DWQ) ; u path
+        if (!ts->tens[ts->iWaT].frozen) {
+            const long long ldT = (UB + 15) & ~15LL;
+            HIPCHK(hipMemsetAsync(ts->T1.p, 0, (size_t)W * ldT * 4, st));
+            launch_transpose(ts->DWQ.as<float>(), (int)UB, W, W, ts->T1.as<float>(), ldT, st);
+            // T3 still holds RecIn^T [kr][ldT]: rows C.. are h_prev^T
+            GemmArgs gw = plain_gemm(ts->T1.as<float>(), ldT, W, (int)ldT, ts->T3.as<float>() + (size_t)C * ldT, W, nullptr, ts->G_(ts->iWaT), W, 1);
+            run_gemm(m, EPI_PLAIN, gw);
+            launch_colsum(ts->DWQ.as<float>(), UB, W, W, ts->G_(ts->ibUW), st);
+        }
+        {
+            const long long ldT = (TB + 15) & ~15LL;
+            HIPCHK(hipMemsetAsync(ts->T1.p, 0, (size_t)W * ldT * 4, st));
+            launch_transpose(ts->du.as<float>(), (int)TB, W, W, ts->T1.as<float>(), ldT, st);
+            HIPCHK(hipMemsetAsync(ts->T2.p, 0, (size_t)C * ldT * 4, st));
+            launch_transpose(enc_out, (int)TB, C, C, ts->T2.as<float>(), ldT, st);
+            GemmArgs gu = plain_gemm(ts->T1.as<float>(), ldT, W, (int)ldT, ts->T2.as<float>(), C, nullptr, ts->G_(ts->iUT), C, 1);
+            run_gemm(m, EPI_PLAIN, gu);
+            GemmArgs gd = plain_gemm(ts->du.as<float>(), W, (int)TB, W, ts->UaN.as<float>(), C, nullptr, ts->d_enc.as<float>(), C, 1);
+            run_gemm(m, EPI_PLAIN, gd);
+        }
+    }
+    // ---- lower decoder layers ----
+    const float* dy = ts->dXtop.as<float>();        // gradient w.r.t. DO[D-1] (or Y0 when D == 1)
+    for (int n = D - 1; n >= 1; --n) {
+        TLayer& l = dec_layer(n);
+        const float* xin = n == 1 ? ts->Y0.as<float>() : ts->DO[n - 1].as<float>();
+        if (int rc = layer_backward(m, l, dy, W, mdec_n(n), nullptr, nullptr, hfin + (size_t)(n - 1) * B * W, cfin + (size_t)(n - 1) * B * W,
+                                    dfin_c(n), xin, W, ts->dXl.as<float>(), W, 0)) return rc;
+        // dL/dh0, dL/dc0 of this layer go to the encoder layer of the same index
+        HIPCHK(hipMemcpyAsync(dfin_h(n), l.dRec.as<float>(), (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(ts->dXtop.p, ts->dXl.p, UB * W * 4, hipMemcpyDeviceToDevice, st));
+        dy = ts->dXtop.as<float>();
+    }
+    launch_embed_scatter(ts->G_(ts->iE), ts->d_in.as<int>(), nullptr, dy, W, B, U, 1, V, W, st);
+
+    // ---- encoder ----
+    const float* dO = ts->d_enc.as<float>();        // gradient w.r.t. O[D]
+    long long ld_dO = C;
+    for (int n = D; n >= 2; --n) {
+        TLayer& l = enc_layer(n);
+        if (int rc = layer_backward(m, l, dO, ld_dO, menc_n(n), dfin_h(n), dfin_c(n), nullptr, nullptr, ts->dcbuf.as<float>(),
+                                    ts->O[n - 1].as<float>(), l.kx, ts->dXl.as<float>(), l.kx, 0)) return rc;
+        // next layer's dO lives in dXl; keep it in du/d_enc-sized scratch: copy to d_enc-independent buffer
+        const size_t bytes = TB * l.kx * 4;
+        HIPCHK(hipMemcpyAsync(ts->dXtop.p, ts->dXl.p, bytes, hipMemcpyDeviceToDevice, st));
+        dO = ts->dXtop.as<float>(); ld_dO = l.kx;
+    }
+    // layer 1: forward direction takes columns [0,W) of dO1, backward direction [W,2W)
+    if (int rc = layer_backward(m, *Lfw, dO, ld_dO, menc_n(1), nullptr, nullptr, nullptr, nullptr, ts->dcbuf.as<float>(),
+                                ts->X0.as<float>(), W, ts->dX0.as<float>(), W, 0)) return rc;
+    if (int rc = layer_backward(m, *Lbw, dO + W, ld_dO, menc_n(1) ? menc_n(1) + W : nullptr, dfin_h(1), dfin_c(1), nullptr, nullptr,
+                                ts->dcbuf.as<float>(), ts->X0.as<float>(), W, ts->dX0.as<float>(), W, 1)) return rc;
+    launch_embed_scatter(ts->G_(ts->iE), ts->e_idx.as<int>(), enc_val ? ts->e_val.as<float>() : nullptr, ts->dX0.as<float>(), W, B, T, A, V, W, st);
+
+    // ---- regulariser, clip, update ----
+    launch_reg(ts->W_(ts->iE), ts->G_(ts->iE), V, W, ts->loss.as<double>(), 1, st);
+    for (auto& t : ts->tens) if (!t.frozen) launch_sumsq(t.g.as<float>(), (long long)t.n, ts->normsq.as<double>(), st);
+    if (mode == 1) {
+        ts->step += 1;
+        const double b1 = ts->ap.beta1, b2 = ts->ap.beta2;
+        const float lr_t = (float)(ts->ap.lr * sqrt(1.0 - pow(b2, (double)ts->step)) / (1.0 - pow(b1, (double)ts->step)));
+        for (auto& t : ts->tens)
+            if (!t.frozen)
+                launch_adam(t.w.as<float>(), t.g.as<float>(), t.m.as<float>(), t.v.as<float>(), (long long)t.n, ts->normsq.as<double>(),
+                            ts->ap.clipnorm, lr_t, (float)b1, (float)b2, ts->ap.epsilon, st);
+        refresh_derived(m);
+    }
+    double nsq = 0.0;
+    HIPCHK(hipMemcpyAsync(loss_out, ts->loss.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&nsq, ts->normsq.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if (norm_out) *norm_out = sqrt(nsq);
+    if (m->prof.on) m->prof.collect();
+    return CASV_OK;
+}
+
+// Keras-layout view of the master weights (which = 0) or of the last gradients (which = 1).
+static int keras_view(casv_model* m, int which, std::map<std::string, std::vector<float>>& out) {
+    TrainState* ts = m->train;
+    const int W = m->W, C = m->C, D = m->D;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    auto fetch = [&](int i, std::vector<float>& v) -> int {
+        v.resize(ts->tens[i].n);
+        HIPCHK(hipMemcpy(v.data(), which ? ts->tens[i].g.p : ts->tens[i].w.p, v.size() * 4, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    if (int rc = fetch(ts->iE, out["E"])) return rc;
+    for (auto& l : ts->layers) {
+        std::vector<float> wx, wr, b;
+        if (int rc = fetch(l.iwx, wx)) return rc;
+        if (int rc = fetch(l.iwr, wr)) return rc;
+        if (int rc = fetch(l.ib, b)) return rc;
+        unpack_train_lstm(W, l.kx, l.kr - W, wx, wr, b, out[l.name + "_K"], out[l.name + "_R"], out[l.name + "_b"]);
+    }
+    std::vector<float> ut, wat;
+    if (int rc = fetch(ts->iUT, ut)) return rc;
+    if (int rc = fetch(ts->iWaT, wat)) return rc;
+    auto& Uk = out["att_U"]; auto& Wa = out["att_Wa"];
+    Uk.resize((size_t)C * W); Wa.resize((size_t)W * W);
+    for (int j = 0; j < W; ++j) for (int c = 0; c < C; ++c) Uk[(size_t)c * W + j] = ut[(size_t)j * C + c];
+    for (int j = 0; j < W; ++j) for (int k = 0; k < W; ++k) Wa[(size_t)k * W + j] = wat[(size_t)j * W + k];
+    if (int rc = fetch(ts->ibUW, out["att_bUW"])) return rc;
+    if (int rc = fetch(ts->iva, out["att_va"])) return rc;
+    if (int rc = fetch(ts->ibv, out["att_bv"])) return rc;
+    (void)D;
+    return 0;
+}
+
+extern "C" int casv_train_get_gradient(casv_model* m, const char* name, float* out, int64_t capacity) {
+    if (!m || !name || !out) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->train) return fail(CASV_ERR_STATE, "no training session");
+    HIPCHK(hipSetDevice(m->device));
+    std::map<std::string, std::vector<float>> view;
+    if (int rc = keras_view(m, 1, view)) return rc;
+    auto it = view.find(name);
+    if (it == view.end()) return fail(CASV_ERR_ARG, "unknown tensor '%s'", name);
+    if ((size_t)capacity < it->second.size()) return fail(CASV_ERR_ARG, "buffer too small");
+    memcpy(out, it->second.data(), it->second.size() * 4);
+    return CASV_OK;
+}
+
+// Bring the trained weights back into the handle (Keras layout) and repack them for inference
+// (the reference's _resync_decoder after training, seq2seq.py:645).
+extern "C" int casv_train_end(casv_model* m) {
+    if (!m) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->train) return fail(CASV_ERR_STATE, "no training session");
+    HIPCHK(hipSetDevice(m->device));
+    std::map<std::string, std::vector<float>> view;
+    if (int rc = keras_view(m, 0, view)) return rc;
+    for (auto& kv : view) m->host[kv.first] = kv.second;
+    casv_train_release(m);
+    return casv_commit_weights(m);
+}

@@ -1,0 +1,51 @@
+// Kernels of the train step that are not contractions (train_kernels.hip).
+#pragma once
+#include "common.h"
+#include <algorithm>
+
+namespace casv {
+
+void launch_transpose(const float* src, int rows, int cols, long long ld_src, float* dst, long long ld_dst, hipStream_t st);
+void launch_embed_tm(const float* E, const int* idx, const float* val, float* out, int B, int T, int A, int V, int W, hipStream_t st);
+void launch_embed_scatter(float* dE, const int* idx, const float* val, const float* dX, long long ld_dx, int B, int T, int A,
+                          int V, int W, hipStream_t st);
+void launch_mul_mask(const float* in, long long ld_in, const float* mask, float* out, long long ld_out, long long rows, int F, hipStream_t st);
+void launch_build_recin(const float* ctx, const float* mcell, long long ld_mc, int mc_off, const float* hprev, long long ld_h,
+                        float* out, int B, int C, int W, hipStream_t st);
+void launch_mul_rowmask(const float* in, long long ld_in, const float* mask, long long ld_mask, float* out, long long ld_out,
+                        long long rows, int B, int F, hipStream_t st);
+void launch_softmax_ce(float* logits, const int* target, const float* weight, int B, int U, int V, int Vp, float inv_count,
+                       double* loss, int want_grad, hipStream_t st);
+
+struct LstmBwdArgs {
+    const float* a; long long lda; const float* mask_a;     // gradient from the layer above (x dropout mask)
+    const float* b; long long ldb;                           // recurrent gradient
+    const float* c; long long ldc;                           // extra (attention query path)
+    const float* gates; const float* cell;                   // [rows][4W] interleaved, [rows][W]
+    const float* c_prev; long long ld_cprev;                 // nullptr = zero state
+    float* dc;                                               // [rows][W] in: dL/dc_t, out: dL/dc_{t-1}
+    float* dz;                                               // [rows][4W] interleaved
+    int rows, W;
+};
+void launch_lstm_bwd(const LstmBwdArgs& p, hipStream_t st);
+
+struct AttnBwdArgs {
+    const float* dxh; long long ld_dxh; int ctx_off;         // dL/dx of the cell input; context part at ctx_off
+    const float* mcell; long long ld_mcell; int mc_off;      // per-sample input mask (context part at mc_off) or nullptr
+    const float* a; const int* win;                          // alignment rows [B][T] of this step, window (s_lo | cnt<<16)
+    const float* wq; const float* va;
+    const float* u; long long u_line, u_time;
+    const float* enc; long long enc_line, enc_time;
+    float* d_enc; float* du; float* dwq; float* dva; float* dbv;
+    int B, T, W, C;
+};
+void launch_attention_bwd(const AttnBwdArgs& p, hipStream_t st);
+
+void launch_axpy(float* y, const float* x, long long n, hipStream_t st);
+void launch_colsum(const float* in, long long rows, int cols, long long ld, float* out, hipStream_t st);
+void launch_reg(const float* E, float* dE, int V, int W, double* loss, int want_grad, hipStream_t st);
+void launch_sumsq(const float* g, long long n, double* acc, hipStream_t st);
+void launch_adam(float* w, const float* g, float* m, float* v, long long n, const double* normsq, float clipnorm, float lr_t,
+                 float b1, float b2, float eps, hipStream_t st);
+
+}  // namespace casv

@@ -1,0 +1,360 @@
+// Memory-bound kernels of the train step (kt:195 `train_on_batch`): everything of forward / backward /
+// update that is not a contraction.  All sequence tensors of the train step are TIME-MAJOR,
+// [t][b][feature], so that one time step is a contiguous [B][F] slab (a GEMM operand) and a whole
+// sequence is a [T*B][F] matrix (operand of the batched weight-gradient GEMMs).
+#include "train_kernels.h"
+#include <math.h>
+
+namespace casv {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- transpose: dst[c][r] = src[r][c] (32x32 tiles through LDS) ----
+__global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, long long ld_src,
+                                 float* __restrict__ dst, long long ld_dst) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(long long)r * ld_src + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(long long)c * ld_dst + r] = tile[tx][i];
+    }
+}
+void launch_transpose(const float* src, int rows, int cols, long long ld_src, float* dst, long long ld_dst, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, src, rows, cols, ld_src, dst, ld_dst);
+}
+
+// ---- embedding rows, time-major output: out[(t*B+b)][:] = sum_a val * E[idx[b][t][a]] ----
+__global__ void embed_tm_kernel(const float* __restrict__ E, const int* __restrict__ idx, const float* __restrict__ val,
+                                float* __restrict__ out, int B, int T, int A, int V, int W) {
+    const int t = blockIdx.x / B, b = blockIdx.x % B;
+    const long long in = ((long long)b * T + t) * A;
+    for (int w = threadIdx.x * 4; w < W; w += blockDim.x * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < A; ++k) {
+            const int i = idx[in + k];
+            if (i < 0 || i >= V) continue;
+            const float c = val ? val[in + k] : 1.0f;
+            const float4 e = *reinterpret_cast<const float4*>(E + (long long)i * W + w);
+            acc.x += c * e.x; acc.y += c * e.y; acc.z += c * e.z; acc.w += c * e.w;
+        }
+        *reinterpret_cast<float4*>(out + ((long long)t * B + b) * W + w) = acc;
+    }
+}
+void launch_embed_tm(const float* E, const int* idx, const float* val, float* out, int B, int T, int A, int V, int W, hipStream_t st) {
+    hipLaunchKernelGGL(embed_tm_kernel, dim3(B * T), dim3(128), 0, st, E, idx, val, out, B, T, A, V, W);
+}
+
+// dE[idx] += val * dX[(t*B+b)]   (float atomics: rows of frequent characters collide)
+__global__ void embed_scatter_kernel(float* __restrict__ dE, const int* __restrict__ idx, const float* __restrict__ val,
+                                     const float* __restrict__ dX, long long ld_dx, int B, int T, int A, int V, int W) {
+    const int t = blockIdx.x / B, b = blockIdx.x % B;
+    const long long in = ((long long)b * T + t) * A;
+    const float* src = dX + ((long long)t * B + b) * ld_dx;
+    for (int k = 0; k < A; ++k) {
+        const int i = idx[in + k];
+        if (i < 0 || i >= V) continue;
+        const float c = val ? val[in + k] : 1.0f;
+        for (int w = threadIdx.x; w < W; w += blockDim.x) atomicAdd(dE + (long long)i * W + w, c * src[w]);
+    }
+}
+void launch_embed_scatter(float* dE, const int* idx, const float* val, const float* dX, long long ld_dx, int B, int T, int A,
+                          int V, int W, hipStream_t st) {
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(B * T), dim3(128), 0, st, dE, idx, val, dX, ld_dx, B, T, A, V, W);
+}
+
+// ---- out[r][f] = in[r][f] * mask[f] (+ add[r][f]) : time-constant dropout masks (seq2seq.py:298,367) ----
+__global__ void mul_mask_kernel(const float* __restrict__ in, long long ld_in, const float* __restrict__ mask,
+                                float* __restrict__ out, long long ld_out, long long rows, int F) {
+    const long long n = rows * F;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / F; const int f = (int)(i % F);
+        out[r * ld_out + f] = in[r * ld_in + f] * (mask ? mask[f] : 1.0f);
+    }
+}
+void launch_mul_mask(const float* in, long long ld_in, const float* mask, float* out, long long ld_out, long long rows, int F, hipStream_t st) {
+    const long long n = rows * F;
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(mul_mask_kernel, dim3(blocks), dim3(256), 0, st, in, ld_in, mask, out, ld_out, rows, F);
+}
+
+// ---- recurrent-side input of the attention cell: [ctx * mask | h_prev] (LSTMCell(dropout) masks the
+// cell input [y | ctx] per sample, seq2seq.py:345; the y part is masked where it is precomputed) ----
+__global__ void build_recin_kernel(const float* __restrict__ ctx, const float* __restrict__ mcell, long long ld_mc, int mc_off,
+                                   const float* __restrict__ hprev, long long ld_h, float* __restrict__ out, int B, int C, int W) {
+    const int b = blockIdx.x, F = C + W;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        float v;
+        if (f < C) v = ctx[(long long)b * C + f] * (mcell ? mcell[(long long)b * ld_mc + mc_off + f] : 1.0f);
+        else v = hprev ? hprev[(long long)b * ld_h + (f - C)] : 0.0f;
+        out[(long long)b * F + f] = v;
+    }
+}
+void launch_build_recin(const float* ctx, const float* mcell, long long ld_mc, int mc_off, const float* hprev, long long ld_h,
+                        float* out, int B, int C, int W, hipStream_t st) {
+    hipLaunchKernelGGL(build_recin_kernel, dim3(B), dim3(256), 0, st, ctx, mcell, ld_mc, mc_off, hprev, ld_h, out, B, C, W);
+}
+
+// ---- out[(t*B+b)][f] = in[(t*B+b)][f] * mask[b][f]: per-sample, time-constant mask ----
+__global__ void mul_rowmask_kernel(const float* __restrict__ in, long long ld_in, const float* __restrict__ mask, long long ld_mask,
+                                   float* __restrict__ out, long long ld_out, long long rows, int B, int F) {
+    const long long n = rows * F;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / F; const int f = (int)(i % F);
+        out[r * ld_out + f] = in[r * ld_in + f] * (mask ? mask[(r % B) * ld_mask + f] : 1.0f);
+    }
+}
+void launch_mul_rowmask(const float* in, long long ld_in, const float* mask, long long ld_mask, float* out, long long ld_out,
+                        long long rows, int B, int F, hipStream_t st) {
+    const long long n = rows * F;
+    hipLaunchKernelGGL(mul_rowmask_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, in, ld_in, mask,
+                       ld_mask, out, ld_out, rows, B, F);
+}
+
+// ---- softmax + weighted categorical cross-entropy (Keras), dlogits in place ----
+__global__ __launch_bounds__(256) void softmax_ce_kernel(float* __restrict__ logits, const int* __restrict__ target,
+                                                         const float* __restrict__ weight, long long rows, int B, int U, int V,
+                                                         int Vp, float inv_count, double* __restrict__ loss, int want_grad) {
+    const int lane = threadIdx.x & 63;
+    const long long r = blockIdx.x * 4LL + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* x = logits + r * Vp;
+    float m = -INFINITY;
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+    for (int v = lane; v < V; v += 64) sum += expf(x[v] - m);
+    sum = wsum(sum);
+    const long long src = (r % B) * U + r / B;        // row r = t*B + b  <-  (b, t) of the caller's (B,U) arrays
+    const int tg = target[src];
+    const float wgt = weight[src];
+    float pt = 0.f;
+    if (tg >= 0 && tg < V) pt = expf(x[tg] - m) / sum;
+    const bool ok = tg >= 0 && pt > 1e-7f && pt < 1.0f - 1e-7f;      // tf.clip_by_value passes gradient inside only
+    if (lane == 0 && tg >= 0) {
+        const float pc = fminf(fmaxf(pt, 1e-7f), 1.0f - 1e-7f);
+        atomicAdd(loss, (double)(-logf(pc) * wgt * inv_count));
+    }
+    if (want_grad) {
+        const float sc = ok ? wgt * inv_count : 0.0f;
+        for (int v = lane; v < Vp; v += 64) {
+            float gvl = 0.f;
+            if (v < V) gvl = (expf(x[v] - m) / sum - (v == tg ? 1.0f : 0.0f)) * sc;
+            x[v] = gvl;
+        }
+    }
+}
+void launch_softmax_ce(float* logits, const int* target, const float* weight, int B, int U, int V, int Vp, float inv_count,
+                       double* loss, int want_grad, hipStream_t st) {
+    const long long rows = (long long)B * U;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, target, weight, rows, B, U, V,
+                       Vp, inv_count, loss, want_grad);
+}
+
+// ---- LSTM cell backward, pointwise part ----
+// dh = a*mask_a + b + c ; gates/dz in the interleaved column order of the fused weight
+__global__ void lstm_bwd_kernel(const LstmBwdArgs p) {
+    const int W = p.W;
+    const long long n = (long long)p.rows * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / W; const int u = (int)(i % W);
+        float dh = 0.f;
+        if (p.a) dh += p.a[r * p.lda + u] * (p.mask_a ? p.mask_a[u] : 1.0f);
+        if (p.b) dh += p.b[r * p.ldb + u];
+        if (p.c) dh += p.c[r * p.ldc + u];
+        const long long gi = r * 4 * W + (u >> 5) * 128 + (u & 31);
+        const float ig = p.gates[gi], fg = p.gates[gi + 32], gg = p.gates[gi + 64], og = p.gates[gi + 96];
+        const float cc = p.cell[r * W + u];
+        const float cp = p.c_prev ? p.c_prev[r * p.ld_cprev + u] : 0.0f;
+        const float tc = tanhf(cc);
+        const float dov = dh * tc;
+        const float dct = dh * og * (1.0f - tc * tc) + p.dc[r * W + u];
+        p.dz[gi] = dct * gg * ig * (1.0f - ig);
+        p.dz[gi + 32] = dct * cp * fg * (1.0f - fg);
+        p.dz[gi + 64] = dct * ig * (1.0f - gg * gg);
+        p.dz[gi + 96] = dov * og * (1.0f - og);
+        p.dc[r * W + u] = dct * fg;
+    }
+}
+void launch_lstm_bwd(const LstmBwdArgs& p, hipStream_t st) {
+    const long long n = (long long)p.rows * p.W;
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, p);
+}
+
+// ---- attention backward for one decoder time step (oracle/train.py; no gradient through the window
+// mask nor through the previous alignment, attention.py:567) ----
+constexpr int AB_ROWS = 4;
+__global__ __launch_bounds__(64 * AB_ROWS) void attention_bwd_kernel(const AttnBwdArgs p) {
+    __shared__ float s_dva[AB_ROWS][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * AB_ROWS + wave;
+    const int W = p.W, C = p.C, T = p.T;
+    const bool active = b < p.B;
+    const int bb = active ? b : p.B - 1;
+    const int s_lo = p.win[bb] & 0xffff, cnt = active ? (p.win[bb] >> 16) : 0;
+    const float* arow = p.a + (long long)bb * T;
+    const float* dx = p.dxh + (long long)bb * p.ld_dxh + p.ctx_off;
+    const float* mc = p.mcell ? p.mcell + (long long)bb * p.ld_mcell + p.mc_off : nullptr;
+    // da_s = dctx . enc_s ; dot = sum a_s da_s
+    float da[11], av[11];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        da[i] = 0.f; av[i] = 0.f;
+        if (i < cnt) {
+            const float* es = p.enc + (long long)bb * p.enc_line + (long long)(s_lo + i) * p.enc_time;
+            float part = 0.f;
+            for (int c = lane; c < C; c += 64) part += dx[c] * (mc ? mc[c] : 1.0f) * es[c];
+            da[i] = wsum(part);
+            av[i] = arow[s_lo + i];
+            dot += av[i] * da[i];
+        }
+    }
+    float dbv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        if (i < cnt) { da[i] = av[i] * (da[i] - dot); dbv += da[i]; }     // da[] now holds dscore
+    }
+    // d enc_out[s] += a_s * dctx
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        if (i < cnt) {
+            float* des = p.d_enc + (long long)bb * p.enc_line + (long long)(s_lo + i) * p.enc_time;
+            for (int c = lane; c < C; c += 64) des[c] += av[i] * dx[c] * (mc ? mc[c] : 1.0f);
+        }
+    }
+    // energies: th = tanh(wq + u_s); dva += dscore*th ; dpre = dscore*va*(1-th^2) -> du_s, dwq
+    const float* wq = p.wq + (long long)bb * W;
+    for (int j = lane; j < W; j += 64) {
+        float dwq = 0.f, dva = 0.f;
+        const float q = wq[j], v = p.va[j];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            if (i < cnt) {
+                const long long off = (long long)bb * p.u_line + (long long)(s_lo + i) * p.u_time + j;
+                const float th = tanhf(q + p.u[off]);
+                dva += da[i] * th;
+                const float dpre = da[i] * v * (1.0f - th * th);
+                p.du[off] += dpre;
+                dwq += dpre;
+            }
+        }
+        if (active) p.dwq[(long long)b * W + j] = dwq;
+        s_dva[wave][j] = dva;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < AB_ROWS; ++w) s += s_dva[w][j];
+        atomicAdd(p.dva + j, s);
+    }
+    if (lane == 0 && active) atomicAdd(p.dbv, dbv);
+}
+void launch_attention_bwd(const AttnBwdArgs& p, hipStream_t st) {
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3((p.B + AB_ROWS - 1) / AB_ROWS), dim3(64 * AB_ROWS), 0, st, p);
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] += x[i];
+}
+void launch_axpy(float* y, const float* x, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, st, y, x, n);
+}
+
+// ---- out[c] += sum_r in[r][c] ----
+__global__ void colsum_kernel(const float* __restrict__ in, long long rows, int cols, long long ld, float* __restrict__ out,
+                              int rows_per_block) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s = 0.f;
+    if (c < cols)
+        for (long long r = r0 + rl; r < r1; r += 4) s += in[r * ld + c];
+    part[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+void launch_colsum(const float* in, long long rows, int cols, long long ld, float* out, hipStream_t st) {
+    const int rpb = 512;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, in, rows, cols, ld, out, rpb);
+}
+
+// ---- embedding regulariser (seq2seq.py:530-553): value and gradient; one workgroup ----
+__global__ __launch_bounds__(1024) void reg_kernel(const float* __restrict__ E, float* __restrict__ dE, int V, int W,
+                                                   double* __restrict__ loss, int want_grad) {
+    __shared__ float red[1024];
+    const int tid = threadIdx.x;
+    float acc = 0.f;
+    for (int w = tid; w < W; w += 1024) {
+        float s = 0.f;
+        for (int v = 1; v < V; ++v) s += E[(long long)v * W + w];
+        const float mr = s / (float)(V - 1);
+        const float d = E[w] - mr;
+        acc += d * d;
+        if (want_grad) atomicAdd(dE + w, 2.0f * d);
+    }
+    for (int v = tid; v < V; v += 1024) {
+        float n = 0.f;
+        for (int w = 0; w < W; ++w) { const float e = E[(long long)v * W + w]; n += e * e; }
+        acc += 0.01f * (1.0f - n) * (1.0f - n);
+        if (want_grad) {
+            const float k = -0.04f * (1.0f - n);
+            for (int w = 0; w < W; ++w) atomicAdd(dE + (long long)v * W + w, k * E[(long long)v * W + w]);
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) atomicAdd(loss, (double)red[0]);
+}
+void launch_reg(const float* E, float* dE, int V, int W, double* loss, int want_grad, hipStream_t st) {
+    hipLaunchKernelGGL(reg_kernel, dim3(1), dim3(1024), 0, st, E, dE, V, W, loss, want_grad);
+}
+
+// ---- global gradient norm and Adam (Keras Adam(clipnorm)) ----
+__global__ void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ acc) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double v = g[i]; s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+}
+void launch_sumsq(const float* g, long long n, double* acc, hipStream_t st) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, g, n, acc);
+}
+
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long n, const double* __restrict__ normsq, float clipnorm, float lr_t, float b1, float b2, float eps) {
+    const float norm = (float)sqrt(*normsq);
+    const float scale = (clipnorm > 0.f && norm >= clipnorm) ? clipnorm / norm : 1.0f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * scale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+void launch_adam(float* w, const float* g, float* m, float* v, long long n, const double* normsq, float clipnorm, float lr_t,
+                 float b1, float b2, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 2048)), dim3(256), 0, st, w, g, m, v, n,
+                       normsq, clipnorm, lr_t, b1, b2, eps);
+}
+
+}  // namespace casv

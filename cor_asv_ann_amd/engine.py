@@ -157,6 +157,48 @@ class HipEngine(object):
                                            nv.ptr(out['align']), nv.ptr(out['n_found']), nv.ptr(out['n_steps'])))
         return out
 
+    # -- training ------------------------------------------------------------------------------
+    def train_begin(self, lr=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-7, clipnorm=5.0, frozen=()):
+        p = nv.AdamParams(lr, beta1, beta2, epsilon, clipnorm)
+        csv = ','.join(frozen).encode() if frozen else None
+        nv.check(self.lib.casv_train_begin(self.handle, byref(p), csv))
+
+    def train_step(self, enc_idx, enc_val, dec_in, dec_out, weights, masks=None, mode=1):
+        """One train_on_batch (mode 1), test_on_batch (mode 0) or loss+gradients (mode 2).
+        enc_idx (B,T[,A]) int32, dec_in/dec_out (B,U) int32 (-1 = zero row), weights (B,U).
+        masks: {'enc': [..], 'dec': [..], 'cell': (B,W+C)} of scaled keep-masks, or None."""
+        enc_idx = nv.carray(enc_idx, np.int32)
+        if enc_idx.ndim == 2:
+            enc_idx = np.ascontiguousarray(enc_idx[:, :, None])
+        B, T, A = enc_idx.shape
+        enc_val = None if enc_val is None else nv.carray(np.asarray(enc_val, np.float32).reshape(B, T, A), np.float32)
+        dec_in = nv.carray(dec_in, np.int32)
+        dec_out = nv.carray(dec_out, np.int32)
+        weights = nv.carray(weights, np.float32)
+        U = dec_in.shape[1]
+        m_enc = m_dec = m_cell = None
+        if masks is not None:
+            m_enc = nv.carray(np.concatenate([np.asarray(x, np.float32).ravel() for x in masks['enc']]), np.float32)
+            if self.depth > 1:
+                m_dec = nv.carray(np.concatenate([np.asarray(x, np.float32).ravel() for x in masks['dec']]), np.float32)
+            m_cell = nv.carray(masks['cell'], np.float32)
+        loss, norm = c_double(), c_double()
+        nv.check(self.lib.casv_train_step(self.handle, int(mode), B, T, U, A, nv.ptr(enc_idx), nv.ptr(enc_val), nv.ptr(dec_in),
+                                          nv.ptr(dec_out), nv.ptr(weights), nv.ptr(m_enc), nv.ptr(m_dec), nv.ptr(m_cell),
+                                          byref(loss), byref(norm)))
+        return loss.value, norm.value
+
+    def train_gradients(self):
+        out = {}
+        for name, shape in self.shapes.items():
+            a = np.empty(shape, np.float32)
+            nv.check(self.lib.casv_train_get_gradient(self.handle, name.encode(), nv.ptr(a), a.size))
+            out[name] = a
+        return out
+
+    def train_end(self):
+        nv.check(self.lib.casv_train_end(self.handle))
+
     # -- measurement ---------------------------------------------------------------------------
     def profile(self, enable=True):
         nv.check(self.lib.casv_profile(self.handle, int(bool(enable))))

@@ -111,6 +111,34 @@ int casv_decode_beam(casv_model* m, const casv_beam_params* p, int32_t S,
                      int32_t* out_idx, float* out_prob, int32_t* out_len, double* out_score,
                      int32_t* out_rej, float* out_align, int32_t* n_found, int32_t* n_steps);
 
+/* Adam(clipnorm) of seq2seq.py:496 (Keras defaults: lr 1e-3, beta 0.9/0.999, epsilon 1e-7, clipnorm 5). */
+typedef struct {
+    float lr, beta1, beta2, epsilon, clipnorm;
+} casv_adam_params;
+
+/* Start a training session: device master copies of the handle's weights plus zeroed Adam moments
+ * (encoder_decoder_model.compile, seq2seq.py:494-497).  frozen_csv: comma-separated tensor-name prefixes whose
+ * tensors are not trained (layer.trainable = False after load_transfer_weights, seq2seq.py:1206-1211) or NULL. */
+int casv_train_begin(casv_model* m, const casv_adam_params* p, const char* frozen_csv);
+/* One model.train_on_batch (mode 1, keras_train.py:195), model.test_on_batch (mode 0, keras_train.py:407: no
+ * regulariser, no update) or loss + gradients without update (mode 2, parity tests).
+ * enc_idx/enc_val: encoder input as in casv_encode, (B,T,A); dec_in / dec_out: (B,U) character indices of the
+ * one-hot decoder input and target rows of vectorize_lines (seq2seq.py:1095-1106), -1 = true-zero row;
+ * weights (B,U) temporal sample weights (seq2seq.py:1111-1112).  Dropout enters as explicit keep-masks already
+ * scaled by 1/(1-rate), or NULL for none: mask_enc = 2W + (depth-1)*W floats (seq2seq.py:293-298), mask_dec =
+ * (depth-1)*W floats (seq2seq.py:363-367), mask_cell = (B, W+C) (LSTMCell(dropout), seq2seq.py:345).
+ * loss = weighted categorical cross-entropy (+ embedding regulariser in the train phase); grad_norm = global
+ * L2 norm of the gradients before clipping. */
+int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T, int32_t U, int32_t A,
+                    const int32_t* enc_idx, const float* enc_val, const int32_t* dec_in, const int32_t* dec_out,
+                    const float* weights, const float* mask_enc, const float* mask_dec, const float* mask_cell,
+                    double* loss, double* grad_norm);
+/* Gradient of the last step for one tensor, in Keras layout (parity tests). */
+int casv_train_get_gradient(casv_model* m, const char* name, float* out, int64_t capacity);
+/* End the session: the trained weights replace the handle's weights and are repacked for inference
+ * (_resync_decoder after training, seq2seq.py:645). */
+int casv_train_end(casv_model* m);
+
 /* Measurement support for bench.py: per-kernel HIP-event timing on the library's stream.
  * casv_profile(m, 1) starts recording, casv_profile_read returns, for kernel class `name`
  * ("lstm_gemm", "gemm", "attention", "softmax", "beam", "embed"), the number of launches, their
