@@ -53,6 +53,7 @@ SIGNATURES = {
     'casv_train_begin': (c_int, [c_void_p, POINTER(AdamParams), c_char_p]),
     'casv_train_step': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 8 + [POINTER(c_double), POINTER(c_double)]),
     'casv_train_get_gradient': (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    'casv_train_sync_weights': (c_int, [c_void_p]),
     'casv_train_end': (c_int, [c_void_p]),
     'casv_profile': (c_int, [c_void_p, c_int32]),
     'casv_profile_read': (c_int, [c_void_p, c_char_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double),

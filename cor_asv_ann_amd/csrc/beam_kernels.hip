@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
             const int id = h < 64 ? pop_id[h] : nid[h];
             const int chr = h < 64 ? pop_chr[h] : s.n_chr[nbase + id];
             const double key = h < 64 ? pop_key[h] : nkey[h];
-            if (chr == 1) {                        // '\n': finished hypothesis -> final_beam (s2s:1402)
+            if (chr == p.eos) {                    // '\n': finished hypothesis -> final_beam (s2s:1402)
                 ++ftot;
                 int ppos = fn;
                 while (ppos > 0 && before(key, id, fkey[ppos - 1], fid[ppos - 1])) --ppos;

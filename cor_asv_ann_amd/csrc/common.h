@@ -108,6 +108,7 @@ struct BeamParams {
     int N, width_in, width_out, max_results;
     double threshold_in, rejection, cost0;
     int q_stage;   // set by launch_beam_step
+    int eos;       // vocabulary index of the end-of-line character
 };
 
 struct BeamState {

@@ -97,6 +97,7 @@ struct casv_model {
     // training session (train.hip)
     TrainState* train = nullptr;
     // options
+    int eos = 1;                                          // vocabulary index of '\n' (seq2seq.py:1255,1344,1402)
     bool use_graph = false;
     Prof prof;
 

@@ -525,7 +525,7 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (out_len)
         for (int b = 0; b < B; ++b) {
             int len = S;
-            if (mode == 1) for (int s = 0; s < S; ++s) if (out_idx[(size_t)b * S + s] == 1) { len = s + 1; break; }
+            if (mode == 1) for (int s = 0; s < S; ++s) if (out_idx[(size_t)b * S + s] == m->eos) { len = s + 1; break; }
             out_len[b] = len;
         }
     if (out_align) {   // store_a slot s+1 row b -> (b, s, :)
@@ -584,7 +584,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     s.step_ptr = m->d_step.as<int>();
     BeamParams p{};
     p.N = N; p.width_in = bp->beam_width_in; p.width_out = bp->beam_width_out; p.max_results = MR;
-    p.threshold_in = bp->beam_threshold_in; p.rejection = bp->rejection_threshold; p.cost0 = bp->cost0;
+    p.threshold_in = bp->beam_threshold_in; p.rejection = bp->rejection_threshold; p.cost0 = bp->cost0; p.eos = m->eos;
     if ((long long)(S + 1) * R >= (1LL << 31)) return fail(CASV_ERR_ARG, "search too large: (S+1)*B*N overflows int32");
 
     launch_beam_init(s, p, m->stream);
@@ -702,6 +702,10 @@ extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N
 extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
     if (!m || !key) return fail(CASV_ERR_ARG, "null argument");
     if (!strcmp(key, "graph")) { m->use_graph = value != 0; return CASV_OK; }
+    if (!strcmp(key, "eos")) {
+        if (value < 0 || value >= m->V) return fail(CASV_ERR_ARG, "eos index %lld outside the vocabulary", (long long)value);
+        m->eos = (int)value; return CASV_OK;
+    }
     return fail(CASV_ERR_ARG, "unknown option '%s'", key);
 }
 

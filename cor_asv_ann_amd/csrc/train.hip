@@ -611,6 +611,18 @@ extern "C" int casv_train_get_gradient(casv_model* m, const char* name, float* o
     return CASV_OK;
 }
 
+// Copy the current master weights into the handle's Keras-layout tensors without ending the session
+// (ModelCheckpoint / EarlyStopping(restore_best_weights), seq2seq.py:619-622).
+extern "C" int casv_train_sync_weights(casv_model* m) {
+    if (!m) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->train) return fail(CASV_ERR_STATE, "no training session");
+    HIPCHK(hipSetDevice(m->device));
+    std::map<std::string, std::vector<float>> view;
+    if (int rc = keras_view(m, 0, view)) return rc;
+    for (auto& kv : view) m->host[kv.first] = kv.second;
+    return CASV_OK;
+}
+
 // Bring the trained weights back into the handle (Keras layout) and repack them for inference
 // (the reference's _resync_decoder after training, seq2seq.py:645).
 extern "C" int casv_train_end(casv_model* m) {

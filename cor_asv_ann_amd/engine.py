@@ -196,6 +196,10 @@ class HipEngine(object):
             out[name] = a
         return out
 
+    def train_weights(self):
+        nv.check(self.lib.casv_train_sync_weights(self.handle))
+        return self.get_weights()
+
     def train_end(self):
         nv.check(self.lib.casv_train_end(self.handle))
 

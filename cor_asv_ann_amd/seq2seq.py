@@ -333,6 +333,8 @@ class Sequence2Sequence(object):
         if self._dirty:
             self.engine.set_weights(self._weights)
             self._dirty = False
+        self._eos = self.mapping[0].get('\n', 1)
+        self.engine.set_option('eos', self._eos)
         return self.engine
 
     def _codepoint_table(self):
@@ -364,7 +366,7 @@ class Sequence2Sequence(object):
             if not nonpad[j]:
                 lines.append(''); probs.append([]); scores.append(0.); aligns.append([])
                 continue
-            eos = np.nonzero(idx[j] == 1)[0]
+            eos = np.nonzero(idx[j] == self._eos)[0]
             n = int(eos[0]) + 1 if len(eos) else S
             p = prob[j, :n]
             lines.append(self._chars(idx[j, :n]))
@@ -552,6 +554,22 @@ class Sequence2Sequence(object):
                     else:
                         source_text, target_text = line.split('\t')
                         yield source_text + '\n', None, target_text
+
+    def gen_data(self, filenames, split=None, train=False, unsupervised=False, charmap=None, reset_cb=None):
+        """Dense batches ([encoder_input, decoder_input], decoder_output, weights) with False after every pass
+        over the files (seq2seq.py:846-917), for callers that want the Keras-style arrays.  `train()` itself
+        feeds the device with the index form of the same batches (training.batch_to_indices)."""
+        for batch in self.gen_lines(filenames, True, split, train, unsupervised, charmap):
+            if not batch:
+                yield False
+                continue
+            lines_source, lines_sourceconf, lines_target, _ = batch
+            enc, dec_in, dec_out, weights = self.vectorize_lines(lines_source, lines_target, lines_sourceconf)
+            if train:
+                rand = (enc.shape[1] * np.random.uniform(0, 1, len(lines_source)) / 0.01).astype(int)
+                rows = np.nonzero(rand < enc.shape[1])[0]
+                enc[rows, rand[rows], :] = np.eye(self.voc_size, dtype=enc.dtype)[0]
+            yield ([enc, dec_in], dec_out, weights)
 
     def gen_lines(self, filenames, repeat=True, split=None, train=False, unsupervised=False, charmap=None):
         """Batches of (source lines, source confidences or None, target lines, filenames)

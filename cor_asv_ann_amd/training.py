@@ -1,0 +1,130 @@
+"""Host side of `Sequence2Sequence.train()` (seq2seq.py:590-649 + lib/keras_train.py:27-438): epochs over the
+generator, validation, early stopping / NaN termination / per-epoch checkpoints.  Each batch is ONE call into
+the C ABI (`casv_train_step`), which runs forward, backward, clipping and Adam on the device."""
+import signal
+
+import numpy as np
+
+
+def batch_to_indices(s2s, lines_source, lines_target, lines_conf):
+    """The arrays of vectorize_lines (seq2seq.py:1020-1119) in index form: encoder (idx, val) (B,T,A),
+    decoder input / target character indices (B,U) with -1 for true-zero rows, temporal weights (B,U)."""
+    idx, val, _ = s2s._sparse_lines(lines_source, lines_conf)
+    B = len(lines_target)
+    U = max(map(len, lines_target)) + 1
+    dec_in = np.full((B, U), -1, np.int32)
+    dec_out = np.full((B, U), -1, np.int32)
+    for i, line in enumerate(lines_target):
+        codes = [s2s._index(c, 'decoder input', i) for c in line]
+        dec_in[i, 1:len(codes) + 1] = codes
+        dec_out[i, :len(codes)] = codes
+    weights = (dec_out >= 0).astype(np.float32)
+    return idx, val, dec_in, dec_out, weights
+
+
+def degrade(idx, val, rng):
+    """Random degradation of one encoder position per line to index 0 for learning underspecification
+    (seq2seq.py:909-915): position = int(T * U(0,1) / 0.01), applied when it falls inside the line."""
+    B, T = idx.shape[:2]
+    pos = (T * rng.uniform(0, 1, B) / 0.01).astype(int)
+    for b in np.nonzero(pos < T)[0]:
+        idx[b, pos[b], :] = -1
+        idx[b, pos[b], 0] = 0
+        val[b, pos[b], :] = 0
+        val[b, pos[b], 0] = 1
+    return idx, val
+
+
+def dropout_masks(s2s, B, rng):
+    """Keep-masks of the reference's dropout layers, scaled by 1/(1-rate): time-constant feature masks after
+    every encoder layer and every hidden decoder layer (noise_shape (1, F), seq2seq.py:293-298,363-367), a
+    per-sample mask on the attention cell's input (LSTMCell(dropout), seq2seq.py:345)."""
+    rate = float(s2s.dropout or 0.0)
+    if rate <= 0.0:
+        return None
+    W, d = s2s.width, s2s.depth
+    C = 2 * W if d == 1 else W
+    keep = lambda shape: ((rng.uniform(0, 1, shape) >= rate) / (1.0 - rate)).astype(np.float32)
+    return {'enc': [keep(2 * W if n == 0 else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
+            'cell': keep((B, W + C))}
+
+
+def train_files(s2s, filenames, val_filenames=None):
+    num_lines = s2s.map_files(filenames)
+    s2s.logger.info('Training on "%d" files with %d lines', len(filenames), num_lines)
+    if val_filenames:
+        num_lines = s2s.map_files(val_filenames)
+        s2s.logger.info('Validating on "%d" files with %d lines', len(val_filenames), num_lines)
+        split_rand = None
+    else:
+        s2s.logger.info('Validating on random 20% lines from those files')
+        split_rand = np.random.uniform(0, 1, (num_lines,))
+    rng = np.random.default_rng()
+    engine = s2s._require_engine()
+    engine.train_begin(frozen=tuple(s2s.frozen_prefixes))
+    stop = {'flag': False}
+    old_handler = None
+    try:
+        old_handler = signal.signal(signal.SIGINT, lambda *a: stop.__setitem__('flag', True))   # StopSignalCallback
+    except ValueError:
+        pass                                           # not in the main thread
+    history = []
+    best, best_weights, wait = np.inf, None, 0
+    try:
+        for epoch in range(s2s.epochs):
+            total, nb = 0.0, 0
+            nan = False
+            for batch in s2s.gen_lines(filenames, True, split_rand, True):
+                if not batch:
+                    break                              # end of epoch (kt:160-162)
+                src, conf, tgt, _ = batch
+                idx, val, dec_in, dec_out, w = batch_to_indices(s2s, src, tgt, conf)
+                idx, val = degrade(idx, val, rng)
+                loss, _ = engine.train_step(idx, val, dec_in, dec_out, w, dropout_masks(s2s, len(src), rng), mode=1)
+                if not np.isfinite(loss):
+                    s2s.logger.warning('Batch %d: Invalid loss, terminating training', nb)   # TerminateOnNaN
+                    nan = True
+                    break
+                total += loss; nb += 1
+                if stop['flag']:
+                    break
+            vtotal, vn = 0.0, 0
+            if not nan:
+                for batch in s2s.gen_lines(val_filenames or filenames, True, split_rand, False):
+                    if not batch:
+                        break
+                    src, conf, tgt, _ = batch
+                    idx, val, dec_in, dec_out, w = batch_to_indices(s2s, src, tgt, conf)
+                    loss, _ = engine.train_step(idx, val, dec_in, dec_out, w, None, mode=0)
+                    vtotal += loss; vn += 1
+            val_loss = vtotal / vn if vn else float('nan')
+            history.append({'loss': total / max(nb, 1), 'val_loss': val_loss})
+            s2s.logger.info('epoch %d: loss %.4f val_loss %.4f (%d/%d batches)', epoch + 1, history[-1]['loss'], val_loss, nb, vn)
+            if nan or not np.isfinite(val_loss):
+                break
+            weights = engine.train_weights()
+            np.savez('model.ckpt.weights-%02d-%.2f.npz' % (epoch + 1, val_loss), **weights)   # ModelCheckpoint
+            if val_loss < best:
+                best, best_weights, wait = val_loss, weights, 0
+            else:
+                wait += 1
+                if wait >= 3:                          # EarlyStopping(patience=3, restore_best_weights)
+                    s2s.logger.info('Epoch %05d: early stopping', epoch + 1)
+                    break
+            if stop['flag']:
+                break
+    finally:
+        if old_handler is not None:
+            signal.signal(signal.SIGINT, old_handler)
+        engine.train_end()
+    s2s.history = history
+    if best_weights is not None:
+        s2s.logger.info('training finished with val_loss %f', best)
+        s2s._weights = {k: np.array(v) for k, v in best_weights.items()}
+        s2s._dirty = True
+        s2s.status = 2
+    else:
+        s2s.logger.critical('training failed')
+        s2s._weights = engine.get_weights()
+        s2s._dirty = True
+        s2s.status = 1

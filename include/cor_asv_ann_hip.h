@@ -135,6 +135,8 @@ int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T, int32_t U
                     double* loss, double* grad_norm);
 /* Gradient of the last step for one tensor, in Keras layout (parity tests). */
 int casv_train_get_gradient(casv_model* m, const char* name, float* out, int64_t capacity);
+/* Make casv_get_weight see the current training weights (ModelCheckpoint, EarlyStopping restore; seq2seq.py:619-622). */
+int casv_train_sync_weights(casv_model* m);
 /* End the session: the trained weights replace the handle's weights and are repacked for inference
  * (_resync_decoder after training, seq2seq.py:645). */
 int casv_train_end(casv_model* m);
@@ -150,7 +152,8 @@ int casv_profile_read(casv_model* m, const char* name, int64_t* launches, double
  * operands; lstm=1 selects the fused LSTM-cell epilogue (N = 4*units), gather=1 a permuted row index. */
 int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K, int32_t gather,
                     int32_t iters, double* ms_per_launch);
-/* Replay the decode step through a captured hipGraph (1) or launch kernels eagerly (0). */
+/* Options: "graph" = replay the decode step through a captured hipGraph (1) or launch kernels eagerly (0);
+ * "eos" = vocabulary index of the end-of-line character '\n' (default 1: '' and '\n' sort first, seq2seq.py:580). */
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 int casv_synchronize(casv_model* m);
 

@@ -1,0 +1,101 @@
+"""Train step (kt:195 train_on_batch / kt:407 test_on_batch) on the device against the oracle, and the
+facade's train() end to end on a small copy task."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ModelConfig, make_weights, make_lines, vectorize_lines
+from oracle.decode import OracleModel, correct_lines
+from oracle.train import forward_backward, adam_step
+
+
+def _idx(a):
+    return np.where(a.any(axis=2), a.argmax(axis=2), -1).astype(np.int32)
+
+
+@pytest.mark.parametrize('d,W,V,B,L,es,with_masks', [(1, 32, 40, 4, 9, 3.0, False), (2, 32, 40, 4, 9, 3.0, True),
+                                                     (3, 64, 96, 8, 12, 6.0, True), (4, 64, 96, 6, 10, 8.0, False)])
+def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks):
+    from cor_asv_ann_amd.engine import HipEngine
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    w = make_weights(cfg, emb_scale=es)
+    rng = np.random.default_rng(4)
+    for k in w:
+        if k.endswith('_b') or k in ('att_bUW', 'att_bv'):
+            w[k] = (w[k] + rng.normal(size=w[k].shape) * 0.2).astype(np.float32)
+    om = OracleModel(cfg, w)
+    src, sidx = make_lines(B, L, 1, voc_size=V)
+    tgt, _ = make_lines(B, L, 2, voc_size=V)
+    tgt[1] = tgt[1][:L // 2] + '\n'                         # ragged targets: padded steps have weight 0
+    enc_in, dec_in, dec_out, wts = vectorize_lines(om, src, tgt)
+    C = cfg.ctx_width
+    masks = None
+    if with_masks:
+        keep = lambda shape: ((rng.random(shape) > 0.2) / 0.8).astype(np.float32)
+        masks = {'enc': [keep(2 * W if n == 0 else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
+                 'cell': keep((B, W + C))}
+    loss, grads, aux = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, masks)
+    eng = HipEngine(d, W, V)
+    eng.set_weights(w)
+    eng.train_begin()
+    gl, gn = eng.train_step(sidx, None, _idx(dec_in), _idx(dec_out), wts, masks, mode=2)
+    onorm = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values()))
+    assert abs(gl - loss) < 2e-5 * abs(loss) and abs(gn - onorm) < 1e-4 * onorm
+    gg = eng.train_gradients()
+    for k in grads:
+        scale = max(np.abs(grads[k]).max(), 1e-6 * onorm)
+        assert np.abs(gg[k] - grads[k]).max() < 2e-3 * scale + 1e-7, k
+    # test_on_batch: no regulariser, no dropout
+    el, _ = eng.train_step(sidx, None, _idx(dec_in), _idx(dec_out), wts, None, mode=0)
+    _, _, a0 = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, None, want_grads=False)
+    assert abs(el - a0['loss_ce']) < 2e-5 * abs(a0['loss_ce'])
+    # three updates with Adam(clipnorm=5)
+    st = {'t': 0, 'm': {}, 'v': {}}
+    w2 = {k: v.copy() for k, v in w.items()}
+    for _ in range(3):
+        lo, g2, _ = forward_backward(cfg, w2, enc_in, dec_in, dec_out, wts, masks)
+        adam_step(w2, g2, st)
+        lg, _ = eng.train_step(sidx, None, _idx(dec_in), _idx(dec_out), wts, masks, mode=1)
+        assert abs(lg - lo) < 5e-5 * abs(lo)
+    eng.train_end()
+    wg = eng.get_weights()
+    for k in w2:
+        assert np.abs(wg[k] - w2[k]).max() < 5e-6, k
+    eng.close()
+
+
+def test_facade_train_copy_task(tmp_path, monkeypatch):
+    """cor-asv-ann-train's path: map_files -> epochs of train_on_batch -> validation -> early stopping ->
+    trained weights usable by correct_lines; afterwards the trained model is the functional fixture for the
+    beam search (non-degenerate, well-conditioned distributions): GPU == oracle on it."""
+    from cor_asv_ann_amd.seq2seq import Sequence2Sequence
+    monkeypatch.chdir(tmp_path)                              # checkpoints go to the CWD like the reference's
+    rng = np.random.default_rng(0)
+    alphabet = 'abcdefghij '
+    lines = [''.join(rng.choice(list(alphabet), size=rng.integers(5, 12))) for _ in range(640)]
+    (tmp_path / 'train.tsv').write_text(''.join('%s\t%s\n' % (l, l) for l in lines))
+    s2s = Sequence2Sequence()
+    s2s.depth, s2s.width, s2s.batch_size, s2s.epochs, s2s.dropout = 2, 64, 32, 50, 0.0
+    s2s.configure()
+    s2s._rng = np.random.default_rng(1)
+    s2s.train([str(tmp_path / 'train.tsv')])
+    assert s2s.status == 2
+    hist = s2s.history
+    assert min(h['val_loss'] for h in hist) < 0.7 * hist[0]['val_loss']
+    test = [l + '\n' for l in lines[:8]]
+    s2s.batch_size = 4
+    got = s2s.correct_lines(test, fast=False, greedy=False)
+    cfg = ModelConfig(depth=2, width=64, voc_size=s2s.voc_size)
+    om = OracleModel(cfg, s2s.get_weights(), mapping=s2s.mapping, batch_size=4)
+    want = correct_lines(om, test, fast=False, greedy=False)
+    assert got[0] == want[0]
+    assert np.allclose(got[2], want[2], atol=1e-4)
+    fast = s2s.correct_lines(test, fast=True, greedy=True)
+    wfast = correct_lines(om, test, fast=True, greedy=True)
+    assert fast[0] == wfast[0]
+    s2s.save(str(tmp_path / 'm.npz'))
+    other = Sequence2Sequence()
+    other.load_config(str(tmp_path / 'm.npz')); other.configure(); other.load_weights(str(tmp_path / 'm.npz'))
+    other.batch_size = 4
+    assert other.correct_lines(test, fast=True, greedy=True)[0] == fast[0]
