@@ -42,6 +42,8 @@ struct GemmArgs {
     SlotPtr zinit;        // LSTM: pre-activation term added to the contraction, [M][4U] interleaved (x.K + b of all steps, precomputed)
     SlotPtr gates_out;    // training: activated gates i,f,g,o, [M][4U] in the interleaved column order (or null)
     int accumulate;       // PLAIN: C += A.B^T instead of C = (weight-gradient sums)
+    int ksplit;           // PLAIN: 0/1 = one block per tile; n > 1 = K split over n blocks (float atomics into C);
+                          // -1 = let the launcher choose (train step only: sums become order-dependent)
     // step source
     int step_imm;
     const int* step_ptr;

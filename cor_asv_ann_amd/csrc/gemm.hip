@@ -83,7 +83,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     CASV_SETUP_SEG(1, ap1, tiles1)
     CASV_SETUP_SEG(2, ap2, tiles2)
 #undef CASV_SETUP_SEG
-    const int c0 = tiles0, c1 = c0 + tiles1, ntiles = c1 + tiles2;
+    const int c0 = tiles0, c1 = c0 + tiles1, ntiles_all = c1 + tiles2;
+    // split-K: this block contracts k-tiles [kt_begin, kt_begin + ntiles)
+    const int nsplit = gridDim.z;
+    const int per = (ntiles_all + nsplit - 1) / nsplit;
+    const int kt_begin = blockIdx.z * per;
+    const int ntiles = ntiles_all - kt_begin < per ? (ntiles_all - kt_begin > 0 ? ntiles_all - kt_begin : 0) : per;
     const int koff0 = g.a[0].koff, koff1 = g.a[1].koff, koff2 = g.a[2].koff;
 
     const float* bp[2];
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     }
 
     f32x4 ga[2], gb[2];
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt_rel) {
+        const int kt = kt_rel + kt_begin;
         int kb;
         if (kt < c0) {
             const int ko = kt * BK;
@@ -208,7 +214,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
                     const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (m < g.M) {
                         float* dst = cbase + (long long)m * g.out.ld + n;
-                        *dst = g.accumulate ? (*dst + acc[c][r] + b) : (acc[c][r] + b);
+                        if (nsplit > 1) atomicAdd(dst, acc[c][r] + (blockIdx.z == 0 ? b : 0.0f));
+                        else *dst = g.accumulate ? (*dst + acc[c][r] + b) : (acc[c][r] + b);
                     }
                 }
             }
@@ -265,7 +272,25 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
         const int nb = ((b.g[j].M + BM - 1) / BM) * ((b.g[j].N + BN - 1) / BN);
         blocks = nb > blocks ? nb : blocks;
     }
-    const dim3 grid(blocks, b.count), block(256);
+    int ksplit = 1;
+    if (epi == EPI_PLAIN && b.count == 1 && b.g[0].ksplit != 0 && b.g[0].ksplit != 1) {
+        const GemmArgs& g = b.g[0];
+        int ktiles = 0;
+        for (int i = 0; i < g.nseg; ++i) ktiles += g.a[i].width / BK;
+        ksplit = g.ksplit;
+        if (ksplit < 0) {                       // fill ~2 blocks per CU, keep >= 16 k-tiles per block
+            ksplit = (512 + blocks - 1) / blocks;
+            if (ksplit > ktiles / 16) ksplit = ktiles / 16;
+        }
+        if (ksplit > ktiles) ksplit = ktiles;
+        if (ksplit < 1) ksplit = 1;
+        if (ksplit > 1 && !g.accumulate) {      // partial sums are added atomically: start from zero
+            float* cbase = g.out.base + (long long)(g.step_imm * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
+            if (g.out.ld == g.N) (void)hipMemsetAsync(cbase, 0, (size_t)g.M * g.N * sizeof(float), stream);
+            else (void)hipMemset2DAsync(cbase, (size_t)g.out.ld * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream);
+        }
+    }
+    const dim3 grid(blocks, b.count, ksplit), block(256);
     if (epi == EPI_LSTM)
         hipLaunchKernelGGL(gemm_kernel<EPI_LSTM>, grid, block, GEMM_LDS_BYTES, stream, b);
     else

@@ -188,7 +188,7 @@ static GemmArgs plain_gemm(const float* A, long long lda, int M, int K, const fl
     GemmArgs g{};
     g.nseg = 1; g.a[0] = mkseg(A, (int)lda, K, 0);
     g.Bt = Bt; g.bias = bias; g.M = M; g.N = N; g.Ktot = K;
-    g.out = mkslot(C_, (int)ldc); g.accumulate = accumulate;
+    g.out = mkslot(C_, (int)ldc); g.accumulate = accumulate; g.ksplit = -1;
     return g;
 }
 

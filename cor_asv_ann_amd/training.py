@@ -58,8 +58,8 @@ def train_files(s2s, filenames, val_filenames=None):
         split_rand = None
     else:
         s2s.logger.info('Validating on random 20% lines from those files')
-        split_rand = np.random.uniform(0, 1, (num_lines,))
-    rng = np.random.default_rng()
+        split_rand = s2s._rng.uniform(0, 1, (num_lines,))
+    rng = s2s._rng
     engine = s2s._require_engine()
     engine.train_begin(frozen=tuple(s2s.frozen_prefixes))
     stop = {'flag': False}
