@@ -56,7 +56,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     const int l31 = lane & 31, lh = lane >> 5;
     const int step = g.step_ptr ? *g.step_ptr : g.step_imm;
     const int nbn = (g.N + BN - 1) / BN;
-    const int bn = blockIdx.x % nbn, bm = blockIdx.x / nbn;
+    int bn = blockIdx.x % nbn, bm = blockIdx.x / nbn;
+    if (g.xcd_rows > 0) {
+        // Workgroups are dealt round-robin over the 8 XCDs (private L2s).  Give each XCD a compact block of the
+        // tile grid so that an A row-panel / B column-panel is fetched into ONE L2 instead of all eight
+        // (placement only changes speed, never results).
+        const int xr = g.xcd_rows, xc = 8 / xr;
+        const int nbm = (g.M + BM - 1) / BM;
+        const int pr = nbm / xr, pc = nbn / xc;            // tiles per XCD along rows / columns (host checked divisibility)
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        bm = (xcd / xc) * pr + local / pc;
+        bn = (xcd % xc) * pc + local % pc;
+    }
     const int m0 = bm * BM, n0 = bn * BN;
     if (m0 >= g.M || bm * nbn + bn >= ((g.M + BM - 1) / BM) * nbn) return;
 
@@ -272,6 +283,22 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
         const int nb = ((b.g[j].M + BM - 1) / BM) * ((b.g[j].N + BN - 1) / BN);
         blocks = nb > blocks ? nb : blocks;
     }
+    // XCD-aware tile order: minimise (A bytes x column-splits + B bytes x row-splits) over the 8 = xr * xc splits
+    GemmBatch bb = b;
+    for (int j = 0; j < bb.count; ++j) {
+        GemmArgs& g = bb.g[j];
+        const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+        g.xcd_rows = 0;
+        if ((nbm * nbn) % 8 != 0 || nbm * nbn != blocks) continue;
+        double best = 0; int best_xr = 0;
+        for (int xr = 1; xr <= 8; xr *= 2) {
+            const int xc = 8 / xr;
+            if (nbm % xr || nbn % xc) continue;
+            const double cost = (double)g.M * xc + (double)g.N * xr;     // both operands share K
+            if (!best_xr || cost < best) { best = cost; best_xr = xr; }
+        }
+        g.xcd_rows = best_xr;
+    }
     int ksplit = 1;
     if (epi == EPI_PLAIN && b.count == 1 && b.g[0].ksplit != 0 && b.g[0].ksplit != 1) {
         const GemmArgs& g = b.g[0];
@@ -292,9 +319,9 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     }
     const dim3 grid(blocks, b.count, ksplit), block(256);
     if (epi == EPI_LSTM)
-        hipLaunchKernelGGL(gemm_kernel<EPI_LSTM>, grid, block, GEMM_LDS_BYTES, stream, b);
+        hipLaunchKernelGGL(gemm_kernel<EPI_LSTM>, grid, block, GEMM_LDS_BYTES, stream, bb);
     else
-        hipLaunchKernelGGL(gemm_kernel<EPI_PLAIN>, grid, block, GEMM_LDS_BYTES, stream, b);
+        hipLaunchKernelGGL(gemm_kernel<EPI_PLAIN>, grid, block, GEMM_LDS_BYTES, stream, bb);
 }
 
 void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream) {
