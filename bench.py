@@ -39,7 +39,10 @@ def make_model(device):
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
     cfg = ModelConfig(depth=DEPTH, width=WIDTH, voc_size=VOC)
     weights = make_weights(cfg, emb_scale=EMB_SCALE)
-    s2s = Sequence2Sequence(device=device)
+    import logging
+    logger = logging.getLogger('bench')
+    logger.setLevel(logging.CRITICAL)     # lines without a finished hypothesis fall back to the input (seq2seq.py:826-836)
+    s2s = Sequence2Sequence(logger=logger, device=device)   # and are logged as errors: hundreds per step with random weights
     s2s.depth, s2s.width, s2s.batch_size = DEPTH, WIDTH, BEAM_N
     s2s.mapping, s2s.voc_size = make_vocabulary(VOC), VOC
     s2s.configure()
@@ -72,6 +75,55 @@ def cpu_baseline(cfg, weights, lines, budget_s=20.0):
             'sample': '%d lines of the same workload (numpy fp32 oracle, reference dataflow), %.1f s' % (n, dt)}
 
 
+def train_bench(args):
+    """BASELINE configs[3]: depth 4, width 512, teacher-forced train step (forward + backward + clip + Adam) on 512
+    lines of 100 characters (targets = sources with 5 % substitutions), dropout 0.2.  One GPU."""
+    from oracle.weights import ModelConfig, make_weights, make_lines
+    from cor_asv_ann_amd.engine import HipEngine
+    B = 512
+    cfg = ModelConfig(depth=DEPTH, width=WIDTH, voc_size=VOC)
+    eng = HipEngine(DEPTH, WIDTH, VOC)
+    eng.set_weights(make_weights(cfg, emb_scale=4.0))
+    _, sidx = make_lines(B, LENGTH, 104, voc_size=VOC)
+    rng = np.random.default_rng(1104)
+    tidx = sidx.copy()
+    sub = rng.random(tidx.shape) < 0.05
+    sub[:, -1] = False
+    tidx[sub] = rng.integers(2, VOC, size=int(sub.sum()))
+    U = LENGTH + 2
+    dec_in = np.full((B, U), -1, np.int32)
+    dec_out = np.full((B, U), -1, np.int32)
+    dec_in[:, 1:LENGTH + 2] = tidx
+    dec_out[:, :LENGTH + 1] = tidx
+    wts = (dec_out >= 0).astype(np.float32)
+    keep = lambda shape: ((rng.random(shape) >= 0.2) / 0.8).astype(np.float32)
+    masks = {'enc': [keep(2 * WIDTH if n == 0 else WIDTH) for n in range(DEPTH)], 'dec': [keep(WIDTH) for _ in range(DEPTH - 1)],
+             'cell': keep((B, 2 * WIDTH))}
+    eng.train_begin()
+    for _ in range(args.warmup):
+        eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=1)
+    eng.profile(True)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, norm = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=1)
+    eng.synchronize()
+    elapsed = time.perf_counter() - t0
+    pl, pg = eng.profile_read('lstm_gemm'), eng.profile_read('gemm')
+    eng.profile(False)
+    fl, ms = pl['flops'] + pg['flops'], pl['ms'] + pg['ms']
+    print(json.dumps({
+        'metric': 'trained chars/sec (1 GPU), depth-4 width-512 teacher-forced train step, 100-char lines',
+        'value': B * LENGTH * args.steps / elapsed, 'unit': 'chars/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[3]: depth=4 width=512 V=256 train step, batch 512 x 100 chars, dropout 0.2, Adam(clipnorm 5)',
+                   'last_loss': loss, 'last_grad_norm': norm},
+        'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel (all GEMMs of the step)', 'achieved': fl / max(ms, 1e-9) / 1e9,
+                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / max(ms, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS,
+                     'traffic': None, 'launches': pl['launches'] + pg['launches']}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -79,8 +131,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', type=int, default=0, help='replay the decode step from a hipGraph')
+    ap.add_argument('--workload', default='c3', choices=['c3', 'c4'],
+                    help='c3 = beamed decode (the BASELINE metric, default); c4 = train step (BASELINE configs[3])')
     args = ap.parse_args()
 
+    if args.workload == 'c4':
+        return train_bench(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

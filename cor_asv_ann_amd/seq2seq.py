@@ -290,19 +290,24 @@ class Sequence2Sequence(object):
                             val[i, j + k, slot] = p
                     j += width
         else:
-            # plain strings: one table lookup over all code points of the batch
+            # plain strings: ONE table lookup over all code points of the batch
             keys, values = self._codepoint_table()
-            for i, line in enumerate(lines):
-                if not line:
-                    continue
-                cps = np.frombuffer(line.encode('utf-32-le', 'surrogatepass'), dtype=np.uint32)
+            lens = np.fromiter((len(line) for line in lines), dtype=np.int64, count=B)
+            total = int(lens.sum())
+            if total:
+                cps = np.frombuffer(''.join(lines).encode('utf-32-le', 'surrogatepass'), dtype=np.uint32)
                 pos = np.minimum(np.searchsorted(keys, cps), len(keys) - 1)
                 hit = keys[pos] == cps
+                rows = np.repeat(np.arange(B), lens)
+                cols = np.arange(total) - np.repeat(np.cumsum(lens) - lens, lens)
                 if not hit.all():
                     for j in np.nonzero(~hit)[0]:
-                        self._index(line[int(j)], 'encoder input', i)      # logs like the reference
-                idx[i, :len(cps), 0] = np.where(hit, values[pos], 0)
-                val[i, :len(cps), 0] = conf[i] if conf else 1.0
+                        self._index(lines[int(rows[j])][int(cols[j])], 'encoder input', int(rows[j]))   # logs like the reference
+                idx[rows, cols, 0] = np.where(hit, values[pos], 0)
+                if conf:
+                    val[rows, cols, 0] = np.concatenate([np.asarray(c, np.float32) for c in conf if len(c)])
+                else:
+                    val[rows, cols, 0] = 1.0
         return idx, val, conf
 
     @staticmethod
