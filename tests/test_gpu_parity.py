@@ -143,6 +143,39 @@ def test_beam_parameters(params):
     assert np.allclose(got[2], want[2], atol=1e-4)
 
 
+def test_large_vocabulary_and_wide_beam():
+    """V = 640 (the size class of the published models, not a multiple of 64/128) and N = 32 hypotheses per step."""
+    cfg = ModelConfig(depth=2, width=64, voc_size=640)
+    weights = make_weights(cfg, emb_scale=12.0)
+    om = OracleModel(cfg, weights, batch_size=32)
+    lines, _ = make_lines(4, 12, 17, voc_size=640)
+    s2s = _facade(cfg, weights, om.mapping, N=32)
+    for fast, greedy in ((True, True), (False, False)):
+        want = correct_lines(om, lines, fast=fast, greedy=greedy)
+        got = s2s.correct_lines(lines, fast=fast, greedy=greedy)
+        assert got[0] == want[0]
+        assert np.allclose(got[2], want[2], atol=1e-4)
+
+
+def test_argument_errors_are_reported():
+    from cor_asv_ann_amd.engine import HipEngine
+    from cor_asv_ann_amd._native import NativeError
+    with pytest.raises(NativeError):
+        HipEngine(2, 100, 64)                       # width not a multiple of 32
+    cfg = ModelConfig(depth=1, width=32, voc_size=16)
+    eng = HipEngine(1, 32, 16)
+    with pytest.raises(NativeError):
+        eng.decode_greedy()                         # nothing encoded, weights not committed
+    eng.set_weights(make_weights(cfg))
+    _, idx = make_lines(2, 5, 1, voc_size=16)
+    eng.encode(idx)
+    with pytest.raises(NativeError):
+        eng.decode_beam(batch_size=300)             # N out of range
+    with pytest.raises(NativeError):
+        eng.decode_beam(batch_size=256, beam_width_in=50)    # N * (width + 1) > 4096
+    eng.close()
+
+
 def test_beam_generator_yields_best_first():
     cfg = ModelConfig(depth=2, width=64, voc_size=96)
     weights = make_weights(cfg, emb_scale=12.0)
