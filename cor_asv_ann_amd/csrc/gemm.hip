@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     const GemmArgs& g = batch.g[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int step = g.step_ptr ? *g.step_ptr : g.step_imm;
+    // wave-uniform by construction; say so (the value arrives through a vector load)
+    const int step = __builtin_amdgcn_readfirstlane(g.step_ptr ? *g.step_ptr : g.step_imm);
     const int nbn = (g.N + BN - 1) / BN;
     int bn = blockIdx.x % nbn, bm = blockIdx.x / nbn;
     if (g.xcd_rows > 0) {
@@ -94,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     CASV_SETUP_SEG(1, ap1, tiles1)
     CASV_SETUP_SEG(2, ap2, tiles2)
 #undef CASV_SETUP_SEG
-    const int c0 = tiles0, c1 = c0 + tiles1, ntiles_all = c1 + tiles2;
+    const int c0 = __builtin_amdgcn_readfirstlane(tiles0), c1 = __builtin_amdgcn_readfirstlane(tiles0 + tiles1);
+    const int ntiles_all = __builtin_amdgcn_readfirstlane(tiles0 + tiles1 + tiles2);
     // split-K: this block contracts k-tiles [kt_begin, kt_begin + ntiles)
     const int nsplit = gridDim.z;
     const int per = (ntiles_all + nsplit - 1) / nsplit;
@@ -109,30 +111,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
         bp[i] = g.Bt + (long long)n * g.Ktot + 4 * kc;
     }
 
-    f32x4 ga[2], gb[2];
-    auto load_tile = [&](int kt_rel) {
+    // Segment selection without control flow: pointer = ap0 + mask1*(ap1-ap0) + mask2*(ap2-ap0) with wave-uniform
+    // 0/-1 masks, so that the steady-state loop body stays ONE basic block (the scheduler interleaves only inside one).
+    const long long d1_0 = (long long)((const char*)ap1[0] - (const char*)ap0[0]), d1_1 = (long long)((const char*)ap1[1] - (const char*)ap0[1]);
+    const long long d2_0 = (long long)((const char*)ap2[0] - (const char*)ap0[0]), d2_1 = (long long)((const char*)ap2[1] - (const char*)ap0[1]);
+    struct GTile { f32x4 a[2], b[2]; };
+    auto load_tile = [&](GTile& gt, int kt_rel) {
         const int kt = kt_rel + kt_begin;
-        int kb;
-        if (kt < c0) {
-            const int ko = kt * BK;
-            ga[0] = *reinterpret_cast<const f32x4*>(ap0[0] + ko); ga[1] = *reinterpret_cast<const f32x4*>(ap0[1] + ko);
-            kb = koff0 + ko;
-        } else if (kt < c1) {
-            const int ko = (kt - c0) * BK;
-            ga[0] = *reinterpret_cast<const f32x4*>(ap1[0] + ko); ga[1] = *reinterpret_cast<const f32x4*>(ap1[1] + ko);
-            kb = koff1 + ko;
-        } else {
-            const int ko = (kt - c1) * BK;
-            ga[0] = *reinterpret_cast<const f32x4*>(ap2[0] + ko); ga[1] = *reinterpret_cast<const f32x4*>(ap2[1] + ko);
-            kb = koff2 + ko;
-        }
-        gb[0] = *reinterpret_cast<const f32x4*>(bp[0] + kb); gb[1] = *reinterpret_cast<const f32x4*>(bp[1] + kb);
+        const long long m1 = (kt >= c0 && kt < c1) ? -1LL : 0LL, m2 = (kt >= c1) ? -1LL : 0LL;
+        const int ko = kt - ((int)m1 & c0) - ((int)m2 & c1);                       // tile index inside its segment
+        const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * BK;
+        const char* pa0 = (const char*)ap0[0] + (d1_0 & m1) + (d2_0 & m2) + (long long)ko * (BK * 4);
+        const char* pa1 = (const char*)ap0[1] + (d1_1 & m1) + (d2_1 & m2) + (long long)ko * (BK * 4);
+        gt.a[0] = *reinterpret_cast<const f32x4*>(pa0); gt.a[1] = *reinterpret_cast<const f32x4*>(pa1);
+        gt.b[0] = *reinterpret_cast<const f32x4*>(bp[0] + kb); gt.b[1] = *reinterpret_cast<const f32x4*>(bp[1] + kb);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const GTile& gt, int buf) {
         float* sa = smem + buf * 2 * TILE_FLOATS + r0 * LDW + 4 * kc;
         float* sb = sa + TILE_FLOATS;
-        *reinterpret_cast<f32x4*>(sa) = ga[0]; *reinterpret_cast<f32x4*>(sa + 64 * LDW) = ga[1];
-        *reinterpret_cast<f32x4*>(sb) = gb[0]; *reinterpret_cast<f32x4*>(sb + 64 * LDW) = gb[1];
+        *reinterpret_cast<f32x4*>(sa) = gt.a[0]; *reinterpret_cast<f32x4*>(sa + 64 * LDW) = gt.a[1];
+        *reinterpret_cast<f32x4*>(sb) = gt.b[0]; *reinterpret_cast<f32x4*>(sb + 64 * LDW) = gt.b[1];
     };
     const int a_off = (wave * 32 + l31) * LDW + 4 * lh;
     const int b_off = TILE_FLOATS + l31 * LDW + 4 * lh;
@@ -183,34 +181,62 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     }
 
     Frag f0, f1;
-    // prologue: LDS[0] <- tile 0, F0 <- LDS[0], LDS[1] <- tile 1, G <- tile 2
-    if (ntiles > 0) { load_tile(0); store_tile(0); }
-    if (ntiles > 1) load_tile(1);
+    GTile g0, g1;
+    // prologue: LDS[0] <- tile 0, LDS[1] <- tile 1, F0 <- LDS[0]; G0 <- tile 2, G1 <- tile 3
+    if (ntiles > 0) load_tile(g0, 0);
+    if (ntiles > 1) load_tile(g1, 1);
+    if (ntiles > 0) store_tile(g0, 0);
+    if (ntiles > 1) store_tile(g1, 1);
+    if (ntiles > 2) load_tile(g0, 2);
+    if (ntiles > 3) load_tile(g1, 3);
     __syncthreads();
     if (ntiles > 0) read_frags(f0, 0);
-    if (ntiles > 1) store_tile(1);
-    if (ntiles > 2) load_tile(2);
-    __syncthreads();
 
-    // one pipelined tile step; FC = fragments of tile kt, FN = to be filled with tile kt+1
 #ifndef CASV_EXP
 #define CASV_EXP 0
 #endif
-#define CASV_TILE_STEP(FC, FN, KT)                                   \
-    {                                                                \
-        if (!(CASV_EXP & 4)) if ((KT) + 1 < ntiles) read_frags(FN, ((KT) + 1) & 1);       \
-        mma(FC);                                                     \
-        if (!(CASV_EXP & 8)) if ((KT) + 2 < ntiles) store_tile((KT) & 1);                 \
-        if (!(CASV_EXP & 1)) if ((KT) + 3 < ntiles) load_tile((KT) + 3);                  \
-        if (!(CASV_EXP & 2)) __syncthreads();                                             \
+    // Steady state (tiles kt+1..kt+4 exist, no conditionals): while the 32 MFMAs of tile kt issue from FC,
+    //   LDS[kt&1] <- G (tile kt+2, requested two steps ago; the buffer's old content, tile kt, sits in FC)
+    //   G <- global tile kt+4 ;  FN <- LDS[(kt+1)&1]
+    // with the issue order pinned: one memory instruction + a few address ops behind each of the first MFMAs,
+    // so a wave has no memory-only phase in which its SIMD partner's MFMA stream starves its instruction issue.
+#define CASV_TILE_FULL(FC, FN, G, KT)                                                     \
+    {                                                                                     \
+        store_tile(G, (KT) & 1);                                                          \
+        load_tile(G, (KT) + 4);                                                           \
+        read_frags(FN, ((KT) + 1) & 1);                                                   \
+        mma(FC);                                                                          \
+        if (!(CASV_EXP & 16)) {                                                           \
+            _Pragma("unroll") for (int q_ = 0; q_ < 18; ++q_) {                           \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                        \
+                __builtin_amdgcn_sched_group_barrier(0x320, 1, 0);                        \
+            }                                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);                           \
+        }                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);   /* keep all 32 MFMAs in front of the barrier: by then the LDS ops have landed */ \
+        __syncthreads();                                                                  \
+    }
+#define CASV_TILE_STEP(FC, FN, G, KT)                                                     \
+    {                                                                                     \
+        if ((KT) + 2 < ntiles) store_tile(G, (KT) & 1);                                   \
+        if ((KT) + 4 < ntiles) load_tile(G, (KT) + 4);                                    \
+        if ((KT) + 1 < ntiles) read_frags(FN, ((KT) + 1) & 1);                            \
+        mma(FC);                                                                          \
+        __syncthreads();                                                                  \
     }
     int kt = 0;
-    for (; kt + 1 < ntiles; kt += 2) {
-        CASV_TILE_STEP(f0, f1, kt)
-        CASV_TILE_STEP(f1, f0, kt + 1)
+    for (; kt + 5 < ntiles; kt += 2) {
+        CASV_TILE_FULL(f0, f1, g0, kt)
+        CASV_TILE_FULL(f1, f0, g1, kt + 1)
     }
-    if (kt < ntiles) CASV_TILE_STEP(f0, f1, kt)
+    for (; kt + 1 < ntiles; kt += 2) {
+        CASV_TILE_STEP(f0, f1, g0, kt)
+        CASV_TILE_STEP(f1, f0, g1, kt + 1)
+    }
+    if (kt < ntiles) CASV_TILE_STEP(f0, f1, g0, kt)
 #undef CASV_TILE_STEP
+#undef CASV_TILE_FULL
 
     // ---- epilogue ----
     if (EPI == EPI_PLAIN) {
