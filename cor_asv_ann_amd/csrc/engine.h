@@ -46,6 +46,7 @@ inline const char* kProfNames[PC_COUNT] = {"lstm_gemm", "gemm", "attention", "so
 
 struct Prof {
     bool on = false;
+    bool only_lstm = false;          // level 2: events only around the dominant kernel (cheaper inside a timed region)
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     struct Rec { hipEvent_t a, b; int cls; };
@@ -102,12 +103,12 @@ struct casv_model {
     Prof prof;
 
     void prof_begin(int cls, double fl, double by, hipEvent_t& a) {
-        if (!prof.on) return;
+        if (!prof.on || (prof.only_lstm && cls != PC_LSTM)) return;
         a = prof.get(); (void)hipEventRecord(a, stream);
         prof.flops[cls] += fl; prof.bytes[cls] += by; prof.launches[cls] += 1;
     }
     void prof_end(int cls, hipEvent_t a) {
-        if (!prof.on) return;
+        if (!prof.on || (prof.only_lstm && cls != PC_LSTM)) return;
         hipEvent_t b = prof.get(); (void)hipEventRecord(b, stream);
         prof.recs.push_back({a, b, cls});
     }

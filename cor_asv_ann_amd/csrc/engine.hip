@@ -637,6 +637,7 @@ extern "C" int casv_profile(casv_model* m, int32_t enable) {
     HIPCHK(hipStreamSynchronize(m->stream));
     m->prof.reset();
     m->prof.on = enable != 0;
+    m->prof.only_lstm = enable == 2;
     return CASV_OK;
 }
 

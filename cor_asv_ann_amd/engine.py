@@ -205,7 +205,8 @@ class HipEngine(object):
 
     # -- measurement ---------------------------------------------------------------------------
     def profile(self, enable=True):
-        nv.check(self.lib.casv_profile(self.handle, int(bool(enable))))
+        """0/False = off, 1/True = every kernel class, 2 = only the dominant kernel (fused LSTM GEMM)."""
+        nv.check(self.lib.casv_profile(self.handle, int(enable)))
 
     def profile_read(self, name):
         launches, ms, fl, by = c_int64(), c_double(), c_double(), c_double()

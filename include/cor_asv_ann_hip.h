@@ -142,7 +142,8 @@ int casv_train_sync_weights(casv_model* m);
 int casv_train_end(casv_model* m);
 
 /* Measurement support for bench.py: per-kernel HIP-event timing on the library's stream.
- * casv_profile(m, 1) starts recording, casv_profile_read returns, for kernel class `name`
+ * casv_profile(m, 1) starts recording for all kernel classes, casv_profile(m, 2) only for "lstm_gemm" (fewer
+ * event records inside a timed region), casv_profile(m, 0) stops; casv_profile_read returns, for kernel class `name`
  * ("lstm_gemm", "gemm", "attention", "softmax", "beam", "embed"), the number of launches, their
  * summed duration (ms) and their summed algorithmic FLOPs and bytes. */
 int casv_profile(casv_model* m, int32_t enable);
