@@ -142,11 +142,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
     torch = None
+    backend = os.environ.get('CASV_BENCH_BACKEND', 'nccl')     # 'gloo' + CASV_BENCH_SAME_DEVICE=1: rehearsal of the
+    if os.environ.get('CASV_BENCH_SAME_DEVICE'):               # N-rank path on a one-GPU box (all ranks on device 0)
+        local_rank = 0
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from oracle.weights import make_lines
     from cor_asv_ann_amd import sharding
@@ -159,7 +165,7 @@ def main():
     if args.graph:
         eng.set_option('graph', 1)
     S = 2 * (LENGTH + 1)
-    device = ('cuda:%d' % local_rank) if world > 1 else None
+    device = ('cuda:%d' % local_rank) if (world > 1 and backend == 'nccl') else None
 
     def step():
         out_lines, probs, scores, _ = s2s.correct_lines(lines, fast=False, greedy=False, alignments=False)
@@ -182,9 +188,11 @@ def main():
     def sync():
         eng.synchronize()
         if world > 1:
-            torch.cuda.synchronize()
+            if backend == 'nccl':
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == 'nccl':
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -202,7 +210,7 @@ def main():
     others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'gemm', 'attention', 'softmax', 'beam', 'embed')}
     eng.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device or 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
