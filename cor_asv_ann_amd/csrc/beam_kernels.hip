@@ -14,7 +14,6 @@
 
 namespace casv {
 
-constexpr int NEWMAX = 4096;      // N * (beam_width_in + 1) must not exceed this
 constexpr int ROWMAX = 256;       // N <= 256
 constexpr int VPL = 16;           // V <= 64 * VPL
 
@@ -40,7 +39,6 @@ __global__ void beam_init_kernel(const BeamState s, const BeamParams p) {
         s.f_n[line] = 0; s.f_total[line] = 0;
         s.nact[line] = 1; s.line_done[line] = 0; s.line_steps[line] = 0;
         s.beam_node[line * N] = 0;
-        s.beam0_key[line] = 0.0;
         if (line == 0) *s.active_lines = s.B;
     }
     for (int i = threadIdx.x; i < N; i += blockDim.x) s.prev[line * N + i] = line * N;

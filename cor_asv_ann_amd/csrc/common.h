@@ -123,15 +123,15 @@ struct BeamState {
     int* n_k; int* n_rejpos; double* n_pos; int* n_is1;
     int* n_count;               // [B]
     // per expansion row [(S+1)*R]
-    short* created;             // [..][16]
-    // queue [B][q_cap + 16N] keys + ids, ping-pong not needed (rebuilt through LDS)
+    short* created;             // [..][beam_width_in + 1] vocabulary indices of the children, in creation order
+    // queue: two buffers [2][B][q_cap] of (key, node id) sorted best-first (step parity selects the live one);
+    // q_n[0..B) = entries, q_n[B..2B) = offset of the first entry after the last pop
     double* q_key; int* q_id; int* q_n;
     // finals
     double* f_key; int* f_id; int* f_n; int* f_total;
     // current beam
     int* beam_node;             // [R]
     int* nact;                  // [B] active rows of the current step
-    double* beam0_key;          // [B]
     int* line_done;             // [B]
     int* line_steps;            // [B]
     int* active_lines;          // [1]

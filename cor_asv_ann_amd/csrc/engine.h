@@ -78,7 +78,7 @@ struct casv_model {
     std::map<std::string, size_t> expect;                // name -> element count
     bool committed = false;
     // packed device weights
-    DevBuf E, ETp, WaT, bUW, va, bv, UT;
+    DevBuf E, WaT, bUW, va, bv, UT;
     LstmW enc_fw, enc_bw;
     std::vector<LstmW> enc, dec;                         // enc[n] for layer n>=2 at index n; dec[n] n=1..D
     // encoder session
@@ -89,11 +89,11 @@ struct casv_model {
     // decode session
     int R = 0, S = 0;
     std::vector<DevBuf> st_h, st_c;
-    DevBuf st_a, st_p, y0, ctx, wq, logits, prev, pin, apos, amax1, d_step, d_line, d_nan;
+    DevBuf st_a, st_p, ctx, wq, logits, prev, pin, apos, amax1, d_step, d_line, d_nan;
     DevBuf o_idx, o_prob, o_align;
     // beam
     DevBuf b_parent, b_chr, b_prob, b_cum, b_len, b_exp, b_k, b_rejpos, b_pos, b_is1, b_count, b_created;
-    DevBuf b_qkey, b_qid, b_qn, b_fkey, b_fid, b_fn, b_ftotal, b_beamnode, b_nact, b_beam0, b_done, b_steps, b_active;
+    DevBuf b_qkey, b_qid, b_qn, b_fkey, b_fid, b_fn, b_ftotal, b_beamnode, b_nact, b_done, b_steps, b_active;
     DevBuf bo_idx, bo_prob, bo_len, bo_score, bo_rej, bo_align, bo_found, bo_nsteps;
     // training session (train.hip)
     TrainState* train = nullptr;

@@ -58,13 +58,13 @@ extern "C" void casv_model_destroy(casv_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
-    DevBuf* bufs[] = {&m->E, &m->ETp, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
+    DevBuf* bufs[] = {&m->E, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
         &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->Hc, &m->cfin,
-        &m->hfin, &m->u, &m->st_a, &m->st_p, &m->y0, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
+        &m->hfin, &m->u, &m->st_a, &m->st_p, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
         &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->b_parent, &m->b_chr, &m->b_prob,
         &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos, &m->b_pos, &m->b_is1, &m->b_count, &m->b_created,
         &m->b_qkey, &m->b_qid, &m->b_qn, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_beamnode, &m->b_nact,
-        &m->b_beam0, &m->b_done, &m->b_steps, &m->b_active, &m->bo_idx, &m->bo_prob, &m->bo_len, &m->bo_score,
+        &m->b_done, &m->b_steps, &m->b_active, &m->bo_idx, &m->bo_prob, &m->bo_len, &m->bo_score,
         &m->bo_rej, &m->bo_align, &m->bo_found, &m->bo_nsteps};
     for (DevBuf* b : bufs) b->release();
     for (auto& l : m->enc) { l.wt.release(); l.bias.release(); }
@@ -154,9 +154,6 @@ extern "C" int casv_commit_weights(casv_model* m) {
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, D = m->D;
     const auto& E = m->host["E"];
     if (int rc = upload(m->E, E)) return rc;
-    std::vector<float> etp((size_t)W * Vp, 0.f);
-    for (int v = 0; v < V; ++v) for (int w = 0; w < W; ++w) etp[(size_t)w * Vp + v] = E[(size_t)v * W + w];
-    if (int rc = upload(m->ETp, etp)) return rc;
     if (int rc = pack_lstm(m, m->enc_fw, "enc1_fw", W)) return rc;
     if (int rc = pack_lstm(m, m->enc_bw, "enc1_bw", W)) return rc;
     for (int n = 2; n <= D; ++n) if (int rc = pack_lstm(m, m->enc[n], "enc" + std::to_string(n), n == 2 ? 2 * W : W)) return rc;
@@ -319,7 +316,6 @@ static int ensure_session(casv_model* m, int R, int S) {
     }
     if (int rc = m->st_a.ensure(slots * T * 4)) return rc;
     if (int rc = m->st_p.ensure(slots * Vp * 4)) return rc;
-    if (int rc = m->y0.ensure((size_t)R * W * 4)) return rc;
     if (int rc = m->ctx.ensure((size_t)R * C * 4)) return rc;
     if (int rc = m->wq.ensure((size_t)R * W * 4)) return rc;
     if (int rc = m->logits.ensure((size_t)R * Vp * 4)) return rc;
@@ -564,7 +560,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     ENS(m->b_count, (size_t)B * 4) ENS(m->b_created, (size_t)(S + 1) * R * CM * 2)
     ENS(m->b_qkey, (size_t)2 * B * s.q_cap * 8) ENS(m->b_qid, (size_t)2 * B * s.q_cap * 4) ENS(m->b_qn, (size_t)2 * B * 4)
     ENS(m->b_fkey, (size_t)B * s.f_cap * 8) ENS(m->b_fid, (size_t)B * s.f_cap * 4) ENS(m->b_fn, (size_t)B * 4) ENS(m->b_ftotal, (size_t)B * 4)
-    ENS(m->b_beamnode, (size_t)R * 4) ENS(m->b_nact, (size_t)B * 4) ENS(m->b_beam0, (size_t)B * 8) ENS(m->b_done, (size_t)B * 4)
+    ENS(m->b_beamnode, (size_t)R * 4) ENS(m->b_nact, (size_t)B * 4) ENS(m->b_done, (size_t)B * 4)
     ENS(m->b_steps, (size_t)B * 4) ENS(m->b_active, 16)
     const size_t OR = (size_t)B * MR;
     ENS(m->bo_idx, OR * S * 4) ENS(m->bo_prob, OR * S * 4) ENS(m->bo_len, OR * 4) ENS(m->bo_score, OR * 8) ENS(m->bo_rej, OR * S * 4)
@@ -577,7 +573,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     s.n_count = m->b_count.as<int>(); s.created = m->b_created.as<short>();
     s.q_key = m->b_qkey.as<double>(); s.q_id = m->b_qid.as<int>(); s.q_n = m->b_qn.as<int>();
     s.f_key = m->b_fkey.as<double>(); s.f_id = m->b_fid.as<int>(); s.f_n = m->b_fn.as<int>(); s.f_total = m->b_ftotal.as<int>();
-    s.beam_node = m->b_beamnode.as<int>(); s.nact = m->b_nact.as<int>(); s.beam0_key = m->b_beam0.as<double>();
+    s.beam_node = m->b_beamnode.as<int>(); s.nact = m->b_nact.as<int>();
     s.line_done = m->b_done.as<int>(); s.line_steps = m->b_steps.as<int>(); s.active_lines = m->b_active.as<int>();
     s.prev = m->prev.as<int>(); s.p_in = m->pin.as<float>(); s.p_base = m->st_p.as<float>();
     s.apos = m->apos.as<double>(); s.amax1 = m->amax1.as<int>(); s.src_rej = m->d_srcrej.as<int>();
