@@ -151,7 +151,7 @@ extern "C" int casv_commit_weights(casv_model* m) {
     HIPCHK(hipSetDevice(m->device));
     for (auto& kv : m->expect)
         if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());
-    const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, D = m->D;
+    const int W = m->W, C = m->C, D = m->D;
     const auto& E = m->host["E"];
     if (int rc = upload(m->E, E)) return rc;
     if (int rc = pack_lstm(m, m->enc_fw, "enc1_fw", W)) return rc;

@@ -133,6 +133,7 @@ static void refresh_derived(casv_model* m) {
 
 extern "C" int casv_train_begin(casv_model* m, const casv_adam_params* ap, const char* frozen_csv) {
     if (!m || !ap) return fail(CASV_ERR_ARG, "null argument");
+    if (m->W > 1024) return fail(CASV_ERR_ARG, "training supports width <= 1024");
     HIPCHK(hipSetDevice(m->device));
     for (auto& kv : m->expect)
         if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());
@@ -304,6 +305,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     const int L = std::max(T, U);
     const long long TB = (long long)T * B, UB = (long long)U * B, LB = (long long)L * B;
     ts->B = B; ts->T = T; ts->U = U; ts->A = A;
+    m->encoded = false;                    // the final-state buffers are shared with the inference session
     const bool training = mode != 0;
 
     // ---- buffers ----
