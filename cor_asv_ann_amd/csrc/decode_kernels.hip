@@ -174,11 +174,13 @@ __global__ __launch_bounds__(256) void softmax_kernel(const SoftmaxArgs a) {
     sum = wave_sum(sum);
     float best = -INFINITY; int bidx = 0x7fffffff;          // over v >= 1
     float p0 = 0.0f;
-    for (int v = lane; v < V; v += 64) {
-        const float pv = expf(x[v] - m) / sum;
+    for (int v = lane; v < Vp; v += 64) {
+        // columns V..Vp-1 are padding of the K dimension of the next step's GEMM: they must be exact zeros
+        // (their weight rows are zero, but 0 * stale-NaN would poison the row)
+        const float pv = v < V ? expf(x[v] - m) / sum : 0.0f;
         p[v] = pv;
         if (v == 0) p0 = pv;
-        if (v >= 1 && pv > best) { best = pv; bidx = v; }
+        if (v >= 1 && v < V && pv > best) { best = pv; bidx = v; }
     }
     if (a.mode < 0) return;
 #pragma unroll

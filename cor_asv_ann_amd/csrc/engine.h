@@ -8,6 +8,7 @@
 #include "../../include/cor_asv_ann_hip.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstring>
 #include <map>
@@ -35,6 +36,10 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return fail(CASV_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         cap = bytes;
+        // CASV_POISON=1 (tests): fresh buffers hold 0xFF bytes (NaN as float, -1 as int) so that any read of memory
+        // the kernels have not written shows up in the results instead of depending on what the allocator returns
+        static const bool poison = getenv("CASV_POISON") && getenv("CASV_POISON")[0] == '1';
+        if (poison) (void)hipMemset(p, 0xFF, bytes);
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
