@@ -58,3 +58,49 @@ def test_random_beam_configurations(seed, ncase):
                 bad.append((case, j, dict(d=d, W=W, V=V, B=B, L=L, es=es, seed=wseed, **kw)))
         s2s.engine.close()
     assert total > 50 and not bad, bad
+
+
+def test_random_train_steps():
+    """Loss and every gradient tensor of the device train step against the oracle over random shapes (odd batch
+    sizes, ragged sources/targets, with and without dropout masks)."""
+    from cor_asv_ann_amd.engine import HipEngine
+    from oracle import vectorize_lines
+    from oracle.train import forward_backward
+    rng = np.random.default_rng(3)
+    idx_of = lambda a: np.where(a.any(axis=2), a.argmax(axis=2), -1).astype(np.int32)
+    for case in range(12):
+        d = int(rng.integers(1, 5)); W = int(rng.choice([32, 64])); V = int(rng.choice([20, 50, 100])); B = int(rng.integers(1, 8))
+        L = int(rng.integers(2, 14)); Lt = int(rng.integers(2, 14)); es = float(rng.choice([1., 3., 6.]))
+        masks_on = rng.random() < 0.6
+        cfg = ModelConfig(depth=d, width=W, voc_size=V)
+        w = make_weights(cfg, seed=int(rng.integers(1, 10 ** 6)), emb_scale=es)
+        for k in w:
+            if k.endswith('_b') or k in ('att_bUW', 'att_bv'):
+                w[k] = (w[k] + rng.normal(size=w[k].shape) * 0.2).astype(np.float32)
+        om = OracleModel(cfg, w)
+        src, _ = make_lines(B, L, int(rng.integers(1, 10 ** 6)), voc_size=V)
+        tgt, _ = make_lines(B, Lt, int(rng.integers(1, 10 ** 6)), voc_size=V)
+        if B > 1:
+            tgt[0] = tgt[0][:max(1, Lt // 2)] + '\n'
+            src[-1] = src[-1][:max(1, L // 2)] + '\n'
+        enc_in, dec_in, dec_out, wts = vectorize_lines(om, src, tgt)
+        C = cfg.ctx_width
+        masks = None
+        if masks_on:
+            keep = lambda shape: ((rng.random(shape) > 0.2) / 0.8).astype(np.float32)
+            masks = {'enc': [keep(2 * W if n == 0 else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
+                     'cell': keep((B, W + C))}
+        loss, grads, _ = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, masks)
+        eng = HipEngine(d, W, V)
+        eng.set_weights(w)
+        eng.train_begin()
+        gl, gn = eng.train_step(idx_of(enc_in), None, idx_of(dec_in), idx_of(dec_out), wts, masks, mode=2)
+        gg = eng.train_gradients()
+        onorm = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values()))
+        assert abs(gl - loss) < 3e-5 * abs(loss) and abs(gn - onorm) < 1e-4 * onorm, (case, gl, loss)
+        for k in grads:
+            if k == 'att_bv':
+                continue                           # analytically zero (sum of softmax-Jacobian rows)
+            assert np.abs(gg[k] - grads[k]).max() < 2e-3 * max(np.abs(grads[k]).max(), 1e-6 * onorm), (case, k)
+        eng.train_end()
+        eng.close()
