@@ -104,3 +104,56 @@ def test_random_train_steps():
             assert np.abs(gg[k] - grads[k]).max() < 2e-3 * max(np.abs(grads[k]).max(), 1e-6 * onorm), (case, k)
         eng.train_end()
         eng.close()
+
+
+def test_random_greedy_inputs():
+    """Fast (batched greedy) and per-line greedy decoding over random shapes and the three input forms
+    (plain, probability lines, confusion networks with alternatives of different length)."""
+    from cor_asv_ann_amd.seq2seq import Sequence2Sequence
+    rng = np.random.default_rng(11)
+    checked = 0
+    for case in range(30):
+        d = int(rng.integers(1, 4)); W = int(rng.choice([32, 64])); V = int(rng.choice([24, 64, 100, 257]))
+        B = int(rng.integers(1, 7)); L = int(rng.integers(3, 16)); es = float(rng.choice([2., 6., 10.]))
+        kind = str(rng.choice(['plain', 'prob', 'confmat']))
+        cfg = ModelConfig(depth=d, width=W, voc_size=V)
+        wseed = int(rng.integers(1, 10 ** 6))
+        lines, _ = make_lines(B, L, wseed, voc_size=V)
+        if B > 1:
+            lines[0] = lines[0][:max(1, L // 2)] + '\n'
+        if kind == 'plain':
+            inp, conf = lines, None
+        elif kind == 'prob':
+            inp, conf = lines, [list(rng.uniform(0.3, 1.0, len(line)).astype(np.float32)) for line in lines]
+        else:
+            conf = []
+            for line in lines:
+                chunks = []
+                for k, ch in enumerate(line):
+                    if ch != '\n' and rng.random() < 0.4:
+                        p = float(rng.uniform(0.5, 0.9))
+                        alt = line[(k + 1) % (len(line) - 1)]
+                        chunks.append([(ch, p), (alt + ch if rng.random() < 0.5 else alt, 1 - p)])
+                    else:
+                        chunks.append([(ch, 1.0)])
+                conf.append(chunks)
+            inp = conf
+        res = {}
+        for dt in (np.float32, np.float64):
+            om = OracleModel(cfg, make_weights(cfg, seed=wseed, dtype=dt, emb_scale=es))
+            res[dt] = correct_lines(om, inp, conf, fast=True, greedy=True)
+        w32 = make_weights(cfg, seed=wseed, emb_scale=es)
+        s2s = Sequence2Sequence()
+        s2s.depth, s2s.width = d, W
+        s2s.mapping, s2s.voc_size = OracleModel(cfg, w32).mapping, V
+        s2s.configure(); s2s.set_weights(w32); s2s.status = 2
+        got = s2s.correct_lines(inp, conf, fast=True, greedy=True)
+        for j in range(B):
+            if res[np.float64][0][j] != res[np.float32][0][j]:
+                continue                                  # ill-conditioned line
+            checked += 1
+            assert got[0][j] == res[np.float32][0][j], (case, j, kind)
+            assert abs(got[2][j] - res[np.float32][2][j]) < 1e-4
+            assert np.allclose(got[1][j], res[np.float32][1][j], rtol=2e-4, atol=2e-6)
+        s2s.engine.close()
+    assert checked > 40
