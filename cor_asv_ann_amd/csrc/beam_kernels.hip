@@ -15,7 +15,6 @@
 namespace casv {
 
 constexpr int ROWMAX = 256;       // N <= 256
-constexpr int VPL = 16;           // V <= 64 * VPL
 
 __device__ __forceinline__ bool before(double ka, int ia, double kb, int ib) {
     if (ia == 0x7fffffff) return false;
@@ -48,7 +47,10 @@ void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t strea
     hipLaunchKernelGGL(beam_init_kernel, dim3(s.B), dim3(256), 0, stream, s, p);
 }
 
-__global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const BeamParams p) {
+// VPL = vocabulary entries per lane (V <= 64 * VPL); NWV = waves per workgroup (one wave expands one hypothesis row)
+template <int VPL, int NWV>
+__global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, const BeamParams p) {
+    constexpr int NT = 64 * NWV;
     // dynamic LDS: [npow2 new keys (f64)] [q_stage old keys (f64)] [npow2 new ids] [q_stage old ids]
     extern __shared__ __attribute__((aligned(16))) unsigned char beam_smem[];
     __shared__ int r_count[ROWMAX], r_off[ROWMAX + 1], r_beampos[ROWMAX], r_rej[ROWMAX], r_srcpos[ROWMAX];
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
     if (step + 1 >= s.S) return;       // children of the last iteration are never popped (s2s:1398)
 
     // ---------------- A1: per row, rejection overwrite + child count ----------------
-    for (int i = wave; i < nact; i += 4) {
+    for (int i = wave; i < nact; i += NWV) {
         const int r = line * N + i;
         const long long exp = (long long)(step + 1) * R + r;
         float* sc = const_cast<float*>(s.p_base) + exp * Vp;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
     const int id0 = s.n_count[line];
 
     // ---------------- A2: iterative selection, node records, keys ----------------
-    for (int i = wave; i < nact; i += 4) {
+    for (int i = wave; i < nact; i += NWV) {
         if (r_count[i] == 0) continue;
         const int r = line * N + i;
         const long long exp = (long long)(step + 1) * R + r;
@@ -230,11 +232,11 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
     // ---------------- B: sort the new nodes, merge with the queue, cap ----------------
     int npow = 1;
     while (npow < nnew) npow <<= 1;
-    for (int i = nnew + tid; i < npow; i += 256) { s_key[i] = 0.0; s_id[i] = 0x7fffffff; }
+    for (int i = nnew + tid; i < npow; i += NT) { s_key[i] = 0.0; s_id[i] = 0x7fffffff; }
     __syncthreads();
     for (int k = 2; k <= npow; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow; i += 256) {
+            for (int i = tid; i < npow; i += NT) {
                 const int l = i ^ j;
                 if (l > i) {
                     const bool up = (i & k) == 0;
@@ -257,10 +259,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
     const int qcap = 2 * T * N;                   // max_batches * batch_size (s2s:1531)
     const bool staged = qn_old <= q_stage;
     if (staged) {                                 // one coalesced pass instead of log2(n) dependent HBM probes
-        for (int i = tid; i < qn_old; i += 256) { o_key[i] = okey[i]; o_id[i] = oid[i]; }
+        for (int i = tid; i < qn_old; i += NT) { o_key[i] = okey[i]; o_id[i] = oid[i]; }
         __syncthreads();
     }
-    for (int i = tid; i < qn_old; i += 256) {     // old element i moves behind the new ones before it
+    for (int i = tid; i < qn_old; i += NT) {      // old element i moves behind the new ones before it
         const double k = staged ? o_key[i] : okey[i]; const int id = staged ? o_id[i] : oid[i];
         int lo = 0, hi = nnew;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(s_key[mid], s_id[mid], k, id)) lo = mid + 1; else hi = mid; }
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
         if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
         if (pos < 64) { pop_key[pos] = k; pop_id[pos] = id; }
     }
-    for (int j = tid; j < nnew; j += 256) {
+    for (int j = tid; j < nnew; j += NT) {
         const double k = s_key[j]; const int id = s_id[j];
         int lo = 0, hi = qn_old;
         if (staged) {
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamState s, const
     if (sh_done) return;
     const int nb = sh_nb;
     // next step's inputs: fed-back scores with the better siblings reset (s2s:1515-1520); one wave per row
-    for (int j = wave; j < N; j += 4) {
+    for (int j = wave; j < N; j += NWV) {
         const int r = line * N + j;
         float* pin = s.p_in + (long long)r * Vp;
         if (j < nb) {
@@ -360,7 +362,13 @@ void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t strea
     const size_t lds = beam_lds_bytes(p.N, p.width_in, s.q_cap, &q_stage);
     BeamParams pp = p;
     pp.q_stage = q_stage;
-    hipLaunchKernelGGL(beam_step_kernel, dim3(s.B), dim3(256), lds, stream, s, pp);
+    const int vpl = (s.V + 63) / 64;
+    const bool wide = p.N >= 8;          // eight waves: one hypothesis row per wave at the default N = 8
+#define CASV_BEAM_LAUNCH(VPL_, NWV_) hipLaunchKernelGGL((beam_step_kernel<VPL_, NWV_>), dim3(s.B), dim3(64 * NWV_), lds, stream, s, pp)
+    if (vpl <= 4) { if (wide) CASV_BEAM_LAUNCH(4, 8); else CASV_BEAM_LAUNCH(4, 4); }
+    else if (vpl <= 8) { if (wide) CASV_BEAM_LAUNCH(8, 8); else CASV_BEAM_LAUNCH(8, 4); }
+    else { if (wide) CASV_BEAM_LAUNCH(16, 8); else CASV_BEAM_LAUNCH(16, 4); }
+#undef CASV_BEAM_LAUNCH
 }
 
 // Results, best first (seq2seq.py:1538-1544): walk the trie from each finished node to the root.
