@@ -42,6 +42,7 @@ struct GemmArgs {
     SlotPtr zinit;        // LSTM: pre-activation term added to the contraction, [M][4U] interleaved (x.K + b of all steps, precomputed)
     SlotPtr gates_out;    // training: activated gates i,f,g,o, [M][4U] in the interleaved column order (or null)
     int accumulate;       // PLAIN: C += A.B^T instead of C = (weight-gradient sums)
+    int kgroups;          // 2 = allow the two-wave-group split-K variant (train step; changes the summation order)
     int xcd_rows;         // XCD-aware tile order: the 8 XCDs form an xcd_rows x (8/xcd_rows) grid over the tile grid (0 = off)
     int ksplit;           // PLAIN: 0/1 = one block per tile; n > 1 = K split over n blocks (float atomics into C);
                           // -1 = let the launcher choose (train step only: sums become order-dependent)

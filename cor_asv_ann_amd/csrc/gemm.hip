@@ -48,11 +48,17 @@ __device__ __forceinline__ float tanhf_(float x) {
 //                                     content, tile kt, already sits in F[kt&1])
 //     G           <- global tile kt+3
 //   one barrier per tile.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// KS = 2 (train step only): two 4-wave groups per workgroup take alternate K-tiles of the SAME output tile and add
+// their accumulators through LDS before the epilogue -- a deterministic split-K that halves the critical path of the
+// small-M recurrent GEMMs (M = 512 gives only 64 workgroups).  Inference keeps KS = 1 so that a row's sum order never
+// depends on the batch it sits in.
+template <int EPI, int KS>
+__global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const GemmArgs& g = batch.g[blockIdx.y];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = KS > 1 ? (threadIdx.x >> 8) : 0;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    float* smem = smem_all + grp * (2 * 2 * TILE_FLOATS);
     const int l31 = lane & 31, lh = lane >> 5;
     // wave-uniform by construction; say so (the value arrives through a vector load)
     const int step = __builtin_amdgcn_readfirstlane(g.step_ptr ? *g.step_ptr : g.step_imm);
@@ -101,7 +107,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     const int nsplit = gridDim.z;
     const int per = (ntiles_all + nsplit - 1) / nsplit;
     const int kt_begin = blockIdx.z * per;
-    const int ntiles = ntiles_all - kt_begin < per ? (ntiles_all - kt_begin > 0 ? ntiles_all - kt_begin : 0) : per;
+    const int nt_blk = ntiles_all - kt_begin < per ? (ntiles_all - kt_begin > 0 ? ntiles_all - kt_begin : 0) : per;
+    // this wave group's share: tiles kt_begin + KS*i + grp
+    const int ntiles = (nt_blk - grp + KS - 1) / KS, nt_min = nt_blk / KS, nt_max = (nt_blk + KS - 1) / KS;
     const int koff0 = g.a[0].koff, koff1 = g.a[1].koff, koff2 = g.a[2].koff;
 
     const float* bp[2];
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     const long long d2_0 = (long long)((const char*)ap2[0] - (const char*)ap0[0]), d2_1 = (long long)((const char*)ap2[1] - (const char*)ap0[1]);
     struct GTile { f32x4 a[2], b[2]; };
     auto load_tile = [&](GTile& gt, int kt_rel) {
-        const int kt = kt_rel + kt_begin;
+        const int kt = kt_rel * KS + grp + kt_begin;
         const long long m1 = (kt >= c0 && kt < c1) ? -1LL : 0LL, m2 = (kt >= c1) ? -1LL : 0LL;
         const int ko = kt - ((int)m1 & c0) - ((int)m2 & c1);                       // tile index inside its segment
         const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * BK;
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
 
     // LSTM: previous cell state of this lane's 16 (row, unit) elements, fetched under the main loop
     float cpv[16];
-    if (EPI == EPI_LSTM) {
+    if (EPI == EPI_LSTM && grp == 0) {
         const bool cfirst = g.c_in.first_base && step == 0;
         const bool czero = g.c_in.skip_first && step == 0 && !cfirst;
         const float* cin = cfirst ? g.c_in.first_base
@@ -222,21 +230,37 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
         if ((KT) + 2 < ntiles) store_tile(G, (KT) & 1);                                   \
         if ((KT) + 4 < ntiles) load_tile(G, (KT) + 4);                                    \
         if ((KT) + 1 < ntiles) read_frags(FN, ((KT) + 1) & 1);                            \
-        mma(FC);                                                                          \
+        if ((KT) < ntiles) mma(FC);                                                       \
         __syncthreads();                                                                  \
     }
     int kt = 0;
-    for (; kt + 5 < ntiles; kt += 2) {
+    for (; kt + 5 < nt_min; kt += 2) {          // both wave groups have all the tiles of the steady state
         CASV_TILE_FULL(f0, f1, g0, kt)
         CASV_TILE_FULL(f1, f0, g1, kt + 1)
     }
-    for (; kt + 1 < ntiles; kt += 2) {
+    for (; kt + 1 < nt_max; kt += 2) {          // same barrier count for both groups
         CASV_TILE_STEP(f0, f1, g0, kt)
         CASV_TILE_STEP(f1, f0, g1, kt + 1)
     }
-    if (kt < ntiles) CASV_TILE_STEP(f0, f1, g0, kt)
+    if (kt < nt_max) CASV_TILE_STEP(f0, f1, g0, kt)
 #undef CASV_TILE_STEP
 #undef CASV_TILE_FULL
+
+    if (KS > 1) {       // acc(group 0) += acc(group 1), through LDS (all staging reads are behind the last barrier)
+        float* red = smem_all + tid;
+        if (grp == 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(c * 16 + r) * 256] = acc[c][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] += red[(c * 16 + r) * 256];
+    }
 
     // ---- epilogue ----
     if (EPI == EPI_PLAIN) {
@@ -295,15 +319,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmBatch batch) {
     }
 }
 
-void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
+template <int EPI, int KS>
+static void launch_one(const GemmBatch& bb, int blocks, int ksplit, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI_PLAIN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI_LSTM>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GEMM_LDS_BYTES * KS);
         attr_set = true;
     }
+    hipLaunchKernelGGL((gemm_kernel<EPI, KS>), dim3(blocks, bb.count, ksplit), dim3(256 * KS), GEMM_LDS_BYTES * KS, stream, bb);
+}
+
+void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     int blocks = 0;
     for (int j = 0; j < b.count; ++j) {
         const int nb = ((b.g[j].M + BM - 1) / BM) * ((b.g[j].N + BN - 1) / BN);
@@ -343,11 +370,16 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
             else (void)hipMemset2DAsync(cbase, (size_t)g.out.ld * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream);
         }
     }
-    const dim3 grid(blocks, b.count, ksplit), block(256);
-    if (epi == EPI_LSTM)
-        hipLaunchKernelGGL(gemm_kernel<EPI_LSTM>, grid, block, GEMM_LDS_BYTES, stream, bb);
-    else
-        hipLaunchKernelGGL(gemm_kernel<EPI_PLAIN>, grid, block, GEMM_LDS_BYTES, stream, bb);
+    // wave-group split-K (train step only, GemmArgs.kgroups): worth it while the grid leaves CUs idle
+    bool two = true;
+    for (int j = 0; j < b.count; ++j) {
+        int ktiles = 0;
+        for (int i = 0; i < b.g[j].nseg; ++i) ktiles += b.g[j].a[i].width / BK;
+        if (b.g[j].kgroups != 2 || ktiles / ksplit < 16) two = false;
+    }
+    if (blocks * b.count * ksplit > 256) two = false;
+    if (epi == EPI_LSTM) { if (two) launch_one<EPI_LSTM, 2>(bb, blocks, ksplit, stream); else launch_one<EPI_LSTM, 1>(bb, blocks, ksplit, stream); }
+    else { if (two) launch_one<EPI_PLAIN, 2>(bb, blocks, ksplit, stream); else launch_one<EPI_PLAIN, 1>(bb, blocks, ksplit, stream); }
 }
 
 void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream) {

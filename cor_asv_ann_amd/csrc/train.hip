@@ -189,7 +189,7 @@ static GemmArgs plain_gemm(const float* A, long long lda, int M, int K, const fl
     GemmArgs g{};
     g.nseg = 1; g.a[0] = mkseg(A, (int)lda, K, 0);
     g.Bt = Bt; g.bias = bias; g.M = M; g.N = N; g.Ktot = K;
-    g.out = mkslot(C_, (int)ldc); g.accumulate = accumulate; g.ksplit = -1;
+    g.out = mkslot(C_, (int)ldc); g.accumulate = accumulate; g.ksplit = -1; g.kgroups = 2;
     return g;
 }
 
@@ -212,7 +212,7 @@ static GemmArgs layer_step_job(casv_model* m, TLayer& l, int k, const float* h0,
     g.c_in.first_base = c0;
     g.c_out = mkslot(l.Cs.as<float>(), W, (long long)B * W, mul, add_t);
     g.gates_out = mkslot(l.Gt.as<float>(), 4 * W, (long long)B * 4 * W, mul, add_t);
-    g.step_imm = k; g.step_ptr = nullptr;
+    g.step_imm = k; g.step_ptr = nullptr; g.kgroups = 2;
     return g;
 }
 
