@@ -5,6 +5,19 @@
 
 namespace casv {
 
+// tanh on the transcendental units (v_exp_f32 + v_rcp_f32): |error| <= ~2e-7 absolute.  The energies
+// need 11*W tanh per decoder row; libm's tanhf made this kernel VALU-bound at 5x the time.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    if (ax < 0.25f) {
+        const float x2 = x * x;
+        return x * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * (-0.0539682540f + x2 * 0.0218694885f))));
+    }
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ax * 2.88539008177792681472f));
+    return copysignf(t, x);
+}
+
+
 // One K-segment of a GEMM's A operand: rows of `width` floats (a multiple of 32) taken from
 //   base + slot * slot_stride + row_id * ld,   slot = step * step_mul + step_add,
 // where row_id = rows ? rows[m] : m.  `skip_first` drops the segment (treated as zeros) at
@@ -42,6 +55,7 @@ struct GemmArgs {
     SlotPtr zinit;        // LSTM: pre-activation term added to the contraction, [M][4U] interleaved (x.K + b of all steps, precomputed)
     SlotPtr gates_out;    // training: activated gates i,f,g,o, [M][4U] in the interleaved column order (or null)
     int accumulate;       // PLAIN: C += A.B^T instead of C = (weight-gradient sums)
+    int out_zeroed;       // PLAIN with split-K: the caller has already cleared the output (no memset per launch)
     int kgroups;          // 2 = allow the two-wave-group split-K variant (train step; changes the summation order)
     int xcd_rows;         // XCD-aware tile order: the 8 XCDs form an xcd_rows x (8/xcd_rows) grid over the tile grid (0 = off)
     int ksplit;           // PLAIN: 0/1 = one block per tile; n > 1 = K split over n blocks (float atomics into C);

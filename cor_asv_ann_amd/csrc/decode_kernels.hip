@@ -33,18 +33,6 @@ __device__ __forceinline__ float wave_max(float v) {
 constexpr int MAXWIN = 11;
 constexpr int ATT_ROWS = 8;      // rows (waves) per workgroup: the N=8 hypotheses of one line share u/enc rows in L1
 
-// tanh on the transcendental units (v_exp_f32 + v_rcp_f32): |error| <= ~2e-7 absolute.  The energies
-// need 11*W tanh per decoder row; libm's tanhf made this kernel VALU-bound at 5x the time.
-__device__ __forceinline__ float fast_tanh(float x) {
-    const float ax = fabsf(x);
-    if (ax < 0.25f) {
-        const float x2 = x * x;
-        return x * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * (-0.0539682540f + x2 * 0.0218694885f))));
-    }
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ax * 2.88539008177792681472f));
-    return copysignf(t, x);
-}
-
 __global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * ATT_ROWS + wave;

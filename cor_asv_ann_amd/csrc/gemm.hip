@@ -292,16 +292,20 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
         float* gout = g.gates_out.base
             ? g.gates_out.base + (long long)(step * g.gates_out.step_mul + g.gates_out.step_add) * g.gates_out.slot_stride
             : nullptr;
+        if (zin) {      // precomputed input term (train step): all loads issue before the first store of the loop below
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float* zr = zin + (long long)(m < g.M ? m : g.M - 1) * g.zinit.ld + n0 + l31;
+                acc[0][r] += zr[0]; acc[1][r] += zr[32]; acc[2][r] += zr[64]; acc[3][r] += zr[96];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m < g.M) {
                 const float cprev = cpv[r];
                 float zi = acc[0][r] + bi, zf = acc[1][r] + bf_, zg = acc[2][r] + bg, zo = acc[3][r] + bo;
-                if (zin) {
-                    const float* zr = zin + (long long)m * g.zinit.ld + n0 + l31;
-                    zi += zr[0]; zf += zr[32]; zg += zr[64]; zo += zr[96];
-                }
                 const float ig = sigmoidf_(zi);
                 const float fg = sigmoidf_(zf);
                 const float gg = tanhf_(zg);
@@ -353,18 +357,23 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
         g.xcd_rows = best_xr;
     }
     int ksplit = 1;
-    if (epi == EPI_PLAIN && b.count == 1 && b.g[0].ksplit != 0 && b.g[0].ksplit != 1) {
-        const GemmArgs& g = b.g[0];
+    bool splittable = epi == EPI_PLAIN;         // every job of the batch must ask for it and share the shape
+    for (int j = 0; j < b.count; ++j)
+        if (b.g[j].ksplit == 0 || b.g[j].ksplit == 1 || b.g[j].ksplit != b.g[0].ksplit || b.g[j].Ktot != b.g[0].Ktot ||
+            b.g[j].M != b.g[0].M || b.g[j].N != b.g[0].N) splittable = false;
+    if (splittable) {
         int ktiles = 0;
-        for (int i = 0; i < g.nseg; ++i) ktiles += g.a[i].width / BK;
-        ksplit = g.ksplit;
+        for (int i = 0; i < b.g[0].nseg; ++i) ktiles += b.g[0].a[i].width / BK;
+        ksplit = b.g[0].ksplit;
         if (ksplit < 0) {                       // fill ~2 blocks per CU, keep >= 16 k-tiles per block
-            ksplit = (512 + blocks - 1) / blocks;
+            ksplit = (512 + blocks * b.count - 1) / (blocks * b.count);
             if (ksplit > ktiles / 16) ksplit = ktiles / 16;
         }
         if (ksplit > ktiles) ksplit = ktiles;
         if (ksplit < 1) ksplit = 1;
-        if (ksplit > 1 && !g.accumulate) {      // partial sums are added atomically: start from zero
+        for (int j = 0; j < b.count && ksplit > 1; ++j) {
+            const GemmArgs& g = b.g[j];
+            if (g.accumulate || g.out_zeroed) continue;   // partial sums are added atomically: start from zero
             float* cbase = g.out.base + (long long)(g.step_imm * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
             if (g.out.ld == g.N) (void)hipMemsetAsync(cbase, 0, (size_t)g.M * g.N * sizeof(float), stream);
             else (void)hipMemset2DAsync(cbase, (size_t)g.out.ld * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream);

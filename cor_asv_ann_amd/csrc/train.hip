@@ -37,7 +37,7 @@ struct TrainState {
     DevBuf ETp, WaN, UaN;                  // derived: E^T padded [W][Vp], W_a [W][W], U_a [C][W]
     int B = 0, T = 0, U = 0, A = 0;
     DevBuf e_idx, e_val, d_in, d_out, d_w, m_enc, m_dec, m_cell;
-    DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, CTX, RecIn, prev, logits, dG, d_enc, du, DWQ, dhatt, dfin, dcbuf, HP, dX0, dXtop, dXl;
+    DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, CTX, RecIn, prev, logits, dG, d_enc, du, DWQ, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
     std::vector<DevBuf> O, DO;             // masked layer outputs (encoder O[n], decoder DO[n])
     DevBuf T1, T2, T3;                     // transposition scratch
     DevBuf loss, normsq;
@@ -108,7 +108,7 @@ int casv_train_release(casv_model* m) {
     for (auto& l : ts->layers) { l.wxT.release(); l.wrT.release(); l.Hown.release(); l.Cs.release(); l.Gt.release(); l.Z.release(); l.dRec.release(); }
     DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
         &ts->m_cell, &ts->X0, &ts->H1, &ts->u, &ts->Y0, &ts->Ym, &ts->WQ, &ts->Ast, &ts->WIN, &ts->CTX, &ts->RecIn, &ts->prev,
-        &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl,
+        &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl, &ts->dYl, &ts->dOin, &ts->dcbuf2, &ts->dvaP, &ts->dbvP,
         &ts->T1, &ts->T2, &ts->T3, &ts->loss, &ts->normsq};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : ts->O) b.release();
@@ -246,39 +246,49 @@ static int layer_weight_grads(casv_model* m, TLayer& l, const float* x, long lon
     return 0;
 }
 
-// Backward of a plain LSTM layer.  dOut (+mask) = gradient w.r.t. its output sequence; dh_fin/dc_fin w.r.t. its
+// Backward of plain LSTM layers.  dOut (+mask) = gradient w.r.t. the layer's output sequence; dh_fin/dc_fin w.r.t. its
 // final state; h0/c0 its initial state (nullptr = zero).  Leaves dL/dh0 in dRec slot(first step) and dL/dc0 in dc.
-static int layer_backward(casv_model* m, TLayer& l, const float* dOut, long long ld_out, const float* mask,
-                          const float* dh_fin, const float* dc_fin, const float* h0, const float* c0, float* dc,
-                          const float* x, long long ldx, float* dX, long long ld_dx, int dx_accumulate) {
+struct LayerBwd {
+    TLayer* l;
+    const float* dOut; long long ld_out; const float* mask;
+    const float* dh_fin; const float* dc_fin; const float* h0; const float* c0; float* dc;
+    const float* x; long long ldx; float* dX; long long ld_dx; int dx_accumulate;
+};
+
+// pointwise part of processing index k (gate derivatives -> dZ) and the data GEMM that carries dZ to the previous step
+static GemmArgs layer_backward_step(casv_model* m, const LayerBwd& a, int k) {
     TrainState* ts = m->train;
+    TLayer& l = *a.l;
     const int W = m->W, B = ts->B;
-    if (dc_fin) HIPCHK(hipMemcpyAsync(dc, dc_fin, (size_t)B * W * 4, hipMemcpyDeviceToDevice, m->stream));
-    else HIPCHK(hipMemsetAsync(dc, 0, (size_t)B * W * 4, m->stream));
-    for (int k = l.len - 1; k >= 0; --k) {
-        const int t = time_of(l, k);
-        LstmBwdArgs p{};
-        p.a = dOut ? dOut + (long long)t * B * ld_out : nullptr; p.lda = ld_out; p.mask_a = mask;
-        if (k < l.len - 1) { p.b = l.dRec.as<float>() + (long long)time_of(l, k + 1) * B * W; p.ldb = W; }
-        else if (dh_fin) { p.b = dh_fin; p.ldb = W; }
-        p.gates = l.Gt.as<float>() + (long long)t * B * 4 * W;
-        p.cell = l.Cs.as<float>() + (long long)t * B * W;
-        if (k > 0) { p.c_prev = l.Cs.as<float>() + (long long)time_of(l, k - 1) * B * W; p.ld_cprev = W; }
-        else { p.c_prev = c0; p.ld_cprev = W; }
-        p.dc = dc; p.dz = l.Z.as<float>() + (long long)t * B * 4 * W; p.rows = B; p.W = W;
-        launch_lstm_bwd(p, m->stream);
-        GemmArgs g = plain_gemm(p.dz, 4 * W, B, 4 * W, l.wrT.as<float>(), l.kr, nullptr, l.dRec.as<float>() + (long long)t * B * W, W);
-        run_gemm(m, EPI_PLAIN, g);
-    }
+    const int t = time_of(l, k);
+    LstmBwdArgs p{};
+    p.a = a.dOut ? a.dOut + (long long)t * B * a.ld_out : nullptr; p.lda = a.ld_out; p.mask_a = a.mask;
+    if (k < l.len - 1) { p.b = l.dRec.as<float>() + (long long)time_of(l, k + 1) * B * W; p.ldb = W; }
+    else if (a.dh_fin) { p.b = a.dh_fin; p.ldb = W; }
+    p.gates = l.Gt.as<float>() + (long long)t * B * 4 * W;
+    p.cell = l.Cs.as<float>() + (long long)t * B * W;
+    if (k > 0) { p.c_prev = l.Cs.as<float>() + (long long)time_of(l, k - 1) * B * W; p.ld_cprev = W; }
+    else { p.c_prev = a.c0; p.ld_cprev = W; }
+    p.dc = a.dc; p.dz = l.Z.as<float>() + (long long)t * B * 4 * W; p.rows = B; p.W = W;
+    launch_lstm_bwd(p, m->stream);
+    GemmArgs g = plain_gemm(p.dz, 4 * W, B, 4 * W, l.wrT.as<float>(), l.kr, nullptr, l.dRec.as<float>() + (long long)t * B * W, W);
+    g.out_zeroed = 1;           // casv_train_step clears dRec once per step
+    return g;
+}
+
+static int layer_backward_finish(casv_model* m, const LayerBwd& a) {
+    TrainState* ts = m->train;
+    TLayer& l = *a.l;
+    const int W = m->W, B = ts->B;
     const long long rows = (long long)l.len * B;
-    if (dX) {
-        GemmArgs g = plain_gemm(l.Z.as<float>(), 4 * W, (int)rows, 4 * W, l.wxT.as<float>(), l.kx, nullptr, dX, ld_dx, dx_accumulate);
+    if (a.dX) {
+        GemmArgs g = plain_gemm(l.Z.as<float>(), 4 * W, (int)rows, 4 * W, l.wxT.as<float>(), l.kx, nullptr, a.dX, a.ld_dx, a.dx_accumulate);
         run_gemm(m, EPI_PLAIN, g);
     }
     // recurrent-side inputs of every step: HP[t] = h of the previously processed step (h0 / zero at the first)
     float* HP = ts->HP.as<float>();
     const int t0 = time_of(l, 0);
-    if (h0) HIPCHK(hipMemcpyAsync(HP + (long long)t0 * B * W, h0, (size_t)B * W * 4, hipMemcpyDeviceToDevice, m->stream));
+    if (a.h0) HIPCHK(hipMemcpyAsync(HP + (long long)t0 * B * W, a.h0, (size_t)B * W * 4, hipMemcpyDeviceToDevice, m->stream));
     else HIPCHK(hipMemsetAsync(HP + (long long)t0 * B * W, 0, (size_t)B * W * 4, m->stream));
     if (l.len > 1) {
         // forward layer: HP[1..] = H[0..len-2]; reversed layer: HP[0..len-2] = H[1..]
@@ -287,7 +297,31 @@ static int layer_backward(casv_model* m, TLayer& l, const float* dOut, long long
         HIPCHK(hipMemcpy2DAsync(dst, (size_t)W * 4, src, (size_t)l.hs_ld * 4, (size_t)W * 4, (size_t)(l.len - 1) * B,
                                 hipMemcpyDeviceToDevice, m->stream));
     }
-    return layer_weight_grads(m, l, x, ldx, HP, W);
+    return layer_weight_grads(m, l, a.x, a.ldx, HP, W);
+}
+
+// Up to two independent layers walk their sequences backwards in lockstep: one pointwise launch each and ONE data-GEMM
+// launch per step for both (the per-step launches are latency-bound, so pairing them is nearly free).
+static int layers_backward(casv_model* m, const LayerBwd* a, int count) {
+    TrainState* ts = m->train;
+    const int W = m->W, B = ts->B;
+    int maxlen = 0;
+    for (int j = 0; j < count; ++j) {
+        if (a[j].dc_fin) HIPCHK(hipMemcpyAsync(a[j].dc, a[j].dc_fin, (size_t)B * W * 4, hipMemcpyDeviceToDevice, m->stream));
+        else HIPCHK(hipMemsetAsync(a[j].dc, 0, (size_t)B * W * 4, m->stream));
+        maxlen = std::max(maxlen, a[j].l->len);
+    }
+    for (int i = 0; i < maxlen; ++i) {
+        GemmBatch b{};
+        for (int j = 0; j < count; ++j) {
+            const int k = a[j].l->len - 1 - i;
+            if (k >= 0) b.g[b.count++] = layer_backward_step(m, a[j], k);
+        }
+        run_gemm_batch(m, EPI_PLAIN, b);
+    }
+    for (int j = 0; j < count; ++j)
+        if (int rc = layer_backward_finish(m, a[j])) return rc;
+    return 0;
 }
 
 extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T, int32_t U, int32_t A,
@@ -315,9 +349,10 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     ENS(ts->X0, TB * W * 4) ENS(ts->H1, TB * 2 * W * 4) ENS(ts->u, TB * W * 4) ENS(ts->Y0, UB * W * 4) ENS(ts->Ym, UB * W * 4)
     ENS(ts->WQ, UB * W * 4) ENS(ts->Ast, (size_t)(U + 1) * B * T * 4) ENS(ts->WIN, UB * 4) ENS(ts->CTX, (size_t)B * C * 4)
     ENS(ts->RecIn, UB * (C + W) * 4) ENS(ts->prev, (size_t)B * 4) ENS(ts->logits, UB * Vp * 4)
-    ENS(ts->dG, UB * W * 4) ENS(ts->d_enc, TB * C * 4) ENS(ts->du, TB * W * 4) ENS(ts->DWQ, UB * W * 4) ENS(ts->dhatt, (size_t)B * W * 4)
+    ENS(ts->dG, UB * W * 4) ENS(ts->d_enc, TB * C * 4) ENS(ts->du, TB * W * 4) ENS(ts->DWQ, UB * W * 4) ENS(ts->dhatt, UB * W * 4)
     ENS(ts->dfin, (size_t)2 * D * B * W * 4) ENS(ts->dcbuf, (size_t)B * W * 4) ENS(ts->HP, LB * W * 4)
-    ENS(ts->dX0, TB * W * 4) ENS(ts->dXtop, std::max(UB * W, TB * 2 * W) * 4) ENS(ts->dXl, LB * 2 * W * 4)
+    ENS(ts->dX0, TB * W * 4) ENS(ts->dXtop, UB * W * 4) ENS(ts->dXl, TB * 2 * W * 4) ENS(ts->dYl, UB * W * 4) ENS(ts->dOin, TB * 2 * W * 4)
+    ENS(ts->dcbuf2, (size_t)B * W * 4) ENS(ts->dvaP, (size_t)B * W * 4) ENS(ts->dbvP, (size_t)B * 4)
     const long long ldTmax = (LB + 15) & ~15LL;
     ENS(ts->T1, (size_t)4 * W * ldTmax * 4) ENS(ts->T2, (size_t)std::max(2 * W, Vp) * ldTmax * 4) ENS(ts->T3, (size_t)(C + W) * ldTmax * 4)
     for (auto& l : ts->layers) {
@@ -375,37 +410,42 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     HIPCHK(hipMemcpy2DAsync(hfin, (size_t)W * 4, Lbw->hs, (size_t)2 * W * 4, (size_t)W * 4, B, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(cfin, Lbw->Cs.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
     launch_mul_mask(ts->H1.as<float>(), 2 * W, menc_n(1), ts->O[1].as<float>(), 2 * W, TB, 2 * W, st);
+    launch_embed_tm(ts->W_(ts->iE), ts->d_in.as<int>(), nullptr, ts->Y0.as<float>(), B, U, 1, V, W, st);
+    // Encoder layer n and decoder layer n-1 depend only on encoder layer n-1 / decoder layer n-2, so the two
+    // recurrences advance in lockstep, one launch per step for both.
+    const float* y = ts->Y0.as<float>();
     for (int n = 2; n <= D; ++n) {
-        TLayer& l = enc_layer(n);
-        layer_input_gemm(m, l, ts->O[n - 1].as<float>(), l.kx);
-        for (int k = 0; k < T; ++k) { GemmArgs g = layer_step_job(m, l, k, nullptr, nullptr, nullptr); run_gemm(m, EPI_LSTM, g); }
-        HIPCHK(hipMemcpyAsync(hfin + (size_t)(n - 1) * B * W, l.hs + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(cfin + (size_t)(n - 1) * B * W, l.Cs.as<float>() + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
-        launch_mul_mask(l.hs, W, menc_n(n), ts->O[n].as<float>(), W, TB, W, st);
+        TLayer& le = enc_layer(n);
+        TLayer& ld = dec_layer(n - 1);
+        layer_input_gemm(m, le, ts->O[n - 1].as<float>(), le.kx);
+        layer_input_gemm(m, ld, y, W);
+        const float* h0 = hfin + (size_t)(n - 2) * B * W; const float* c0 = cfin + (size_t)(n - 2) * B * W;
+        for (int k = 0; k < L; ++k) {
+            GemmBatch b{};
+            if (k < T) b.g[b.count++] = layer_step_job(m, le, k, nullptr, nullptr, nullptr);
+            if (k < U) b.g[b.count++] = layer_step_job(m, ld, k, h0, c0, nullptr);
+            run_gemm_batch(m, EPI_LSTM, b);
+        }
+        HIPCHK(hipMemcpyAsync(hfin + (size_t)(n - 1) * B * W, le.hs + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(cfin + (size_t)(n - 1) * B * W, le.Cs.as<float>() + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+        launch_mul_mask(le.hs, W, menc_n(n), ts->O[n].as<float>(), W, TB, W, st);
+        launch_mul_mask(ld.hs, W, mdec_n(n - 1), ts->DO[n - 1].as<float>(), W, UB, W, st);
+        y = ts->DO[n - 1].as<float>();
     }
     const float* enc_out = ts->O[D].as<float>();
     { GemmArgs g = plain_gemm(enc_out, C, (int)TB, C, ts->W_(ts->iUT), W, nullptr, ts->u.as<float>(), W); run_gemm(m, EPI_PLAIN, g); }
 
-    // ================= forward: decoder =================
-    launch_embed_tm(ts->W_(ts->iE), ts->d_in.as<int>(), nullptr, ts->Y0.as<float>(), B, U, 1, V, W, st);
-    const float* y = ts->Y0.as<float>();
-    for (int n = 1; n < D; ++n) {
-        TLayer& l = dec_layer(n);
-        layer_input_gemm(m, l, y, W);
-        const float* h0 = hfin + (size_t)(n - 1) * B * W; const float* c0 = cfin + (size_t)(n - 1) * B * W;
-        for (int k = 0; k < U; ++k) { GemmArgs g = layer_step_job(m, l, k, h0, c0, nullptr); run_gemm(m, EPI_LSTM, g); }
-        launch_mul_mask(l.hs, W, mdec_n(n), ts->DO[n].as<float>(), W, UB, W, st);
-        y = ts->DO[n].as<float>();
-    }
+    // ================= forward: attention cell =================
     TLayer& top = dec_layer(D);
     launch_mul_rowmask(y, W, mcell, W + C, ts->Ym.as<float>(), W, UB, B, W, st);
     layer_input_gemm(m, top, ts->Ym.as<float>(), W);
     const float* h0t = hfin + (size_t)(D - 1) * B * W; const float* c0t = cfin + (size_t)(D - 1) * B * W;
     HIPCHK(hipMemsetAsync(ts->Ast.p, 0, (size_t)B * T * 4, st));
+    HIPCHK(hipMemsetAsync(ts->WQ.p, 0, UB * W * 4, st));        // split-K partial sums land here
     for (int t = 0; t < U; ++t) {
         const float* hprev = t == 0 ? h0t : top.hs + (long long)(t - 1) * B * W;
         float* wq = ts->WQ.as<float>() + (long long)t * B * W;
-        { GemmArgs g = plain_gemm(hprev, W, B, W, ts->W_(ts->iWaT), W, ts->W_(ts->ibUW), wq, W); run_gemm(m, EPI_PLAIN, g); }
+        { GemmArgs g = plain_gemm(hprev, W, B, W, ts->W_(ts->iWaT), W, ts->W_(ts->ibUW), wq, W); g.out_zeroed = 1; run_gemm(m, EPI_PLAIN, g); }
         launch_fill_prev(ts->prev.as<int>(), B, t, nullptr, st);
         AttnArgs a{};
         a.wq = wq; a.u = ts->u.as<float>(); a.enc = enc_out; a.va = ts->W_(ts->iva); a.bv = ts->W_(ts->ibv);
@@ -448,6 +488,10 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     }
     HIPCHK(hipMemsetAsync(ts->d_enc.p, 0, TB * C * 4, st));
     HIPCHK(hipMemsetAsync(ts->du.p, 0, TB * W * 4, st));
+    HIPCHK(hipMemsetAsync(ts->dvaP.p, 0, (size_t)B * W * 4, st));
+    HIPCHK(hipMemsetAsync(ts->dhatt.p, 0, UB * W * 4, st));     // split-K outputs of the per-step GEMMs
+    for (auto& l : ts->layers) HIPCHK(hipMemsetAsync(l.dRec.p, 0, (size_t)l.len * B * l.kr * 4, st));
+    HIPCHK(hipMemsetAsync(ts->dbvP.p, 0, (size_t)B * 4, st));
     float* dfin = ts->dfin.as<float>();          // [n-1][0|1][B][W]
     auto dfin_h = [&](int n) { return dfin + (size_t)(2 * (n - 1)) * B * W; };
     auto dfin_c = [&](int n) { return dfin + (size_t)(2 * (n - 1) + 1) * B * W; };
@@ -461,7 +505,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             p.a = ts->dG.as<float>() + (long long)t * B * W; p.lda = W;
             if (t < U - 1) {
                 p.b = top.dRec.as<float>() + (long long)(t + 1) * B * kr + C; p.ldb = kr;
-                p.c = ts->dhatt.as<float>(); p.ldc = W;
+                p.c = ts->dhatt.as<float>() + (long long)(t + 1) * B * W; p.ldc = W;
             }
             p.gates = top.Gt.as<float>() + (long long)t * B * 4 * W;
             p.cell = top.Cs.as<float>() + (long long)t * B * W;
@@ -469,7 +513,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             p.dc = dc; p.dz = top.Z.as<float>() + (long long)t * B * 4 * W; p.rows = B; p.W = W;
             launch_lstm_bwd(p, st);
             float* drec = top.dRec.as<float>() + (long long)t * B * kr;
-            { GemmArgs g = plain_gemm(p.dz, 4 * W, B, 4 * W, top.wrT.as<float>(), kr, nullptr, drec, kr); run_gemm(m, EPI_PLAIN, g); }
+            { GemmArgs g = plain_gemm(p.dz, 4 * W, B, 4 * W, top.wrT.as<float>(), kr, nullptr, drec, kr); g.out_zeroed = 1; run_gemm(m, EPI_PLAIN, g); }
             AttnBwdArgs ab{};
             ab.dxh = drec; ab.ld_dxh = kr; ab.ctx_off = 0; ab.mcell = mcell; ab.ld_mcell = W + C; ab.mc_off = W;
             ab.a = ts->Ast.as<float>() + (long long)(t + 1) * B * T; ab.win = ts->WIN.as<int>() + (long long)t * B;
@@ -477,14 +521,17 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             ab.u = ts->u.as<float>(); ab.u_line = W; ab.u_time = (long long)B * W;
             ab.enc = enc_out; ab.enc_line = C; ab.enc_time = (long long)B * C;
             ab.d_enc = ts->d_enc.as<float>(); ab.du = ts->du.as<float>(); ab.dwq = ts->DWQ.as<float>() + (long long)t * B * W;
-            ab.dva = ts->G_(ts->iva); ab.dbv = ts->G_(ts->ibv); ab.B = B; ab.T = T; ab.W = W; ab.C = C;
+            ab.dva_part = ts->dvaP.as<float>(); ab.dbv_part = ts->dbvP.as<float>(); ab.B = B; ab.T = T; ab.W = W; ab.C = C;
             launch_attention_bwd(ab, st);
-            GemmArgs g = plain_gemm(ab.dwq, W, B, W, ts->WaN.as<float>(), W, nullptr, ts->dhatt.as<float>(), W);
+            GemmArgs g = plain_gemm(ab.dwq, W, B, W, ts->WaN.as<float>(), W, nullptr, ts->dhatt.as<float>() + (long long)t * B * W, W);
+            g.out_zeroed = 1;
             run_gemm(m, EPI_PLAIN, g);
         }
+        launch_colsum(ts->dvaP.as<float>(), B, W, W, ts->G_(ts->iva), st);
+        launch_colsum(ts->dbvP.as<float>(), B, 1, 1, ts->G_(ts->ibv), st);
         // dL/dh0 of the cell = recurrent part of step 0 + the query path of step 0
         launch_mul_mask(top.dRec.as<float>() + C, kr, nullptr, dfin_h(D), W, B, W, st);
-        launch_axpy(dfin_h(D), ts->dhatt.as<float>(), (long long)B * W, st);
+        launch_axpy(dfin_h(D), ts->dhatt.as<float>(), (long long)B * W, st);       // slot of step 0
         // y-part gradient for all steps, weight grads
         GemmArgs g = plain_gemm(top.Z.as<float>(), 4 * W, (int)UB, 4 * W, top.wxT.as<float>(), W, nullptr, ts->dXtop.as<float>(), W);
         run_gemm(m, EPI_PLAIN, g);
@@ -512,37 +559,38 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             run_gemm(m, EPI_PLAIN, gd);
         }
     }
-    // ---- lower decoder layers ----
+    // ---- decoder layer n with encoder layer n+1 (the mirror of the forward pairing) ----
     const float* dy = ts->dXtop.as<float>();        // gradient w.r.t. DO[D-1] (or Y0 when D == 1)
+    const float* dO = ts->d_enc.as<float>();        // gradient w.r.t. O[D]
+    long long ld_dO = C;
     for (int n = D - 1; n >= 1; --n) {
-        TLayer& l = dec_layer(n);
+        TLayer& ld = dec_layer(n);
+        TLayer& le = enc_layer(n + 1);
         const float* xin = n == 1 ? ts->Y0.as<float>() : ts->DO[n - 1].as<float>();
-        if (int rc = layer_backward(m, l, dy, W, mdec_n(n), nullptr, nullptr, hfin + (size_t)(n - 1) * B * W, cfin + (size_t)(n - 1) * B * W,
-                                    dfin_c(n), xin, W, ts->dXl.as<float>(), W, 0)) return rc;
-        // dL/dh0, dL/dc0 of this layer go to the encoder layer of the same index
-        HIPCHK(hipMemcpyAsync(dfin_h(n), l.dRec.as<float>(), (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(ts->dXtop.p, ts->dXl.p, UB * W * 4, hipMemcpyDeviceToDevice, st));
+        LayerBwd pair[2] = {
+            {&ld, dy, W, mdec_n(n), nullptr, nullptr, hfin + (size_t)(n - 1) * B * W, cfin + (size_t)(n - 1) * B * W, dfin_c(n),
+             xin, W, ts->dYl.as<float>(), W, 0},
+            {&le, dO, ld_dO, menc_n(n + 1), dfin_h(n + 1), dfin_c(n + 1), nullptr, nullptr, ts->dcbuf.as<float>(),
+             ts->O[n].as<float>(), le.kx, ts->dXl.as<float>(), le.kx, 0}};
+        if (int rc = layers_backward(m, pair, 2)) return rc;
+        // dL/dh0, dL/dc0 of the decoder layer go to the encoder layer of the same index
+        HIPCHK(hipMemcpyAsync(dfin_h(n), ld.dRec.as<float>(), (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(ts->dXtop.p, ts->dYl.p, UB * W * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(ts->dOin.p, ts->dXl.p, TB * le.kx * 4, hipMemcpyDeviceToDevice, st));
         dy = ts->dXtop.as<float>();
+        dO = ts->dOin.as<float>(); ld_dO = le.kx;
     }
     launch_embed_scatter(ts->G_(ts->iE), ts->d_in.as<int>(), nullptr, dy, W, B, U, 1, V, W, st);
 
-    // ---- encoder ----
-    const float* dO = ts->d_enc.as<float>();        // gradient w.r.t. O[D]
-    long long ld_dO = C;
-    for (int n = D; n >= 2; --n) {
-        TLayer& l = enc_layer(n);
-        if (int rc = layer_backward(m, l, dO, ld_dO, menc_n(n), dfin_h(n), dfin_c(n), nullptr, nullptr, ts->dcbuf.as<float>(),
-                                    ts->O[n - 1].as<float>(), l.kx, ts->dXl.as<float>(), l.kx, 0)) return rc;
-        // next layer's dO lives in dXl; keep it in du/d_enc-sized scratch: copy to d_enc-independent buffer
-        const size_t bytes = TB * l.kx * 4;
-        HIPCHK(hipMemcpyAsync(ts->dXtop.p, ts->dXl.p, bytes, hipMemcpyDeviceToDevice, st));
-        dO = ts->dXtop.as<float>(); ld_dO = l.kx;
+    // ---- encoder layer 1: forward direction takes columns [0,W) of dO1, backward direction [W,2W) ----
+    {
+        LayerBwd pair[2] = {
+            {Lfw, dO, ld_dO, menc_n(1), nullptr, nullptr, nullptr, nullptr, ts->dcbuf.as<float>(),
+             ts->X0.as<float>(), W, ts->dX0.as<float>(), W, 0},
+            {Lbw, dO + W, ld_dO, menc_n(1) ? menc_n(1) + W : nullptr, dfin_h(1), dfin_c(1), nullptr, nullptr, ts->dcbuf2.as<float>(),
+             ts->X0.as<float>(), W, ts->dX0.as<float>(), W, 1}};
+        if (int rc = layers_backward(m, pair, 2)) return rc;
     }
-    // layer 1: forward direction takes columns [0,W) of dO1, backward direction [W,2W)
-    if (int rc = layer_backward(m, *Lfw, dO, ld_dO, menc_n(1), nullptr, nullptr, nullptr, nullptr, ts->dcbuf.as<float>(),
-                                ts->X0.as<float>(), W, ts->dX0.as<float>(), W, 0)) return rc;
-    if (int rc = layer_backward(m, *Lbw, dO + W, ld_dO, menc_n(1) ? menc_n(1) + W : nullptr, dfin_h(1), dfin_c(1), nullptr, nullptr,
-                                ts->dcbuf.as<float>(), ts->X0.as<float>(), W, ts->dX0.as<float>(), W, 1)) return rc;
     launch_embed_scatter(ts->G_(ts->iE), ts->e_idx.as<int>(), enc_val ? ts->e_val.as<float>() : nullptr, ts->dX0.as<float>(), W, B, T, A, V, W, st);
 
     // ---- regulariser, clip, update ----

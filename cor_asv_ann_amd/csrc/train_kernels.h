@@ -36,7 +36,8 @@ struct AttnBwdArgs {
     const float* wq; const float* va;
     const float* u; long long u_line, u_time;
     const float* enc; long long enc_line, enc_time;
-    float* d_enc; float* du; float* dwq; float* dva; float* dbv;
+    float* d_enc; float* du; float* dwq;
+    float* dva_part; float* dbv_part;                        // [B][W], [B]: per-sample sums over the steps
     int B, T, W, C;
 };
 void launch_attention_bwd(const AttnBwdArgs& p, hipStream_t st);

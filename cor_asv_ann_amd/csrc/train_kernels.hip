@@ -193,76 +193,71 @@ void launch_lstm_bwd(const LstmBwdArgs& p, hipStream_t st) {
 
 // ---- attention backward for one decoder time step (oracle/train.py; no gradient through the window
 // mask nor through the previous alignment, attention.py:567) ----
-constexpr int AB_ROWS = 4;
-__global__ __launch_bounds__(64 * AB_ROWS) void attention_bwd_kernel(const AttnBwdArgs p) {
-    __shared__ float s_dva[AB_ROWS][1024];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * AB_ROWS + wave;
+// One workgroup per sample.  Everything that is read is independent of what is written, so the loads batch; the
+// read-modify-writes of d_enc / du go out as fire-and-forget float atomics (distinct addresses: no contention).
+// dva / dbv are kept as per-sample partial sums across the steps and reduced once after the loop.
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdArgs p) {
+    __shared__ float s_dx[2048];
+    __shared__ float s_da[16], s_ds[16], s_av[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
     const int W = p.W, C = p.C, T = p.T;
-    const bool active = b < p.B;
-    const int bb = active ? b : p.B - 1;
-    const int s_lo = p.win[bb] & 0xffff, cnt = active ? (p.win[bb] >> 16) : 0;
-    const float* arow = p.a + (long long)bb * T;
-    const float* dx = p.dxh + (long long)bb * p.ld_dxh + p.ctx_off;
-    const float* mc = p.mcell ? p.mcell + (long long)bb * p.ld_mcell + p.mc_off : nullptr;
-    // da_s = dctx . enc_s ; dot = sum a_s da_s
-    float da[11], av[11];
-    float dot = 0.f;
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-        da[i] = 0.f; av[i] = 0.f;
-        if (i < cnt) {
-            const float* es = p.enc + (long long)bb * p.enc_line + (long long)(s_lo + i) * p.enc_time;
-            float part = 0.f;
-            for (int c = lane; c < C; c += 64) part += dx[c] * (mc ? mc[c] : 1.0f) * es[c];
-            da[i] = wsum(part);
-            av[i] = arow[s_lo + i];
-            dot += av[i] * da[i];
-        }
-    }
-    float dbv = 0.f;
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-        if (i < cnt) { da[i] = av[i] * (da[i] - dot); dbv += da[i]; }     // da[] now holds dscore
-    }
-    // d enc_out[s] += a_s * dctx
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-        if (i < cnt) {
-            float* des = p.d_enc + (long long)bb * p.enc_line + (long long)(s_lo + i) * p.enc_time;
-            for (int c = lane; c < C; c += 64) des[c] += av[i] * dx[c] * (mc ? mc[c] : 1.0f);
-        }
-    }
-    // energies: th = tanh(wq + u_s); dva += dscore*th ; dpre = dscore*va*(1-th^2) -> du_s, dwq
-    const float* wq = p.wq + (long long)bb * W;
-    for (int j = lane; j < W; j += 64) {
-        float dwq = 0.f, dva = 0.f;
-        const float q = wq[j], v = p.va[j];
-#pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            if (i < cnt) {
-                const long long off = (long long)bb * p.u_line + (long long)(s_lo + i) * p.u_time + j;
-                const float th = tanhf(q + p.u[off]);
-                dva += da[i] * th;
-                const float dpre = da[i] * v * (1.0f - th * th);
-                p.du[off] += dpre;
-                dwq += dpre;
-            }
-        }
-        if (active) p.dwq[(long long)b * W + j] = dwq;
-        s_dva[wave][j] = dva;
+    const int wv = p.win[b];
+    const int s_lo = wv & 0xffff, cnt = wv >> 16;
+    const float* dx = p.dxh + (long long)b * p.ld_dxh + p.ctx_off;
+    const float* mc = p.mcell ? p.mcell + (long long)b * p.ld_mcell + p.mc_off : nullptr;
+    for (int c = tid; c < C; c += 256) s_dx[c] = dx[c] * (mc ? mc[c] : 1.0f);
+    if (tid < 16) s_av[tid] = tid < cnt ? p.a[(long long)b * T + s_lo + tid] : 0.0f;
+    __syncthreads();
+    // da_s = dctx . enc_s
+    for (int i = wave; i < cnt; i += 4) {
+        const float* es = p.enc + (long long)b * p.enc_line + (long long)(s_lo + i) * p.enc_time;
+        float part = 0.f;
+        for (int c = lane; c < C; c += 64) part += s_dx[c] * es[c];
+        part = wsum(part);
+        if (lane == 0) s_da[i] = part;
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < W; j += blockDim.x) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < AB_ROWS; ++w) s += s_dva[w][j];
-        atomicAdd(p.dva + j, s);
+    if (tid < 16) {
+        float dot = 0.f;
+        for (int i = 0; i < cnt; ++i) dot += s_av[i] * s_da[i];
+        s_ds[tid] = tid < cnt ? s_av[tid] * (s_da[tid] - dot) : 0.0f;          // dL/dscore
     }
-    if (lane == 0 && active) atomicAdd(p.dbv, dbv);
+    __syncthreads();
+    // d enc_out[s] += a_s * dctx
+    float* de = p.d_enc + (long long)b * p.enc_line + (long long)s_lo * p.enc_time;
+    for (int i = 0; i < cnt; ++i) {
+        const float av = s_av[i];
+        for (int c = tid; c < C; c += 256) atomicAdd(de + (long long)i * p.enc_time + c, av * s_dx[c]);
+    }
+    // energies: th = tanh(wq + u_s); dva += dscore*th ; dpre = dscore*va*(1-th^2) -> du_s, dwq
+    for (int j = tid; j < W; j += 256) {
+        const float q = p.wq[(long long)b * W + j], v = p.va[j];
+        const long long off0 = (long long)b * p.u_line + (long long)s_lo * p.u_time + j;
+        float uu[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) uu[i] = p.u[off0 + (long long)(i < cnt ? i : 0) * p.u_time];
+        float dwq = 0.f, dva = 0.f;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const float th = fast_tanh(q + uu[i]);
+            const float ds = s_ds[i];
+            dva += ds * th;
+            const float dpre = ds * v * (1.0f - th * th);
+            if (i < cnt) atomicAdd(p.du + off0 + (long long)i * p.u_time, dpre);
+            dwq += dpre;
+        }
+        p.dwq[(long long)b * W + j] = dwq;
+        p.dva_part[(long long)b * W + j] += dva;
+    }
+    if (tid == 0) {
+        float dbv = 0.f;
+        for (int i = 0; i < cnt; ++i) dbv += s_ds[i];
+        p.dbv_part[b] += dbv;
+    }
 }
 void launch_attention_bwd(const AttnBwdArgs& p, hipStream_t st) {
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3((p.B + AB_ROWS - 1) / AB_ROWS), dim3(64 * AB_ROWS), 0, st, p);
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(p.B), dim3(256), 0, st, p);
 }
 
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long long n) {
