@@ -12,11 +12,13 @@ import logging
 import math
 import pickle
 import unicodedata
+from collections import OrderedDict
 
 import numpy as np
 
 from . import GAP
 from . import _native as nv
+from . import hdf5, keras_h5
 from .engine import HipEngine, weight_shapes
 
 _UNSUPPORTED = ('residual_connections', 'deep_bidirectional_encoder', 'bridge_dense', 'lm_loss',
@@ -158,70 +160,129 @@ class Sequence2Sequence(object):
                 self.set_weights(new)
                 self.status = status
 
+    def _config_dict(self):
+        return OrderedDict([
+            ('width', np.array(self.width)), ('depth', np.array(self.depth)), ('stateful', np.array(bool(self.stateful))),
+            ('residual_connections', np.array(bool(self.residual_connections))),
+            ('deep_bidirectional_encoder', np.array(bool(self.deep_bidirectional_encoder))),
+            ('bridge_dense', np.array(bool(self.bridge_dense))),
+            ('mapping', np.fromiter((ord(self.mapping[1][i]) if i in self.mapping[1] and self.mapping[1][i] else 0
+                                     for i in range(self.voc_size)), dtype=np.uint32))])
+
     def save(self, filename):
-        """Store weights + configuration (seq2seq.py:1121-1141).  Container: numpy .npz with the
-        tensor names of SURVEY.md A.2 plus `config/*` entries (h5py is not available here; reading
-        the published Keras HDF5 files is the next item of SURVEY.md section 8f)."""
+        """Store weights + configuration (seq2seq.py:1121-1141) in the reference's container: the Keras
+        `save_weights` HDF5 layout plus the `config` group (keras_h5.py; written without h5py).
+        A filename ending in `.npz` selects a plain numpy archive of the same tensors instead."""
         assert self.status > 1
         self.logger.info('Saving model under "%s"', filename)
-        data = {k: v for k, v in self._weights.items()}
-        data['config/width'] = np.array(self.width)
-        data['config/depth'] = np.array(self.depth)
-        data['config/stateful'] = np.array(self.stateful)
-        data['config/residual_connections'] = np.array(self.residual_connections)
-        data['config/deep_bidirectional_encoder'] = np.array(self.deep_bidirectional_encoder)
-        data['config/bridge_dense'] = np.array(self.bridge_dense)
-        data['config/mapping'] = np.fromiter(
-            (ord(self.mapping[1][i]) if i in self.mapping[1] and self.mapping[1][i] else 0
-             for i in range(self.voc_size)), dtype=np.uint32)
-        with open(filename, 'wb') as f:
-            np.savez(f, **data)
+        if str(filename).endswith('.npz'):
+            data = {k: v for k, v in self._weights.items()}
+            for key, value in self._config_dict().items():
+                data['config/' + key] = value
+            with open(filename, 'wb') as f:
+                np.savez(f, **data)
+        else:
+            keras_h5.write_model(filename, self._config_dict(), self._weights)
 
-    def load_config(self, filename):
-        """seq2seq.py:1143-1162."""
+    def _read_container(self, filename):
+        """(config dict, {keras layer name: {tensor name: array}}) from a Keras HDF5 or an .npz model file."""
+        if hdf5.is_hdf5(filename):
+            return keras_h5.read_model(filename, self.logger)
         with np.load(filename) as data:
-            self.width = int(data['config/width'])
-            self.depth = int(data['config/depth'])
-            self.stateful = bool(data['config/stateful'])
-            self.residual_connections = bool(data['config/residual_connections']) \
-                if 'config/residual_connections' in data else False
-            self.deep_bidirectional_encoder = bool(data['config/deep_bidirectional_encoder']) \
-                if 'config/deep_bidirectional_encoder' in data else False
-            self.bridge_dense = bool(data['config/bridge_dense']) if 'config/bridge_dense' in data else False
-            codes = data['config/mapping']
+            src = {k: data[k] for k in data.files}
+        config = {k[len('config/'):]: v for k, v in src.items() if k.startswith('config/')}
+        depth = int(config['depth']) if 'depth' in config else self.depth
+        layers = OrderedDict()
+        for lname, tensors in keras_h5.layer_tensors(depth).items():
+            if all(t in src for t in tensors):
+                layers[lname] = OrderedDict((t, src[t]) for t in tensors)
+        return config, layers
+
+    def _set_mapping_from_codes(self, codes):
         c_i = dict((chr(c), i) if c > 0 else ('', 0) for i, c in enumerate(codes))
         i_c = dict((i, chr(c)) if c > 0 else (0, '') for i, c in enumerate(codes))
         self.mapping = (c_i, i_c)
         self.voc_size = len(c_i)
 
+    def load_config(self, filename):
+        """seq2seq.py:1143-1162."""
+        if hdf5.is_hdf5(filename):
+            config = keras_h5.read_config(filename)
+        else:
+            config, _ = self._read_container(filename)
+        if 'width' not in config or 'mapping' not in config:
+            raise KeyError('model file "%s" has no config group' % filename)
+        self.width = int(config['width'])
+        self.depth = int(config['depth'])
+        self.stateful = bool(config['stateful'])
+        self.residual_connections = bool(config.get('residual_connections', False))           # old default
+        self.deep_bidirectional_encoder = bool(config.get('deep_bidirectional_encoder', False))
+        self.bridge_dense = bool(config.get('bridge_dense', False))
+        self._set_mapping_from_codes(config['mapping'])
+
+    def _assign_layers(self, layers, table, skip_mismatch):
+        """Keras' by-name weight loading: a layer of the file goes into the layer of the same name if the number
+        and the shapes of its weights agree (ValueError, or a warning with skip_mismatch); layers the file does
+        not have keep their values."""
+        shapes = weight_shapes(self.depth, self.width, self.voc_size)
+        w = self.get_weights()
+        taken = []
+        for lname, tensors in table.items():
+            if lname not in layers:
+                continue
+            src = list(layers[lname].values())
+            problem = None
+            if len(src) != len(tensors):
+                problem = 'layer "%s" expects %d weight(s), but the saved weights have %d element(s)' % (
+                    lname, len(tensors), len(src))
+            else:
+                for name, arr in zip(tensors, src):
+                    if int(np.prod(arr.shape)) != int(np.prod(shapes[name])) or (
+                            arr.ndim == len(shapes[name]) and tuple(arr.shape) != tuple(shapes[name])):
+                        problem = 'layer "%s": weight %s has shape %s, but the saved weight has shape %s' % (
+                            lname, name, shapes[name], arr.shape)
+                        break
+            if problem:
+                if not skip_mismatch:
+                    raise ValueError(problem)
+                self.logger.warning('skipping loading of weights for %s', problem)
+                continue
+            for name, arr in zip(tensors, src):
+                w[name] = np.asarray(arr, np.float32).reshape(shapes[name])
+            taken.append(lname)
+        self.set_weights(w)
+        return taken
+
     def load_weights(self, filename):
-        """seq2seq.py:1164-1174."""
+        """seq2seq.py:1164-1174 (`load_weights(filename, by_name=True)` + decoder resync)."""
         assert self.status > 0
         self.logger.info('Loading model from "%s"', filename)
-        with np.load(filename) as data:
-            self.set_weights({k: data[k] for k in weight_shapes(self.depth, self.width, self.voc_size)})
+        _, layers = self._read_container(filename)
+        table = keras_h5.layer_tensors(self.depth)
+        taken = self._assign_layers(layers, table, skip_mismatch=False)
+        for lname in table:
+            if lname not in taken:
+                self.logger.warning('model file has no weights for layer "%s"', lname)
         self.status = 2
 
     def load_transfer_weights(self, filename):
-        """Initialise matching tensors from another (possibly shallower) model (seq2seq.py:1176-1213)."""
+        """Initialise matching layers from another (possibly shallower) model (seq2seq.py:1176-1213)."""
         assert self.status > 0
         assert self.depth > 1
-        with np.load(filename) as data:
-            src = {k: data[k] for k in data.files}
-        if 'config/mapping' in src:
-            codes = src['config/mapping']
-            self.mapping = (dict((chr(c), i) if c > 0 else ('', 0) for i, c in enumerate(codes)),
-                            dict((i, chr(c)) if c > 0 else (0, '') for i, c in enumerate(codes)))
-            self.voc_size = len(self.mapping[0])
+        config, layers = self._read_container(filename)
+        was_shallow = False
+        if 'mapping' in config:
+            self._set_mapping_from_codes(config['mapping'])
             self._reconfigure_for_mapping()
+            was_shallow = 'depth' in config and int(config['depth']) == self.depth - 1
         self.logger.info('Transferring model from "%s"', filename)
-        w = self.get_weights()
-        for name, arr in w.items():
-            if name in src and src[name].shape == arr.shape:
-                w[name] = src[name]
-        self.set_weights(w)
+        table = keras_h5.layer_tensors(self.depth)
+        # the reference hands keras the attention CELL in place of the top decoder layer (seq2seq.py:1200-1204);
+        # its name matches no layer of the file, so that layer is never transferred
+        del table['decoder_lstm_%d' % self.depth]
+        self._assign_layers(layers, table, skip_mismatch=True)
         self.frozen_prefixes = []
-        if 'config/depth' in src and int(src['config/depth']) == self.depth - 1:
+        if was_shallow:
             # layers taken over from a model one layer shallower stay fixed (seq2seq.py:1206-1211)
             self.logger.info('fixing weights from shallower model')
             self.frozen_prefixes = ['enc%d_' % i for i in range(1, self.depth)] + \

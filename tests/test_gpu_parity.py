@@ -283,3 +283,34 @@ def test_c3_full_size_properties():
     for k in ('idx', 'len', 'score', 'n_found', 'n_steps'):
         assert np.array_equal(a[k][512:576], c[k]), k
     eng.close()
+
+
+def test_model_loaded_from_the_reference_container(golden_dir, tmp_path):
+    """A Keras-2.3 HDF5 model file (written by libhdf5, tests/golden/make_keras_h5.py) loads through
+    load_config / configure / load_weights (scripts/proc.py:52-55) and decodes like the oracle with the same
+    tensors; saved again in the reference's container, it reloads to the same results."""
+    from cor_asv_ann_amd.seq2seq import Sequence2Sequence
+    path = os.path.join(golden_dir, 'keras_d2_w32_v12.h5')
+    s2s = Sequence2Sequence()
+    s2s.load_config(path)
+    s2s.configure()
+    s2s.load_weights(path)
+    s2s.batch_size = 4
+    cfg = ModelConfig(depth=2, width=32, voc_size=12)
+    om = OracleModel(cfg, make_weights(cfg), batch_size=4)
+    assert s2s.mapping == om.mapping
+    lines, _ = make_lines(5, 9, 77, voc_size=12)
+    want = correct_lines(om, lines, None, fast=True, greedy=True)
+    got = s2s.correct_lines(lines, None, fast=True, greedy=True)
+    assert got[0] == want[0]
+    for j in range(len(lines)):
+        assert np.allclose(got[1][j], want[1][j], rtol=RT, atol=AT)
+    again = str(tmp_path / 'resaved.h5')
+    s2s.save(again)
+    other = Sequence2Sequence()
+    other.load_config(again)
+    other.configure()
+    other.load_weights(again)
+    other.batch_size = 4
+    got2 = other.correct_lines(lines, None, fast=True, greedy=True)
+    assert got2[0] == got[0] and got2[1] == got[1]

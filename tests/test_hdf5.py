@@ -1,0 +1,217 @@
+"""Model container: the dependency-free HDF5 reader against files written by libhdf5
+(tests/golden/keras_*.h5, made by tests/golden/make_keras_h5.py with h5py), the writer against the reader and -- where an
+interpreter with h5py exists -- against libhdf5, and the facade's save / load_config / load_weights /
+load_transfer_weights on the reference's container."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cor_asv_ann_amd import hdf5, keras_h5
+from cor_asv_ann_amd.engine import weight_shapes
+from cor_asv_ann_amd.seq2seq import Sequence2Sequence
+from oracle.weights import ModelConfig, make_vocabulary, make_weights
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+H5PY_PYTHON = '/opt/conda/bin/python3.9'
+
+
+def _expected(d=2, W=16, V=12):
+    return make_weights(ModelConfig(depth=d, width=W, voc_size=V))
+
+
+def test_reader_low_level_on_libhdf5_file():
+    f = hdf5.File(os.path.join(GOLDEN, 'keras_d2_w32_v12.h5'))
+    assert hdf5.is_hdf5(f.filename)
+    names = [n.decode() for n in f.attrs['layer_names']]
+    assert names[:4] == ['encoder_input', 'char_input_projection', 'encoder_lstm_1', 'dropout_1'] and len(names) == 13
+    assert set(f.keys()) == set(names) | {'config'}                        # > 8 links: several symbol-table nodes
+    assert f.attrs['backend'] == b'tensorflow' and f.attrs['keras_version'] == b'2.3.1'
+    g = f['encoder_lstm_1']
+    wn = [n.decode() for n in g.attrs['weight_names']]
+    assert wn[0] == 'encoder_lstm_1/forward_encoder_lstm_1/kernel:0' and len(wn) == 6
+    k = g[wn[0]]
+    assert k.shape == (32, 128) and k.dtype == np.float32
+    assert np.array_equal(k.read(), _expected(W=32)['enc1_fw_K'])
+    assert f['dropout_1'].attrs['weight_names'].shape == (0,) and f['dropout_1'].keys() == []
+    assert f['config/width'][()] == 32 and f['config/depth'][()] == 2
+    assert f['config/stateful'][()] == False and f['config/stateful'].dtype == np.dtype('bool')  # noqa: E712
+    assert f['config/mapping'].dtype == np.uint32 and f['config/mapping'].shape == (12,)
+    with pytest.raises(KeyError):
+        f['no/such/thing']
+    assert 'config' in f and 'nope' not in f
+
+
+@pytest.mark.parametrize('name,W', [('keras_d2_w32_v12.h5', 32), ('keras_d2_w16_v12_cudnn.h5', 16)])
+def test_keras_layout_to_tensors(name, W):
+    """LSTM-format and CuDNNLSTM-format files (fixed- and variable-length string attributes, contiguous and
+    gzip-chunked datasets) give the same tensors, bit for bit."""
+    config, layers = keras_h5.read_model(os.path.join(GOLDEN, name))
+    assert int(config['width']) == W and int(config['depth']) == 2 and not bool(config['bridge_dense'])
+    c_i, i_c = make_vocabulary(12)
+    assert [chr(c) if c else '' for c in config['mapping']] == [i_c[i] for i in range(12)]
+    assert list(layers) == list(keras_h5.layer_tensors(2))
+    want = _expected(W=W)
+    got = {}
+    for lname, tensors in layers.items():
+        assert list(tensors) == keras_h5.layer_tensors(2)[lname]
+        got.update(tensors)
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert np.array_equal(np.asarray(got[k]).reshape(v.shape), v), k
+
+
+def test_facade_loads_reference_container():
+    path = os.path.join(GOLDEN, 'keras_d2_w16_v12_cudnn.h5')
+    s2s = Sequence2Sequence()
+    s2s.load_config(path)
+    assert (s2s.width, s2s.depth, s2s.voc_size, s2s.stateful) == (16, 2, 12, False)
+    assert s2s.mapping[0]['\n'] == 1 and s2s.mapping[1][0] == ''
+    s2s.configure()
+    s2s.load_weights(path)
+    assert s2s.status == 2
+    want = _expected()
+    for k, v in s2s.get_weights().items():
+        assert np.array_equal(v, want[k]), k
+
+
+def test_load_weights_shape_mismatch_raises():
+    s2s = Sequence2Sequence()
+    s2s.load_config(os.path.join(GOLDEN, 'keras_d2_w32_v12.h5'))
+    s2s.width = 64
+    s2s.configure()
+    with pytest.raises(ValueError):
+        s2s.load_weights(os.path.join(GOLDEN, 'keras_d2_w32_v12.h5'))
+
+
+def _h5py_available():
+    if not os.path.exists(H5PY_PYTHON):
+        return False
+    try:
+        return subprocess.run([H5PY_PYTHON, '-c', 'import h5py'], capture_output=True, timeout=120).returncode == 0
+    except Exception:
+        return False
+
+
+CHECK_WITH_H5PY = r'''
+import sys, h5py, numpy as np
+f = h5py.File(sys.argv[1], 'r')
+out = {}
+# keras load_weights_from_hdf5_group_by_name: layer_names -> weight_names -> datasets, in order
+for lname in f.attrs['layer_names']:
+    g = f[lname]
+    for wname in g.attrs['weight_names']:
+        a = g[wname][()]
+        assert a.dtype == np.float32
+        out[lname.decode() + '|' + wname.decode()] = a
+cfg = f['config']
+for k in cfg:
+    out['config|' + k] = cfg[k][()]
+assert f.attrs['backend'] == b'tensorflow' or f.attrs['backend'] == 'tensorflow'
+np.savez(sys.argv[2], **out)
+'''
+
+
+def test_save_writes_the_reference_container(tmp_path):
+    want = _expected()
+    s2s = Sequence2Sequence()
+    s2s.width, s2s.depth = 16, 2
+    s2s.mapping = make_vocabulary(12)
+    s2s.voc_size = 12
+    s2s.configure()
+    s2s.set_weights(want)
+    s2s.status = 2
+    path = str(tmp_path / 'model.h5')
+    s2s.save(path)
+    assert hdf5.is_hdf5(path)
+    # own reader
+    other = Sequence2Sequence()
+    other.load_config(path)
+    assert (other.width, other.depth, other.voc_size) == (16, 2, 12) and other.mapping == s2s.mapping
+    other.configure()
+    other.load_weights(path)
+    for k, v in want.items():
+        assert np.array_equal(other.get_weights()[k], v), k
+    # libhdf5, following keras' loading order
+    if not _h5py_available():
+        pytest.skip('no interpreter with h5py on this machine: writer checked against the own reader only')
+    script = tmp_path / 'check.py'
+    script.write_text(CHECK_WITH_H5PY)
+    dump = str(tmp_path / 'dump.npz')
+    subprocess.run([H5PY_PYTHON, str(script), path, dump], check=True, timeout=300)
+    with np.load(dump) as data:
+        got = {k: data[k] for k in data.files}
+    table, knames = keras_h5.layer_tensors(2), keras_h5._keras_weight_names(2)
+    n = 0
+    for lname, tensors in table.items():
+        for t, kn in zip(tensors, knames[lname]):
+            a = got[lname + '|' + kn]
+            assert np.array_equal(a.reshape(want[t].shape), want[t]), t
+            n += 1
+    assert n == len(want)
+    assert int(got['config|width']) == 16 and got['config|stateful'].dtype == np.dtype('bool')
+    assert got['config|mapping'].dtype == np.uint32 and got['config|mapping'][1] == 10
+
+
+def test_transfer_from_shallower_model():
+    """seq2seq.py:1176-1213: layers are taken over by name; the shallower model's TOP decoder layer carries the
+    attention cell (7 weights) and is skipped, the new top layer is never transferred, and the transferred
+    hidden layers are frozen."""
+    src = _expected(d=1)
+    s2s = Sequence2Sequence()
+    s2s.width, s2s.depth = 16, 2
+    s2s.configure()
+    before = s2s.get_weights()
+    s2s.load_transfer_weights(os.path.join(GOLDEN, 'keras_d1_w16_v12.h5'))
+    assert s2s.status == 1 and s2s.voc_size == 12
+    after = s2s.get_weights()
+    assert after['E'].shape == (12, 16) and np.array_equal(after['E'], src['E'])
+    for k in ('enc1_fw_K', 'enc1_fw_R', 'enc1_fw_b', 'enc1_bw_K', 'enc1_bw_R', 'enc1_bw_b'):
+        assert np.array_equal(after[k], src[k]), k
+    # depth 1 attends to the 2W-wide BiLSTM output: attention_dense does not fit and is skipped
+    assert after['att_U'].shape == (16, 16)
+    assert not np.array_equal(after['dec1_R'], src['dec1_R'])      # the file's decoder_lstm_1 is its attention layer
+    assert not np.array_equal(after['att_Wa'], src['att_Wa'])      # the new top layer is never transferred
+    assert s2s.frozen_prefixes == ['enc1_', 'dec1_']
+    assert set(after) == set(weight_shapes(2, 16, 12)) and before.keys() == after.keys()
+
+
+def test_npz_container_still_works(tmp_path):
+    s2s = Sequence2Sequence()
+    s2s.width, s2s.depth = 16, 2
+    s2s.mapping = make_vocabulary(12)
+    s2s.voc_size = 12
+    s2s.configure()
+    s2s.status = 2
+    path = str(tmp_path / 'model.npz')
+    s2s.save(path)
+    assert not hdf5.is_hdf5(path)
+    other = Sequence2Sequence()
+    other.load_config(path)
+    other.configure()
+    other.load_weights(path)
+    for k, v in s2s.get_weights().items():
+        assert np.array_equal(other.get_weights()[k], v)
+
+
+def test_writer_reader_edge_cases(tmp_path):
+    w = hdf5.Writer()
+    w.create_group('empty')
+    w.create_dataset('scalars/i', np.array(-3))
+    w.create_dataset('scalars/f', np.array(2.5, np.float64))
+    w.create_dataset('scalars/b', np.array(True))
+    w.create_dataset('zero', np.zeros((0, 4), np.float32))
+    for i in range(70):
+        w.create_dataset('wide/n%03d' % i, np.full((2, 2), i, np.int32))
+    w.set_attr('wide', 'names', np.array([b'a', b'bcd'], dtype='S'))
+    w.set_attr('/', 'pi', np.float32(3.25))
+    path = str(tmp_path / 'x.h5')
+    w.save(path)
+    f = hdf5.File(path)
+    assert f['empty'].keys() == [] and f['scalars/i'][()] == -3 and f['scalars/f'][()] == 2.5 and f['scalars/b'][()] == True  # noqa: E712
+    assert f['zero'].read().shape == (0, 4)
+    assert len(f['wide'].keys()) == 70 and f['wide/n069'].read()[1, 1] == 69
+    assert list(f['wide'].attrs['names']) == [b'a', b'bcd'] and f.attrs['pi'] == np.float32(3.25)
+    with pytest.raises(hdf5.H5Error):
+        hdf5.File(__file__)
