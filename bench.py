@@ -51,6 +51,15 @@ def make_model(device):
     return s2s, cfg, weights
 
 
+def survey_flop_per_char():
+    """F = F_enc + N*S*F_row per line, divided by the L corrected characters."""
+    W, V, d, K, T, N = WIDTH, VOC, DEPTH, 11, LENGTH + 1, BEAM_N
+    C = 2 * W if d == 1 else W
+    f_row = 2 * V * W + (d - 1) * 16 * W * W + 2 * W * W + K * (4 * W + 2 * C) + 8 * W * (2 * W + C) + 2 * W * V
+    f_enc = T * (32 * W * W + (24 * W * W if d >= 2 else 0) + 16 * W * W * max(d - 2, 0) + 2 * C * W)
+    return (f_enc + N * 2 * T * f_row) / float(LENGTH)
+
+
 def cpu_baseline(cfg, weights, lines, budget_s=20.0):
     """The oracle in the reference's dataflow (per-character decoder call, dense-T attention, u recomputed
     every step, per-line best-first search) on the host cores, on as many lines of the same workload as
@@ -109,9 +118,9 @@ def train_bench(args):
         loss, norm = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=1)
     eng.synchronize()
     elapsed = time.perf_counter() - t0
-    pl, pg = eng.profile_read('lstm_gemm'), eng.profile_read('gemm')
+    pl, pg, ps = eng.profile_read('lstm_gemm'), eng.profile_read('gemm'), eng.profile_read('lstm_gemm_small')
     eng.profile(False)
-    fl, ms = pl['flops'] + pg['flops'], pl['ms'] + pg['ms']
+    fl, ms = pl['flops'] + pg['flops'] + ps['flops'], pl['ms'] + pg['ms'] + ps['ms']
     print(json.dumps({
         'metric': 'trained chars/sec (1 GPU), depth-4 width-512 teacher-forced train step, 100-char lines',
         'value': B * LENGTH * args.steps / elapsed, 'unit': 'chars/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
@@ -121,7 +130,7 @@ def train_bench(args):
                    'last_loss': loss, 'last_grad_norm': norm},
         'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel (all GEMMs of the step)', 'achieved': fl / max(ms, 1e-9) / 1e9,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / max(ms, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS,
-                     'traffic': None, 'launches': pl['launches'] + pg['launches']}}))
+                     'traffic': None, 'launches': pl['launches'] + pg['launches'] + ps['launches']}}))
 
 
 def main():
@@ -207,7 +216,7 @@ def main():
     eng.profile(1)                 # one extra, untimed step with events around every kernel class
     step()
     sync()
-    others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'gemm', 'attention', 'softmax', 'beam', 'embed')}
+    others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'lstm_gemm_small', 'gemm', 'attention', 'softmax', 'beam', 'embed')}
     eng.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device or 'cpu')
@@ -234,11 +243,15 @@ def main():
                                    'synthetic weights seed 20250614 emb_scale=%g' % (LINES, LENGTH, S, EMB_SCALE),
                        'lines_per_gpu': LINES, 'line_length': LENGTH, 'beam_n': BEAM_N, 'parallelism': 'lines sharded x%d' % world,
                        'graph': bool(args.graph)},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<EPI_LSTM> (fused LSTM-cell GEMM, fp32 MFMA)',
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<EPI_LSTM, 1> (fused LSTM-cell GEMM, 128x128 tiles, fp32 MFMA)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'launches': prof['launches'], 'avg_launch_us': 1e3 * prof['ms'] / max(prof['launches'], 1),
-                         'flops_per_launch': prof['flops'] / max(prof['launches'], 1)},
+                         'flops_per_launch': prof['flops'] / max(prof['launches'], 1),
+                         # the whole path priced with SURVEY.md section 8(d)'s algorithmic FLOP per corrected character
+                         'whole_path': {'flop_per_char': survey_flop_per_char(),
+                                        'achieved': chars / elapsed * survey_flop_per_char() / 1e12 / world,
+                                        'frac': chars / elapsed * survey_flop_per_char() / 1e12 / world / PEAK_F32_MFMA_TFLOPS}},
             'kernel_ms_per_step': {k: v['ms'] for k, v in others.items()},     # from one extra untimed step
         }
         if world == 1 and not args.no_cpu_baseline:

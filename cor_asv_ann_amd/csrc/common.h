@@ -9,12 +9,30 @@ namespace casv {
 // need 11*W tanh per decoder row; libm's tanhf made this kernel VALU-bound at 5x the time.
 __device__ __forceinline__ float fast_tanh(float x) {
     const float ax = fabsf(x);
-    if (ax < 0.25f) {
+    if (ax < 0.25f) {          // odd Taylor region: avoids the cancellation of 1 - 2/(1+e^2x)
         const float x2 = x * x;
         return x * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * (-0.0539682540f + x2 * 0.0218694885f))));
     }
     const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ax * 2.88539008177792681472f));
     return copysignf(t, x);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * 1.44269504088896340736f));
+}
+
+// The LSTM cell on gate pre-activations (Keras gate order i, f, c~, o; recurrent_activation = sigmoid,
+// seq2seq.py:268-272).  ONE definition for every GEMM variant, so that a row's result does not depend on which
+// variant the launcher picked for the batch it sits in.
+struct LstmCellOut { float i, f, g, o, c, h; };
+__device__ __forceinline__ LstmCellOut lstm_cell(float zi, float zf, float zg, float zo, float cprev) {
+    LstmCellOut r;
+    r.i = fast_sigmoid(zi);
+    r.f = fast_sigmoid(zf);
+    r.g = fast_tanh(zg);
+    r.o = fast_sigmoid(zo);
+    r.c = __builtin_fmaf(r.f, cprev, r.i * r.g);
+    r.h = r.o * fast_tanh(r.c);
+    return r;
 }
 
 
@@ -77,6 +95,10 @@ struct GemmBatch {
 
 void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream);
 void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream);
+void launch_gemm_skinny(int epi, const GemmBatch& b, int ksplit, hipStream_t stream);
+bool gemm_is_skinny(int epi, const GemmBatch& b);     // which tile shape launch_gemm_batch will pick
+// which tile shape small-M launches use: -1 = by size (default), 0 = always 128x128, 1 = always 32x128 (same results)
+void set_gemm_skinny_mode(int mode);
 
 // ---- small kernels (decode_kernels.hip) ----
 struct AttnArgs {

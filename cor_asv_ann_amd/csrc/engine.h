@@ -46,8 +46,9 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum ProfClass { PC_LSTM = 0, PC_GEMM, PC_ATTN, PC_SOFTMAX, PC_BEAM, PC_EMBED, PC_COUNT };
-inline const char* kProfNames[PC_COUNT] = {"lstm_gemm", "gemm", "attention", "softmax", "beam", "embed"};
+enum ProfClass { PC_LSTM = 0, PC_GEMM, PC_ATTN, PC_SOFTMAX, PC_BEAM, PC_EMBED, PC_LSTM_SMALL, PC_COUNT };
+// "lstm_gemm" = the 128x128-tile fused LSTM GEMM (the dominant kernel); "lstm_gemm_small" = its 32x128-tile variant
+inline const char* kProfNames[PC_COUNT] = {"lstm_gemm", "gemm", "attention", "softmax", "beam", "embed", "lstm_gemm_small"};
 
 struct Prof {
     bool on = false;
@@ -138,7 +139,7 @@ inline SlotPtr mkslot(float* base, int ld, long long slot_stride = 0, int mul = 
 
 inline void run_gemm_batch(casv_model* m, int epi, GemmBatch& b) {
     hipEvent_t a{};
-    const int cls = epi == EPI_LSTM ? PC_LSTM : PC_GEMM;
+    const int cls = epi == EPI_LSTM ? (m->prof.on && gemm_is_skinny(epi, b) ? PC_LSTM_SMALL : PC_LSTM) : PC_GEMM;
     double fl = 0, by = 0;
     for (int j = 0; j < b.count; ++j) {
         const GemmArgs& g = b.g[j];
@@ -153,15 +154,10 @@ inline void run_gemm_batch(casv_model* m, int epi, GemmBatch& b) {
 }
 
 inline void run_gemm(casv_model* m, int epi, GemmArgs& g) {
-    hipEvent_t a{};
-    const int cls = epi == EPI_LSTM ? PC_LSTM : PC_GEMM;
-    int kact = 0;
-    for (int i = 0; i < g.nseg; ++i) kact += g.a[i].width;
-    const double fl = 2.0 * g.M * (double)g.N * kact;
-    const double by = 4.0 * ((double)g.M * kact + (double)g.N * kact + (double)g.M * g.N);
-    m->prof_begin(cls, fl, by, a);
-    launch_gemm(epi, g, m->stream);
-    m->prof_end(cls, a);
+    GemmBatch b;
+    b.g[0] = g;
+    b.count = 1;
+    run_gemm_batch(m, epi, b);
 }
 
 

@@ -703,6 +703,10 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
         if (value < 0 || value >= m->V) return fail(CASV_ERR_ARG, "eos index %lld outside the vocabulary", (long long)value);
         m->eos = (int)value; return CASV_OK;
     }
+    if (!strcmp(key, "skinny")) {                   // process-wide: tile shape of small-M GEMM launches (results identical)
+        if (value < -1 || value > 1) return fail(CASV_ERR_ARG, "skinny must be -1 (by size), 0 or 1");
+        set_gemm_skinny_mode((int)value); return CASV_OK;
+    }
     return fail(CASV_ERR_ARG, "unknown option '%s'", key);
 }
 

@@ -26,20 +26,6 @@ constexpr int BM = 128, BN = 128, BK = 16, LDW = BK + 4;   // 80-B LDS rows: ds_
 constexpr int TILE_FLOATS = 128 * LDW;               // one operand tile
 constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;
 
-// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each):
-// absolute error <= 2e-7, far inside the parity tolerance.
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
-__device__ __forceinline__ float tanhf_(float x) {
-    const float ax = fabsf(x);
-    if (ax < 0.25f) {          // odd Taylor region: avoids the cancellation of 1 - 2/(1+e^2x)
-        const float x2 = x * x;
-        return x * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * (-0.0539682540f + x2 * 0.0218694885f))));
-    }
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp(2.0f * ax));
-    return copysignf(t, x);
-}
-
 // Software pipeline (per wave, so that ONE wave keeps its SIMD's matrix pipe busy and the two waves
 // of a SIMD do not have to be out of phase to cover each other):
 //   while the 32 MFMAs of tile kt run from fragment registers F[kt&1],
@@ -306,17 +292,12 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
             if (m < g.M) {
                 const float cprev = cpv[r];
                 float zi = acc[0][r] + bi, zf = acc[1][r] + bf_, zg = acc[2][r] + bg, zo = acc[3][r] + bo;
-                const float ig = sigmoidf_(zi);
-                const float fg = sigmoidf_(zf);
-                const float gg = tanhf_(zg);
-                const float og = sigmoidf_(zo);
-                const float c2 = fg * cprev + ig * gg;
-                const float h2 = og * tanhf_(c2);
-                cout[(long long)m * g.c_out.ld + u] = c2;
-                hout[(long long)m * g.out.ld + u] = h2;
+                const LstmCellOut cell = lstm_cell(zi, zf, zg, zo, cprev);
+                cout[(long long)m * g.c_out.ld + u] = cell.c;
+                hout[(long long)m * g.out.ld + u] = cell.h;
                 if (gout) {
                     float* gr = gout + (long long)m * g.gates_out.ld + n0 + l31;
-                    gr[0] = ig; gr[32] = fg; gr[64] = gg; gr[96] = og;
+                    gr[0] = cell.i; gr[32] = cell.f; gr[64] = cell.g; gr[96] = cell.o;
                 }
             }
         }
@@ -334,12 +315,52 @@ static void launch_one(const GemmBatch& bb, int blocks, int ksplit, hipStream_t 
     hipLaunchKernelGGL((gemm_kernel<EPI, KS>), dim3(blocks, bb.count, ksplit), dim3(256 * KS), GEMM_LDS_BYTES * KS, stream, bb);
 }
 
-void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
-    int blocks = 0;
+static int g_skinny_mode = -1;
+void set_gemm_skinny_mode(int mode) { g_skinny_mode = mode; }
+
+static int count_ktiles(const GemmArgs& g) {
+    int ktiles = 0;
+    for (int i = 0; i < g.nseg; ++i) ktiles += g.a[i].width / BK;
+    return ktiles;
+}
+
+// Tile shape and split-K factor of a launch.  Launches that would occupy at most half the CUs as 128x128 tiles (even
+// after split-K) run as 32x128 tiles: 4x the workgroups, same values.
+struct GemmPlan { int blocks, sblocks, ksplit; bool skinny; };
+static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
+    GemmPlan p{0, 0, 1, false};
     for (int j = 0; j < b.count; ++j) {
-        const int nb = ((b.g[j].M + BM - 1) / BM) * ((b.g[j].N + BN - 1) / BN);
-        blocks = nb > blocks ? nb : blocks;
+        const int nbn = (b.g[j].N + BN - 1) / BN;
+        const int nb = ((b.g[j].M + BM - 1) / BM) * nbn, ns = ((b.g[j].M + 31) / 32) * nbn;
+        p.blocks = nb > p.blocks ? nb : p.blocks;
+        p.sblocks = ns > p.sblocks ? ns : p.sblocks;
     }
+    bool splittable = epi == EPI_PLAIN;         // split-K: every job of the batch must ask for it and share the shape
+    for (int j = 0; j < b.count; ++j)
+        if (b.g[j].ksplit == 0 || b.g[j].ksplit == 1 || b.g[j].ksplit != b.g[0].ksplit || b.g[j].Ktot != b.g[0].Ktot ||
+            b.g[j].M != b.g[0].M || b.g[j].N != b.g[0].N) splittable = false;
+    auto choose_ksplit = [&](int grid, int want) {
+        if (!splittable) return 1;
+        const int ktiles = count_ktiles(b.g[0]);
+        int ks = b.g[0].ksplit;
+        if (ks < 0) {                           // fill the chip, keep >= 16 k-tiles per workgroup
+            ks = (want + grid - 1) / grid;
+            if (ks > ktiles / 16) ks = ktiles / 16;
+        }
+        if (ks > ktiles) ks = ktiles;
+        return ks < 1 ? 1 : ks;
+    };
+    p.ksplit = choose_ksplit(p.blocks * b.count, 512);
+    p.skinny = g_skinny_mode == 1 || (g_skinny_mode < 0 && p.blocks * b.count * p.ksplit <= 128);
+    if (p.skinny) p.ksplit = choose_ksplit(p.sblocks * b.count, 1024);
+    return p;
+}
+bool gemm_is_skinny(int epi, const GemmBatch& b) { return plan_gemm(epi, b).skinny; }
+
+void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
+    const GemmPlan plan = plan_gemm(epi, b);
+    const int blocks = plan.blocks, ksplit = plan.ksplit;
+    const bool skinny = plan.skinny;
     // XCD-aware tile order: minimise (A bytes x column-splits + B bytes x row-splits) over the 8 = xr * xc splits
     GemmBatch bb = b;
     for (int j = 0; j < bb.count; ++j) {
@@ -356,36 +377,18 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
         }
         g.xcd_rows = best_xr;
     }
-    int ksplit = 1;
-    bool splittable = epi == EPI_PLAIN;         // every job of the batch must ask for it and share the shape
-    for (int j = 0; j < b.count; ++j)
-        if (b.g[j].ksplit == 0 || b.g[j].ksplit == 1 || b.g[j].ksplit != b.g[0].ksplit || b.g[j].Ktot != b.g[0].Ktot ||
-            b.g[j].M != b.g[0].M || b.g[j].N != b.g[0].N) splittable = false;
-    if (splittable) {
-        int ktiles = 0;
-        for (int i = 0; i < b.g[0].nseg; ++i) ktiles += b.g[0].a[i].width / BK;
-        ksplit = b.g[0].ksplit;
-        if (ksplit < 0) {                       // fill ~2 blocks per CU, keep >= 16 k-tiles per block
-            ksplit = (512 + blocks * b.count - 1) / (blocks * b.count);
-            if (ksplit > ktiles / 16) ksplit = ktiles / 16;
-        }
-        if (ksplit > ktiles) ksplit = ktiles;
-        if (ksplit < 1) ksplit = 1;
-        for (int j = 0; j < b.count && ksplit > 1; ++j) {
-            const GemmArgs& g = b.g[j];
-            if (g.accumulate || g.out_zeroed) continue;   // partial sums are added atomically: start from zero
-            float* cbase = g.out.base + (long long)(g.step_imm * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
-            if (g.out.ld == g.N) (void)hipMemsetAsync(cbase, 0, (size_t)g.M * g.N * sizeof(float), stream);
-            else (void)hipMemset2DAsync(cbase, (size_t)g.out.ld * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream);
-        }
+    for (int j = 0; j < b.count && ksplit > 1; ++j) {
+        const GemmArgs& g = b.g[j];
+        if (g.accumulate || g.out_zeroed) continue;   // partial sums are added atomically: start from zero
+        float* cbase = g.out.base + (long long)(g.step_imm * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
+        if (g.out.ld == g.N) (void)hipMemsetAsync(cbase, 0, (size_t)g.M * g.N * sizeof(float), stream);
+        else (void)hipMemset2DAsync(cbase, (size_t)g.out.ld * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream);
     }
+    if (skinny) { launch_gemm_skinny(epi, bb, ksplit, stream); return; }
     // wave-group split-K (train step only, GemmArgs.kgroups): worth it while the grid leaves CUs idle
     bool two = true;
-    for (int j = 0; j < b.count; ++j) {
-        int ktiles = 0;
-        for (int i = 0; i < b.g[j].nseg; ++i) ktiles += b.g[j].a[i].width / BK;
-        if (b.g[j].kgroups != 2 || ktiles / ksplit < 16) two = false;
-    }
+    for (int j = 0; j < b.count; ++j)
+        if (b.g[j].kgroups != 2 || count_ktiles(b.g[j]) / ksplit < 16) two = false;
     if (blocks * b.count * ksplit > 256) two = false;
     if (epi == EPI_LSTM) { if (two) launch_one<EPI_LSTM, 2>(bb, blocks, ksplit, stream); else launch_one<EPI_LSTM, 1>(bb, blocks, ksplit, stream); }
     else { if (two) launch_one<EPI_PLAIN, 2>(bb, blocks, ksplit, stream); else launch_one<EPI_PLAIN, 1>(bb, blocks, ksplit, stream); }
