@@ -14,8 +14,10 @@ from oracle import ModelConfig, make_weights, make_lines
 from oracle.decode import OracleModel, correct_lines
 
 
-@pytest.mark.parametrize('seed,ncase', [(1, 40), (7, 40)])
-def test_random_beam_configurations(seed, ncase):
+@pytest.mark.parametrize('seed,ncase,tile', [(1, 40, -1), (7, 40, 0)])
+def test_random_beam_configurations(seed, ncase, tile):
+    """tile: -1 = the launcher's choice (32x128 tiles at these sizes), 0 = 128x128 tiles forced, so that both GEMM
+    kernels see the odd shapes of the sweep."""
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
     rng = np.random.default_rng(seed)
     bad, total = [], 0
@@ -48,7 +50,11 @@ def test_random_beam_configurations(seed, ncase):
         for k, v in kw.items():
             setattr(s2s, k, v)
         s2s.configure(); s2s.set_weights(w32); s2s.status = 2
-        got = s2s.correct_lines(lines, fast=False, greedy=False)
+        s2s._require_engine().set_option('skinny', tile)         # process-wide
+        try:
+            got = s2s.correct_lines(lines, fast=False, greedy=False)
+        finally:
+            s2s.engine.set_option('skinny', -1)
         want = res[np.float32]
         for j in range(B):
             total += 1
