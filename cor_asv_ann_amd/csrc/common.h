@@ -97,8 +97,8 @@ void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream);
 void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream);
 void launch_gemm_skinny(int epi, const GemmBatch& b, int ksplit, hipStream_t stream);
 bool gemm_is_skinny(int epi, const GemmBatch& b);     // which tile shape launch_gemm_batch will pick
-// which tile shape small-M launches use: -1 = by size (default), 0 = always 128x128, 1 = always 32x128 (same results)
-void set_gemm_skinny_mode(int mode);
+// tile shape of the GEMM launches: -1 = by size (default), 0 = always 128x128, 1 = always 32x128 (same results)
+void set_gemm_tile_mode(int mode);
 
 // ---- small kernels (decode_kernels.hip) ----
 struct AttnArgs {

@@ -703,9 +703,9 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
         if (value < 0 || value >= m->V) return fail(CASV_ERR_ARG, "eos index %lld outside the vocabulary", (long long)value);
         m->eos = (int)value; return CASV_OK;
     }
-    if (!strcmp(key, "skinny")) {                   // process-wide: tile shape of small-M GEMM launches (results identical)
-        if (value < -1 || value > 1) return fail(CASV_ERR_ARG, "skinny must be -1 (by size), 0 or 1");
-        set_gemm_skinny_mode((int)value); return CASV_OK;
+    if (!strcmp(key, "skinny") || !strcmp(key, "tile")) {   // process-wide: tile shape of the GEMM launches (results identical)
+        if (value < -1 || value > 1) return fail(CASV_ERR_ARG, "tile must be -1 (by size), 0 (128x128) or 1 (32x128)");
+        set_gemm_tile_mode((int)value); return CASV_OK;
     }
     return fail(CASV_ERR_ARG, "unknown option '%s'", key);
 }

@@ -315,8 +315,8 @@ static void launch_one(const GemmBatch& bb, int blocks, int ksplit, hipStream_t 
     hipLaunchKernelGGL((gemm_kernel<EPI, KS>), dim3(blocks, bb.count, ksplit), dim3(256 * KS), GEMM_LDS_BYTES * KS, stream, bb);
 }
 
-static int g_skinny_mode = -1;
-void set_gemm_skinny_mode(int mode) { g_skinny_mode = mode; }
+static int g_tile_mode = -1;       // -1 by size, 0 = 128x128, 1 = 32x128
+void set_gemm_tile_mode(int mode) { g_tile_mode = mode; }
 
 static int count_ktiles(const GemmArgs& g) {
     int ktiles = 0;
@@ -351,7 +351,7 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
         return ks < 1 ? 1 : ks;
     };
     p.ksplit = choose_ksplit(p.blocks * b.count, 512);
-    p.skinny = g_skinny_mode == 1 || (g_skinny_mode < 0 && p.blocks * b.count * p.ksplit <= 128);
+    p.skinny = g_tile_mode == 1 || (g_tile_mode < 0 && p.blocks * b.count * p.ksplit <= 128);
     if (p.skinny) p.ksplit = choose_ksplit(p.sblocks * b.count, 1024);
     return p;
 }

@@ -155,7 +155,7 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
                     int32_t iters, double* ms_per_launch);
 /* Options: "graph" = replay the decode step through a captured hipGraph (1) or launch kernels eagerly (0);
  * "eos" = vocabulary index of the end-of-line character '\n' (default 1: '' and '\n' sort first, seq2seq.py:580);
- * "skinny" (process-wide) = tile shape of small-M GEMM launches: -1 by size (default), 0 always 128x128,
+ * "tile" (process-wide; alias "skinny") = tile shape of the GEMM launches: -1 by size (default), 0 always 128x128,
  * 1 always 32x128 -- a measurement/test switch, the values computed are the same bit for bit. */
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 int casv_synchronize(casv_model* m);

@@ -317,23 +317,24 @@ def test_model_loaded_from_the_reference_container(golden_dir, tmp_path):
 
 
 def test_tile_shape_does_not_change_results():
-    """Small-M launches run as 32x128 tiles, large ones as 128x128 tiles (launcher picks by size): both contract k in
-    the same order with the same instruction sequence per element, so the choice -- which depends on the batch size --
-    must not change a single bit (the batch-independence of a row's result rests on it)."""
+    """GEMM launches run as 32x128 or 128x128 tiles (the launcher picks by size): both contract k in the same order
+    with the same instruction sequence per element, so the choice -- which depends on the batch size -- must not
+    change a single bit (the batch-independence of a row's result rests on it)."""
     cfg = ModelConfig(depth=2, width=96, voc_size=70)
     weights = make_weights(cfg, emb_scale=10.0)
-    _, idx = make_lines(40, 23, 5, voc_size=70)
+    _, idx = make_lines(70, 23, 5, voc_size=70)          # beam: 280 rows = three 128-row tiles, the last one ragged
     eng = _engine(cfg, weights)
     outs = []
     try:
         for mode in (0, 1):
-            eng.set_option('skinny', mode)
+            eng.set_option('tile', mode)
             eng.encode(idx)
             enc, states = eng.encoder_outputs()
             gi, gp, gl, _ = eng.decode_greedy(mode=0)
             bo = eng.decode_beam(batch_size=4)
             outs.append((enc, np.stack(states), gi, gp, gl, bo['idx'], bo['prob'], bo['score'], bo['len']))
     finally:
-        eng.set_option('skinny', -1)
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b, equal_nan=True)
+        eng.set_option('tile', -1)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b, equal_nan=True)

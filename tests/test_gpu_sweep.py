@@ -50,11 +50,11 @@ def test_random_beam_configurations(seed, ncase, tile):
         for k, v in kw.items():
             setattr(s2s, k, v)
         s2s.configure(); s2s.set_weights(w32); s2s.status = 2
-        s2s._require_engine().set_option('skinny', tile)         # process-wide
+        s2s._require_engine().set_option('tile', tile)         # process-wide
         try:
             got = s2s.correct_lines(lines, fast=False, greedy=False)
         finally:
-            s2s.engine.set_option('skinny', -1)
+            s2s.engine.set_option('tile', -1)
         want = res[np.float32]
         for j in range(B):
             total += 1
