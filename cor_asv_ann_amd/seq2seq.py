@@ -693,9 +693,62 @@ class Sequence2Sequence(object):
 
     def evaluate(self, filenames, fast=False, normalization='historic_latin', charmap=None, gt_level=1,
                  confusion=10, histogram=True):
-        raise NotImplementedError('evaluate() depends on lib/alignment.py (CER/WER metrics), which is outside the '
-                                  'hot path this package replaces; feed correct_lines() output to the reference\'s '
-                                  'Alignment/Edits classes instead')
+        """Character/word error rates of source (OCR), greedy and beamed output against the target (seq2seq.py:651-754).
+
+        The decoding runs here; the metrics are the reference's own `Alignment` / `Edits` / `splitwords`
+        (`ocrd_cor_asv_ann/lib/alignment.py`, outside the path this package replaces): they are imported from the
+        reference package, which a drop-in installation has."""
+        assert self.status == 2
+        try:
+            from ocrd_cor_asv_ann.lib.alignment import Alignment, Edits, splitwords
+        except ImportError as err:
+            raise NotImplementedError('evaluate() needs the reference\'s metrics (ocrd_cor_asv_ann.lib.alignment: Alignment, '
+                                      'Edits, splitwords), which this package does not replace: %s' % err)
+        names = ('origin', 'greedy', 'beamed')
+        c_counts = {k: Edits(self.logger, histogram=histogram) for k in names}
+        w_counts = {k: Edits(self.logger) for k in names}
+        c_aligner = {k: Alignment(0, logger=self.logger, confusion=confusion > 0) for k in names}
+        w_aligner = {k: Alignment(0, logger=self.logger) for k in names}
+
+        def get_counts(aligner, line_source, line_target):
+            dist, length = aligner.get_adjusted_distance(line_source, line_target, normalization=normalization, gtlevel=gt_level)
+            return dist, length, line_source, line_target
+
+        for batch in self.gen_lines(filenames, False, charmap=charmap):
+            lines_source, lines_sourceconf, lines_target, _ = batch
+            lines_greedy, _, scores_greedy, _ = self.correct_lines(lines_source, lines_sourceconf, fast=fast, greedy=True)
+            if fast:
+                lines_beamed, scores_beamed = lines_greedy, scores_greedy
+            else:
+                lines_beamed, _, scores_beamed, _ = self.correct_lines(lines_source, lines_sourceconf, fast=False, greedy=False)
+            for j in range(len(lines_source)):
+                if not lines_source[j] or not lines_target[j]:
+                    continue                    # from partially filled batch
+                self.logger.info('Source input              : %s', lines_source[j].rstrip(u'\n'))
+                self.logger.info('Target output             : %s', lines_target[j].rstrip(u'\n'))
+                self.logger.info('Target prediction (greedy): %s [%.2f]', lines_greedy[j].rstrip(u'\n'), scores_greedy[j])
+                self.logger.info('Target prediction (beamed): %s [%.2f]', lines_beamed[j].rstrip(u'\n'), scores_beamed[j])
+                lines = {'origin': lines_source[j], 'greedy': lines_greedy[j], 'beamed': lines_beamed[j]}
+                tokens_target = splitwords(lines_target[j])
+                for k in names:
+                    c_counts[k].add(*get_counts(c_aligner[k], lines[k], lines_target[j]))
+                    w_counts[k].add(*get_counts(w_aligner[k], splitwords(lines[k]), tokens_target))
+            c_counts['greedy'].score += sum(scores_greedy)
+            c_counts['beamed'].score += sum(scores_beamed)
+
+        self.logger.info('finished %d lines', c_counts['origin'].length)
+        labels = {'origin': 'OCR   ', 'greedy': 'greedy', 'beamed': 'beamed'}
+        if confusion > 0:
+            for k in names:
+                self.logger.info('%s confusion: %s', labels[k], c_aligner[k].get_confusion(confusion))
+        if histogram:
+            for k in names:
+                self.logger.info('%s histogram: %s', labels[k], repr(c_counts[k].hist()))
+        for k in ('greedy', 'beamed'):
+            self.logger.info('ppl %s: %.3f', k, math.exp(c_counts[k].score / max(c_counts[k].length, 1)))
+        for what, counts in (('CER', c_counts), ('WER', w_counts)):
+            for k in names:
+                self.logger.info('%s %s: %.3f±%.3f', what, labels[k].strip(), counts[k].mean, math.sqrt(counts[k].varia))
 
     def train(self, filenames, val_filenames=None):
         from .training import train_files

@@ -149,3 +149,53 @@ def test_node_api():
     root = Node(state=None, value='', scores=None, cost=0.0, length0=5, cost0=3.0)
     child = Node(state=None, value='x', scores=None, cost=0.5, parent=root)
     assert str(child) == 'x' and child.pro_cost() == -(0.5 + 3.0 * 3) and child > root
+
+
+def test_evaluate_uses_the_reference_metrics(tmp_path, monkeypatch):
+    """evaluate() (seq2seq.py:651-754) decodes here and hands the lines to the reference's Alignment/Edits; without
+    that package it says so instead of inventing metrics."""
+    import sys
+    import types
+    tsv = tmp_path / 'a.tsv'
+    tsv.write_text('abc\tabd\nb\tbb\ncab\tcab\n')
+    s2s = _small_model()
+    s2s.status, s2s.batch_size = 2, 2
+    monkeypatch.setattr(s2s, 'correct_lines', lambda lines, conf=None, fast=True, greedy=True:
+                        (list(lines), [[1.0] * len(l) for l in lines], [0.5 if l else 0 for l in lines], [[] for _ in lines]))
+    for name in ('ocrd_cor_asv_ann', 'ocrd_cor_asv_ann.lib', 'ocrd_cor_asv_ann.lib.alignment'):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    with pytest.raises(NotImplementedError):
+        s2s.evaluate([str(tsv)])
+
+    calls = []
+
+    class Alignment(object):
+        def __init__(self, gap, logger=None, confusion=False):
+            pass
+
+        def get_adjusted_distance(self, a, b, normalization=None, gtlevel=1):
+            calls.append((tuple(a) if isinstance(a, list) else a, tuple(b) if isinstance(b, list) else b, normalization, gtlevel))
+            return float(sum(x != y for x, y in zip(a, b))), max(len(a), len(b))
+
+        def get_confusion(self, n):
+            return []
+
+    class Edits(object):
+        def __init__(self, logger=None, histogram=False):
+            self.length = 0; self.mean = 0.0; self.varia = 0.0; self.score = 0.0; self.total = 0.0
+
+        def add(self, dist, length, seq1, seq2):
+            self.length += 1; self.total += dist / max(length, 1); self.mean = self.total / self.length
+
+        def hist(self):
+            return {}
+
+    mod = types.ModuleType('ocrd_cor_asv_ann.lib.alignment')
+    mod.Alignment, mod.Edits, mod.splitwords = Alignment, Edits, lambda text: text.split()
+    for name in ('ocrd_cor_asv_ann', 'ocrd_cor_asv_ann.lib'):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    monkeypatch.setitem(sys.modules, 'ocrd_cor_asv_ann.lib.alignment', mod)
+    s2s.evaluate([str(tsv)], fast=True, normalization='NFC', gt_level=2, confusion=0, histogram=False)
+    # 3 lines x (origin, greedy, beamed) x (characters, words); the padding line of the last batch is skipped
+    assert len(calls) == 18 and all(c[2] == 'NFC' and c[3] == 2 for c in calls)
+    assert ('abc\n', 'abd\n', 'NFC', 2) in calls and (('abc',), ('abd',), 'NFC', 2) in calls
