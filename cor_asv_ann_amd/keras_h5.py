@@ -72,6 +72,22 @@ def _as_names(attr):
     return [n.decode('utf-8') if isinstance(n, bytes) else str(n) for n in np.asarray(attr).ravel().tolist()]
 
 
+def _guard(func):
+    """Truncated or damaged files surface as hdf5.H5Error, not as struct/index errors from the parser."""
+    import functools
+    import struct
+    from zlib import error as zlib_error
+
+    @functools.wraps(func)
+    def wrapper(*args, **kwargs):
+        try:
+            return func(*args, **kwargs)
+        except (struct.error, IndexError, ValueError, OverflowError, UnicodeDecodeError, RecursionError, MemoryError, zlib_error) as err:
+            raise hdf5.H5Error('damaged or unsupported HDF5 file "%s": %s' % (args[0] if args else '?', err))
+    return wrapper
+
+
+@_guard
 def read_config(filename):
     """The `config` group as a dict (seq2seq.py:1143-1162); {} if the file has none (plain keras weight files)."""
     with hdf5.File(filename) as f:
@@ -89,6 +105,7 @@ def read_config(filename):
         return out
 
 
+@_guard
 def read_layers(filename):
     """{keras layer name: [arrays in weight_names order]} for every layer group that has weights."""
     with hdf5.File(filename) as f:

@@ -215,3 +215,24 @@ def test_writer_reader_edge_cases(tmp_path):
     assert list(f['wide'].attrs['names']) == [b'a', b'bcd'] and f.attrs['pi'] == np.float32(3.25)
     with pytest.raises(hdf5.H5Error):
         hdf5.File(__file__)
+
+
+def test_damaged_files_raise_h5error(tmp_path):
+    data = open(os.path.join(GOLDEN, 'keras_d1_w16_v12.h5'), 'rb').read()
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        if trial % 2:
+            bad = data[:int(rng.integers(16, len(data)))]
+        else:
+            b = bytearray(data)
+            for pos in rng.integers(0, min(len(b), 20000), size=8):
+                b[int(pos)] ^= 0xFF
+            bad = bytes(b)
+        path = str(tmp_path / ('bad%d.h5' % trial))
+        with open(path, 'wb') as f:
+            f.write(bad)
+        try:
+            keras_h5.read_config(path)
+            keras_h5.read_layers(path)
+        except (hdf5.H5Error, KeyError):
+            pass                                    # anything else (struct.error, IndexError, hang) fails the test
