@@ -154,7 +154,10 @@ def main():
     backend = os.environ.get('CASV_BENCH_BACKEND', 'nccl')     # 'gloo' + CASV_BENCH_SAME_DEVICE=1: rehearsal of the
     if os.environ.get('CASV_BENCH_SAME_DEVICE'):               # N-rank path on a one-GPU box (all ranks on device 0)
         local_rank = 0
-    if world > 1:
+    # CASV_BENCH_FORCE_DIST=1: take the multi-rank path (process group, barrier, all-gather, max-reduce) with ONE rank,
+    # to exercise the RCCL calls on a one-GPU box (launch under torch.distributed.run --nproc-per-node 1)
+    dist_on = world > 1 or bool(os.environ.get('CASV_BENCH_FORCE_DIST'))
+    if dist_on:
         import torch
         import torch.distributed as dist
         if backend == 'nccl':
@@ -174,29 +177,20 @@ def main():
     if args.graph:
         eng.set_option('graph', 1)
     S = 2 * (LENGTH + 1)
-    device = ('cuda:%d' % local_rank) if (world > 1 and backend == 'nccl') else None
+    device = ('cuda:%d' % local_rank) if (dist_on and backend == 'nccl') else None
 
     def step():
         out_lines, probs, scores, _ = s2s.correct_lines(lines, fast=False, greedy=False, alignments=False)
-        if world > 1:
+        if dist_on:
             # fixed-width records (characters, probabilities, length, score) -> RCCL all-gather
-            idx = np.zeros((len(lines), S), np.int32)
-            prob = np.zeros((len(lines), S), np.float32)
-            length = np.zeros(len(lines), np.int32)
             keys, values = s2s._codepoint_table()
-            for j, (text, p) in enumerate(zip(out_lines, probs)):
-                n = min(len(text), S)
-                cps = np.frombuffer(text[:n].encode('utf-32-le', 'surrogatepass'), dtype=np.uint32)
-                idx[j, :n] = values[np.searchsorted(keys, cps)]
-                prob[j, :min(len(p), n)] = p[:n]
-                length[j] = n
-            rec = sharding.pack_records(idx, prob, length, np.asarray(scores, np.float64))
+            rec = sharding.records_from_lines(out_lines, probs, scores, keys, values, S)
             return sharding.all_gather_records(rec, len(all_lines), device=device)
         return out_lines
 
     def sync():
         eng.synchronize()
-        if world > 1:
+        if dist_on:
             if backend == 'nccl':
                 torch.cuda.synchronize()
             dist.barrier()
@@ -218,7 +212,7 @@ def main():
     sync()
     others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'lstm_gemm_small', 'gemm', 'attention', 'softmax', 'beam', 'embed')}
     eng.profile(False)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device or 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -256,7 +250,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64])
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

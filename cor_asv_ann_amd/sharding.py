@@ -33,6 +33,26 @@ def pack_records(idx, prob, length, score, found=None):
     return rec
 
 
+def records_from_lines(lines, probs, scores, keys, values, steps):
+    """Decoded strings + per-character probabilities (the return values of correct_lines) -> records.
+    keys/values: sorted code points of the vocabulary and their indices (Sequence2Sequence._codepoint_table)."""
+    n, S = len(lines), int(steps)
+    idx = np.zeros((n, S), np.int32)
+    prob = np.zeros((n, S), np.float32)
+    lens = np.fromiter((min(len(t), S) for t in lines), dtype=np.int64, count=n)
+    total = int(lens.sum())
+    if total:
+        cps = np.frombuffer(''.join(t[:S] for t in lines).encode('utf-32-le', 'surrogatepass'), dtype=np.uint32)
+        rows = np.repeat(np.arange(n), lens)
+        cols = np.arange(total) - np.repeat(np.cumsum(lens) - lens, lens)
+        idx[rows, cols] = values[np.minimum(np.searchsorted(keys, cps), len(keys) - 1)]
+        flat = np.concatenate([np.asarray(p[:m], np.float32) if len(p) >= m else
+                               np.concatenate([np.asarray(p, np.float32), np.zeros(m - len(p), np.float32)])
+                               for p, m in zip(probs, lens) if m])
+        prob[rows, cols] = flat
+    return pack_records(idx, prob, lens.astype(np.int32), np.asarray(scores, np.float64))
+
+
 def unpack_records(rec):
     rec = np.ascontiguousarray(rec, np.int32)
     S = (rec.shape[1] - 4) // 2

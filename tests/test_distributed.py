@@ -33,6 +33,24 @@ def test_records_roundtrip():
         assert np.array_equal(a, b)
 
 
+def test_records_from_lines():
+    """Strings + probability lists (what correct_lines returns) -> records -> strings, incl. empty, truncated and
+    lines whose probability list is shorter than the text (fallback lines)."""
+    chars = ['', '\n'] + [chr(c) for c in range(0x61, 0x61 + 20)] + ['ß', '中']
+    i_c = dict(enumerate(chars))
+    items = sorted((ord(c), i) for i, c in i_c.items() if len(c) == 1)
+    keys = np.array([k for k, _ in items], np.uint32)
+    values = np.array([v for _, v in items], np.int32)
+    lines = ['abc\n', '', 'ß中a\n', 'abcdefghij\n', 'b']
+    probs = [[0.5, 0.25, 1.0, 0.125], [], [0.1, 0.2, 0.3, 0.4], [0.9] * 11, []]
+    scores = [0.1, 0.0, 0.3, 0.4, 0.0]
+    rec = sharding.records_from_lines(lines, probs, scores, keys, values, 6)
+    idx, prob, length, score, found = sharding.unpack_records(rec)
+    assert list(length) == [4, 0, 4, 6, 1] and np.allclose(score, scores)
+    assert sharding.records_to_strings(idx, length, i_c) == ['abc\n', '', 'ß中a\n', 'abcdef', 'b']
+    assert np.allclose(prob[0, :4], probs[0]) and np.allclose(prob[3, :6], 0.9) and prob[4, 0] == 0 and not prob[1].any()
+
+
 def _worker(rank, world, port, n_lines, tmpdir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
