@@ -183,8 +183,7 @@ def main():
         out_lines, probs, scores, _ = s2s.correct_lines(lines, fast=False, greedy=False, alignments=False)
         if dist_on:
             # fixed-width records (characters, probabilities, length, score) -> RCCL all-gather
-            keys, values = s2s._codepoint_table()
-            rec = sharding.records_from_lines(out_lines, probs, scores, keys, values, S)
+            rec = sharding.records_from_lines(out_lines, probs, scores, s2s._codepoint_lut(), S)
             return sharding.all_gather_records(rec, len(all_lines), device=device)
         return out_lines
 

@@ -352,19 +352,19 @@ class Sequence2Sequence(object):
                     j += width
         else:
             # plain strings: ONE table lookup over all code points of the batch
-            keys, values = self._codepoint_table()
+            lut = self._codepoint_lut()
             lens = np.fromiter((len(line) for line in lines), dtype=np.int64, count=B)
             total = int(lens.sum())
             if total:
                 cps = np.frombuffer(''.join(lines).encode('utf-32-le', 'surrogatepass'), dtype=np.uint32)
-                pos = np.minimum(np.searchsorted(keys, cps), len(keys) - 1)
-                hit = keys[pos] == cps
+                found = lut[np.minimum(cps, len(lut) - 1)]
+                hit = found >= 0
                 rows = np.repeat(np.arange(B), lens)
                 cols = np.arange(total) - np.repeat(np.cumsum(lens) - lens, lens)
                 if not hit.all():
                     for j in np.nonzero(~hit)[0]:
                         self._index(lines[int(rows[j])][int(cols[j])], 'encoder input', int(rows[j]))   # logs like the reference
-                idx[rows, cols, 0] = np.where(hit, values[pos], 0)
+                idx[rows, cols, 0] = np.where(hit, found, 0)
                 if conf:
                     val[rows, cols, 0] = np.concatenate([np.asarray(c, np.float32) for c in conf if len(c)])
                 else:
@@ -415,9 +415,16 @@ class Sequence2Sequence(object):
             for i, c in self.mapping[1].items():
                 if len(c) == 1 and i < len(out):
                     out[i] = ord(c)
-            self._cp_cache = (mapping, len(mapping), keys, values, out)
+            lut = np.full(int(keys.max()) + 2, -1, np.int32)       # code point -> index, -1 = unmapped (last slot: beyond)
+            lut[keys] = values
+            self._cp_cache = (mapping, len(mapping), keys, values, out, lut)
             cached = self._cp_cache
         return cached[2], cached[3]
+
+    def _codepoint_lut(self):
+        """Dense code point -> vocabulary index table (-1 = unmapped); the last slot stands for all larger code points."""
+        self._codepoint_table()
+        return self._cp_cache[5]
 
     def _chars(self, indexes):
         self._codepoint_table()

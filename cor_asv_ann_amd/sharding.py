@@ -33,9 +33,10 @@ def pack_records(idx, prob, length, score, found=None):
     return rec
 
 
-def records_from_lines(lines, probs, scores, keys, values, steps):
+def records_from_lines(lines, probs, scores, lut, steps):
     """Decoded strings + per-character probabilities (the return values of correct_lines) -> records.
-    keys/values: sorted code points of the vocabulary and their indices (Sequence2Sequence._codepoint_table)."""
+    lut: code point -> vocabulary index, last slot for everything beyond (Sequence2Sequence._codepoint_lut)."""
+    from itertools import chain
     n, S = len(lines), int(steps)
     idx = np.zeros((n, S), np.int32)
     prob = np.zeros((n, S), np.float32)
@@ -43,13 +44,15 @@ def records_from_lines(lines, probs, scores, keys, values, steps):
     total = int(lens.sum())
     if total:
         cps = np.frombuffer(''.join(t[:S] for t in lines).encode('utf-32-le', 'surrogatepass'), dtype=np.uint32)
-        rows = np.repeat(np.arange(n), lens)
-        cols = np.arange(total) - np.repeat(np.cumsum(lens) - lens, lens)
-        idx[rows, cols] = values[np.minimum(np.searchsorted(keys, cps), len(keys) - 1)]
-        flat = np.concatenate([np.asarray(p[:m], np.float32) if len(p) >= m else
-                               np.concatenate([np.asarray(p, np.float32), np.zeros(m - len(p), np.float32)])
-                               for p, m in zip(probs, lens) if m])
-        prob[rows, cols] = flat
+        starts = np.cumsum(lens) - lens
+        pos = np.repeat(np.arange(n) * S - starts, lens) + np.arange(total)        # flat position of every character
+        np.put(idx, pos, np.maximum(lut[np.minimum(cps, len(lut) - 1)], 0))
+        plens = np.fromiter((min(len(p), m) for p, m in zip(probs, lens)), dtype=np.int64, count=n)
+        ptotal = int(plens.sum())
+        if ptotal:
+            flat = np.fromiter(chain.from_iterable(p[:m] for p, m in zip(probs, plens)), dtype=np.float32, count=ptotal)
+            ppos = np.repeat(np.arange(n) * S - (np.cumsum(plens) - plens), plens) + np.arange(ptotal)
+            np.put(prob, ppos, flat)
     return pack_records(idx, prob, lens.astype(np.int32), np.asarray(scores, np.float64))
 
 

@@ -38,13 +38,14 @@ def test_records_from_lines():
     lines whose probability list is shorter than the text (fallback lines)."""
     chars = ['', '\n'] + [chr(c) for c in range(0x61, 0x61 + 20)] + ['ß', '中']
     i_c = dict(enumerate(chars))
-    items = sorted((ord(c), i) for i, c in i_c.items() if len(c) == 1)
-    keys = np.array([k for k, _ in items], np.uint32)
-    values = np.array([v for _, v in items], np.int32)
+    lut = np.full(max(ord(c) for c in chars if c) + 2, -1, np.int32)
+    for i, c in i_c.items():
+        if c:
+            lut[ord(c)] = i
     lines = ['abc\n', '', 'ß中a\n', 'abcdefghij\n', 'b']
     probs = [[0.5, 0.25, 1.0, 0.125], [], [0.1, 0.2, 0.3, 0.4], [0.9] * 11, []]
     scores = [0.1, 0.0, 0.3, 0.4, 0.0]
-    rec = sharding.records_from_lines(lines, probs, scores, keys, values, 6)
+    rec = sharding.records_from_lines(lines, probs, scores, lut, 6)
     idx, prob, length, score, found = sharding.unpack_records(rec)
     assert list(length) == [4, 0, 4, 6, 1] and np.allclose(score, scores)
     assert sharding.records_to_strings(idx, length, i_c) == ['abc\n', '', 'ß中a\n', 'abcdef', 'b']
