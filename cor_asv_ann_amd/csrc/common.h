@@ -72,6 +72,7 @@ struct GemmArgs {
     SlotPtr c_out;
     SlotPtr zinit;        // LSTM: pre-activation term added to the contraction, [M][4U] interleaved (x.K + b of all steps, precomputed)
     SlotPtr gates_out;    // training: activated gates i,f,g,o, [M][4U] in the interleaved column order (or null)
+    int epi_plain;        // job of an EPI_LSTM launch that takes the PLAIN epilogue (lets independent GEMMs of both kinds share a launch)
     int accumulate;       // PLAIN: C += A.B^T instead of C = (weight-gradient sums)
     int out_zeroed;       // PLAIN with split-K: the caller has already cleared the output (no memset per launch)
     int kgroups;          // 2 = allow the two-wave-group split-K variant (train step; changes the summation order)

@@ -360,6 +360,13 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         return mkseg(m->st_h[n - 1].as<float>(), W, W, 0, nullptr, RW, 1, 1);
     };
     auto xwidth = [&](int n) { return n == 1 ? Vp : W; };
+    // attention query of this step: h_{t-1} . W_a + b_UW (attention.py:539) -- depends only on the previous step, so it
+    // shares the launch of layer 1 (a job with the plain epilogue) instead of waiting behind the lower layers
+    GemmArgs gq{};
+    gq.nseg = 1; gq.a[0] = mkseg(m->st_h[D].as<float>(), W, W, 0, prev);
+    gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W;
+    gq.out = mkslot(m->wq.as<float>(), W);
+    gq.step_ptr = step_ptr; gq.step_imm = step_imm;
     for (int n = 1; n < D; ++n) {
         GemmArgs g{};
         g.nseg = 2;
@@ -371,16 +378,15 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.c_in = mkseg(m->st_c[n].as<float>(), W, W, 0, prev);
         g.c_out = mkslot(m->st_c[n].as<float>(), W, RW, 1, 1);
         g.step_ptr = step_ptr; g.step_imm = step_imm;
-        run_gemm(m, EPI_LSTM, g);
+        if (n == 1) {
+            GemmBatch b{};
+            b.g[0] = g; b.g[1] = gq; b.g[1].epi_plain = 1; b.count = 2;
+            run_gemm_batch(m, EPI_LSTM, b);
+        } else {
+            run_gemm(m, EPI_LSTM, g);
+        }
     }
-    {   // attention query: h_{t-1} . W_a + b_UW (attention.py:539)
-        GemmArgs g{};
-        g.nseg = 1; g.a[0] = mkseg(m->st_h[D].as<float>(), W, W, 0, prev);
-        g.Bt = m->WaT.as<float>(); g.bias = m->bUW.as<float>(); g.M = R; g.N = W; g.Ktot = W;
-        g.out = mkslot(m->wq.as<float>(), W);
-        g.step_ptr = step_ptr; g.step_imm = step_imm;
-        run_gemm(m, EPI_PLAIN, g);
-    }
+    if (D == 1) run_gemm(m, EPI_PLAIN, gq);
     {
         AttnArgs a{};
         a.wq = m->wq.as<float>(); a.u = m->u.as<float>(); a.enc = m->enc_out; a.va = m->va.as<float>(); a.bv = m->bv.as<float>();

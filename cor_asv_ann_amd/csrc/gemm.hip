@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
 
     // LSTM: previous cell state of this lane's 16 (row, unit) elements, fetched under the main loop
     float cpv[16];
-    if (EPI == EPI_LSTM && grp == 0) {
+    if (EPI == EPI_LSTM && grp == 0 && !g.epi_plain) {
         const bool cfirst = g.c_in.first_base && step == 0;
         const bool czero = g.c_in.skip_first && step == 0 && !cfirst;
         const float* cin = cfirst ? g.c_in.first_base
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
     }
 
     // ---- epilogue ----
-    if (EPI == EPI_PLAIN) {
+    if (EPI == EPI_PLAIN || g.epi_plain) {
         float* cbase = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {

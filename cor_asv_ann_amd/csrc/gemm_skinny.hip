@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
 
     // LSTM: wave w finishes rows (r & 3, r >> 2 == w) of the tile; fetch their previous cell state under the K loop
     float cpv[4];
-    if (EPI == EPI_LSTM) {
+    if (EPI == EPI_LSTM && !g.epi_plain) {
         const bool cfirst = g.c_in.first_base && step == 0;
         const bool czero = g.c_in.skip_first && step == 0 && !cfirst;
         const float* cin = cfirst ? g.c_in.first_base
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
     }
 
     // ---- epilogue ----
-    if (EPI == EPI_PLAIN) {
+    if (EPI == EPI_PLAIN || g.epi_plain) {
         float* cbase = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
         const int n = n0 + wave * 32 + l31;
         if (n < g.N) {
