@@ -497,7 +497,7 @@ class Sequence2Sequence(object):
             if n == 0:
                 return
             aligns = [res['align'][r, s] for s in range(n)] if res['align'] is not None else []
-            yield (self._chars(res['idx'][r, :n]), list(res['prob'][r, :n]), float(res['score'][r]), aligns)
+            yield (self._chars(res['idx'][r, :n]), res['prob'][r, :n].tolist(), float(res['score'][r]), aligns)
 
     def _beam_kwargs(self):
         return dict(batch_size=self.batch_size, beam_width_in=self.beam_width_in,
