@@ -10,6 +10,7 @@ back finished strings.  There is no CPU fallback: without the HIP library every 
 """
 import logging
 import math
+import os
 import pickle
 import unicodedata
 from collections import OrderedDict
@@ -525,8 +526,9 @@ class Sequence2Sequence(object):
             return [], [], [], []
         eng = self._require_engine()
         idx, val, _ = self._sparse_lines(lines, conf)
-        eng.encode(idx, val)
         B, T = idx.shape[:2]
+        if fast or greedy:
+            eng.encode(idx, val)
         if fast:
             gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=alignments)
             nonpad = (idx >= 0).any(axis=(1, 2))
@@ -534,24 +536,35 @@ class Sequence2Sequence(object):
         if greedy:
             results = self._sequence_greedy_results(eng, B)
             return self._finish(lines, [r if lines[j] else ('', [], 0, []) for j, r in enumerate(results)])
-        res = eng.decode_beam(max_results=1, want_align=alignments, **self._beam_kwargs())
+        # The search keeps every expansion's state on the device (nothing is recomputed, nothing crosses to the host):
+        # S x (lines x N) rows of h, c per layer, scores and alignments.  Large beams (the reference's default
+        # batch_size = 256 hypotheses per step) are therefore decoded in chunks of lines that fit a memory budget;
+        # lines are independent, so chunking does not change any result.
+        per_line = 2 * T * self.batch_size * (2 * self.depth * self.width + self.voc_size + 32 + T) * 4
+        budget = float(os.environ.get('CASV_BEAM_MEMORY_GB', '96')) * 2 ** 30
+        chunk = int(max(1, min(B, budget // max(per_line, 1))))
         results = []
-        for j, input_line in enumerate(lines):
-            if not input_line:
-                results.append(('', [], 0, []))
-                continue
-            item = next(self._beam_results(res, j, 1, T), None)
-            if item is None:
-                # the generator of the reference raises StopIteration here (seq2seq.py:826-836)
-                self.logger.error('cannot beam-decode input line %d: "%s"', j, input_line)
-                if isinstance(input_line[0], tuple):
-                    line = ''.join(chunk[0] for chunk in input_line)
-                if isinstance(input_line[0], list):
-                    line = ''.join(chunk[0][0] if chunk else '' for chunk in input_line)
-                else:
-                    line = input_line
-                item = (line, [1.0] * len(line), 0, np.eye(len(line)).tolist() if alignments else [])
-            results.append(item)
+        for lo in range(0, B, chunk):
+            hi = min(B, lo + chunk)
+            eng.encode(idx[lo:hi], val[lo:hi])
+            res = eng.decode_beam(max_results=1, want_align=alignments, **self._beam_kwargs())
+            for j in range(lo, hi):
+                input_line = lines[j]
+                if not input_line:
+                    results.append(('', [], 0, []))
+                    continue
+                item = next(self._beam_results(res, j - lo, 1, T), None)
+                if item is None:
+                    # the generator of the reference raises StopIteration here (seq2seq.py:826-836)
+                    self.logger.error('cannot beam-decode input line %d: "%s"', j, input_line)
+                    if isinstance(input_line[0], tuple):
+                        line = ''.join(chunk_[0] for chunk_ in input_line)
+                    if isinstance(input_line[0], list):
+                        line = ''.join(chunk_[0][0] if chunk_ else '' for chunk_ in input_line)
+                    else:
+                        line = input_line
+                    item = (line, [1.0] * len(line), 0, np.eye(len(line)).tolist() if alignments else [])
+                results.append(item)
         return self._finish(lines, results)
 
     @staticmethod

@@ -338,3 +338,19 @@ def test_tile_shape_does_not_change_results():
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_beam_chunking_under_a_memory_budget(monkeypatch):
+    """Large beams are decoded in chunks of lines (the per-expansion state of all steps stays on the device);
+    lines are independent, so the results must not depend on the chunk size."""
+    cfg = ModelConfig(depth=2, width=64, voc_size=96)
+    weights = make_weights(cfg, emb_scale=12.0)
+    om = OracleModel(cfg, weights, batch_size=4)
+    lines, _ = make_lines(7, 14, 31, voc_size=96)
+    s2s = _facade(cfg, weights, om.mapping, N=4)
+    whole = s2s.correct_lines(lines, fast=False, greedy=False)
+    monkeypatch.setenv('CASV_BEAM_MEMORY_GB', '0.0005')         # ~0.5 MB: three lines per chunk at this size
+    parts = s2s.correct_lines(lines, fast=False, greedy=False)
+    assert parts[0] == whole[0] and parts[1] == whole[1] and parts[2] == whole[2]
+    for a, b in zip(parts[3], whole[3]):
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
