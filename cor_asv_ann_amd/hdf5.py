@@ -147,8 +147,10 @@ class Dataset(_Object):
         count = int(np.prod(shape, dtype=np.int64)) if shape else 1
         nbytes = count * self.type.size
         version = lay[0]
-        if version == 3:
+        if version in (3, 4):
             cls = lay[1]
+            if version == 4 and cls == 2:
+                raise H5Error('version-4 chunked layouts (libver="latest") are not supported; re-save contiguous or with libver="earliest"')
             if cls == 0:                                    # compact
                 size = struct.unpack_from('<H', lay, 2)[0]
                 raw = lay[4:4 + size]

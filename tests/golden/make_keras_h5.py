@@ -10,6 +10,7 @@ checked against the real container format rather than against its own writer.
   keras_d2_w16_v12_cudnn.h5  same tensors, encoder/decoder LSTM layers in CuDNNLSTM format (models trained on a GPU,
                              seq2seq.py:216-219), variable-length string attributes (h5py 3.x), gzip-chunked kernels
   keras_d1_w16_v12.h5        a depth-1 model (shallower-model transfer, seq2seq.py:1206-1211)
+  keras_d1_w16_v12_latest.h5 the same written with libver='latest' (superblock v3, version-2 object headers, link messages)
 """
 import os
 import sys
@@ -50,7 +51,7 @@ def layer_list(d):
     return layers
 
 
-def write(path, d, W, V, cudnn=False, vlen_attrs=False):
+def write(path, d, W, V, cudnn=False, vlen_attrs=False, libver='earliest'):
     cfg = ModelConfig(depth=d, width=W, voc_size=V)
     w = make_weights(cfg)
     _, i_c = make_vocabulary(V)
@@ -58,7 +59,7 @@ def write(path, d, W, V, cudnn=False, vlen_attrs=False):
     def names(lst):
         return [n.encode('utf8') for n in lst] if vlen_attrs else np.array([n.encode('utf8') for n in lst] or [], dtype='S')
 
-    with h5py.File(path, 'w') as f:
+    with h5py.File(path, 'w', libver=libver) as f:
         layers = layer_list(d)
         f.attrs['layer_names'] = names([l for l, _ in layers])
         f.attrs['backend'] = 'tensorflow'.encode('utf8')
@@ -98,4 +99,5 @@ if __name__ == '__main__':
     write(os.path.join(HERE, 'keras_d2_w32_v12.h5'), 2, 32, 12)
     write(os.path.join(HERE, 'keras_d2_w16_v12_cudnn.h5'), 2, 16, 12, cudnn=True, vlen_attrs=True)
     write(os.path.join(HERE, 'keras_d1_w16_v12.h5'), 1, 16, 12)
+    write(os.path.join(HERE, 'keras_d1_w16_v12_latest.h5'), 1, 16, 12, libver='latest')
     print('h5py', h5py.__version__, 'hdf5', h5py.version.hdf5_version)

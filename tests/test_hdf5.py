@@ -236,3 +236,14 @@ def test_damaged_files_raise_h5error(tmp_path):
             keras_h5.read_layers(path)
         except (hdf5.H5Error, KeyError):
             pass                                    # anything else (struct.error, IndexError, hang) fails the test
+
+
+def test_libver_latest_file():
+    """Superblock v3, version-2 object headers, link messages, version-3 attributes (h5py with libver='latest')."""
+    a = keras_h5.read_model(os.path.join(GOLDEN, 'keras_d1_w16_v12.h5'))
+    b = keras_h5.read_model(os.path.join(GOLDEN, 'keras_d1_w16_v12_latest.h5'))
+    assert list(a[1]) == list(b[1]) and set(a[0]) == set(b[0])
+    for lname in a[1]:
+        for t in a[1][lname]:
+            assert np.array_equal(a[1][lname][t], b[1][lname][t]), (lname, t)
+    assert np.array_equal(a[0]['mapping'], b[0]['mapping']) and int(b[0]['depth']) == 1
