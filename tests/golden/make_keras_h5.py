@@ -10,7 +10,6 @@ checked against the real container format rather than against its own writer.
   keras_d2_w16_v12_cudnn.h5  same tensors, encoder/decoder LSTM layers in CuDNNLSTM format (models trained on a GPU,
                              seq2seq.py:216-219), variable-length string attributes (h5py 3.x), gzip-chunked kernels
   keras_d1_w16_v12.h5        a depth-1 model (shallower-model transfer, seq2seq.py:1206-1211)
-  keras_d1_w16_v12_latest.h5 the same written with libver='latest' (superblock v3, version-2 object headers, link messages)
 """
 import os
 import sys
@@ -99,5 +98,4 @@ if __name__ == '__main__':
     write(os.path.join(HERE, 'keras_d2_w32_v12.h5'), 2, 32, 12)
     write(os.path.join(HERE, 'keras_d2_w16_v12_cudnn.h5'), 2, 16, 12, cudnn=True, vlen_attrs=True)
     write(os.path.join(HERE, 'keras_d1_w16_v12.h5'), 1, 16, 12)
-    write(os.path.join(HERE, 'keras_d1_w16_v12_latest.h5'), 1, 16, 12, libver='latest')
     print('h5py', h5py.__version__, 'hdf5', h5py.version.hdf5_version)
