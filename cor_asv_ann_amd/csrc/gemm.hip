@@ -63,6 +63,13 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
     }
     const int m0 = bm * BM, n0 = bn * BN;
     if (m0 >= g.M || bm * nbn + bn >= ((g.M + BM - 1) / BM) * nbn) return;
+    if (g.line_done) {      // every wave looks at the same flags: a uniform exit ahead of the first barrier
+        const int mlast = (m0 + BM < g.M ? m0 + BM : g.M) - 1;
+        const int l0 = m0 / g.done_group, l1 = mlast / g.done_group;
+        int alive = 0;
+        for (int l = l0 + lane; l <= l1; l += 64) alive |= g.line_done[l] == 0;
+        if (!__any(alive)) return;
+    }
 
     const int r0 = tid >> 2, kc = tid & 3;     // staging: rows r0, r0+64; floats [4kc, 4kc+4)
 

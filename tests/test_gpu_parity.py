@@ -354,3 +354,30 @@ def test_beam_chunking_under_a_memory_budget(monkeypatch):
     assert parts[0] == whole[0] and parts[1] == whole[1] and parts[2] == whole[2]
     for a, b in zip(parts[3], whole[3]):
         assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_finished_lines_are_skipped_without_changing_results():
+    """Once a line's search has ended, the step's kernels skip tiles whose lines are all finished.  With lines of very
+    different length in one batch (the short ones finish tens of iterations before the long ones) the results must be
+    the oracle's, and bit for bit those of a run without skipping (graph replay never skips: its kernel arguments are
+    fixed at capture)."""
+    cfg = ModelConfig(depth=2, width=64, voc_size=96)
+    weights = make_weights(cfg, emb_scale=14.0)
+    om = OracleModel(cfg, weights, batch_size=4)
+    long_lines, _ = make_lines(3, 60, 91, voc_size=96)
+    short_lines, _ = make_lines(40, 6, 92, voc_size=96)
+    lines = short_lines[:20] + long_lines + short_lines[20:]
+    s2s = _facade(cfg, weights, om.mapping, N=4)
+    got = s2s.correct_lines(lines, fast=False, greedy=False)
+    s2s.engine.set_option('graph', 1)
+    try:
+        plain = s2s.correct_lines(lines, fast=False, greedy=False)
+    finally:
+        s2s.engine.set_option('graph', 0)
+    assert plain[0] == got[0] and plain[1] == got[1] and plain[2] == got[2]
+    for a, b in zip(plain[3], got[3]):
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+    want = correct_lines(om, lines, fast=False, greedy=False)
+    assert got[0] == want[0]
+    for j in range(len(lines)):
+        assert abs(got[2][j] - want[2][j]) < 1e-4
