@@ -72,8 +72,8 @@ struct GemmArgs {
     SlotPtr c_out;
     SlotPtr zinit;        // LSTM: pre-activation term added to the contraction, [M][4U] interleaved (x.K + b of all steps, precomputed)
     SlotPtr gates_out;    // training: activated gates i,f,g,o, [M][4U] in the interleaved column order (or null)
-    const int* line_done; // beam decode: per-line flags; a tile whose lines are all finished is skipped (its rows are never read)
-    int done_group;       // rows per line
+    const int* nact;      // beam decode: live rows per line (0 = search finished); a tile without a live row is skipped --
+    int nact_group;       // rows per line                                   its rows are never read
     int epi_plain;        // job of an EPI_LSTM launch that takes the PLAIN epilogue (lets independent GEMMs of both kinds share a launch)
     int accumulate;       // PLAIN: C += A.B^T instead of C = (weight-gradient sums)
     int out_zeroed;       // PLAIN with split-K: the caller has already cleared the output (no memset per launch)
@@ -120,8 +120,8 @@ struct AttnArgs {
     double* apos;           // [R] sum_s a'[s]*s
     int* amax1;             // [R] max(a') == 1.0
     const int* nrows;       // optional device row count (rows >= *nrows are skipped)
-    const int* line_done;   // optional per-line flags: rows of finished lines are skipped (line = r / done_group)
-    int done_group;
+    const int* nact;        // optional live rows per line: row r is skipped unless r % nact_group < nact[r / nact_group]
+    int nact_group;
     long long u_line, u_time, enc_line, enc_time;   // element strides of u / enc by line and by position
     int* win_out;           // optional [R]: window of this step, s_lo | cnt << 16 (train step backward)
 };
@@ -138,8 +138,8 @@ struct SoftmaxArgs {
     float* out_prob;        // [R][S]
     int S;
     int* nan_flag;          // set when a row is all NaN (numpy would raise)
-    const int* line_done;   // optional per-line flags: rows of finished lines are skipped (line = r / done_group)
-    int done_group;
+    const int* nact;        // optional live rows per line: row r is skipped unless r % nact_group < nact[r / nact_group]
+    int nact_group;
 };
 void launch_softmax(const SoftmaxArgs& a, hipStream_t stream);
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs
     const int r = blockIdx.x * ATT_ROWS + wave;
     const int nrows = a.nrows ? *a.nrows : a.R;
     if (r >= nrows) return;
-    if (a.line_done && a.line_done[r / a.done_group]) return;
+    if (a.nact && r % a.nact_group >= a.nact[r / a.nact_group]) return;
     const int step = a.step_ptr ? *a.step_ptr : a.step_imm;
     const int ln = a.line ? a.line[r] : r / a.rows_per_line;
     const int T = a.T, W = a.W, C = a.C;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void softmax_kernel(const SoftmaxArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wave;
     if (r >= a.R) return;
-    if (a.line_done && a.line_done[r / a.done_group]) return;
+    if (a.nact && r % a.nact_group >= a.nact[r / a.nact_group]) return;
     const int step = a.step_ptr ? *a.step_ptr : a.step_imm;
     const int V = a.V, Vp = (V + 31) & ~31;
     const float* x = a.logits + (long long)r * Vp;

@@ -106,8 +106,8 @@ struct casv_model {
     // options
     int eos = 1;                                          // vocabulary index of '\n' (seq2seq.py:1255,1344,1402)
     bool use_graph = false;
-    const int* skip_done = nullptr;                       // beam decode: per-line finished flags handed to the step's kernels
-    int skip_group = 0;                                   // (set once some line has finished), rows per line
+    const int* skip_nact = nullptr;                       // beam decode: live rows per line, handed to the step's kernels when
+    int skip_group = 0;                                   // skipping can pay (wide beams, or a line has finished); rows per line
     Prof prof;
 
     void prof_begin(int cls, double fl, double by, hipEvent_t& a) {

@@ -351,7 +351,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
     const long long RW = (long long)R * W;
     const int* prev = m->prev.as<int>();
-    const int* done = beam ? m->skip_done : nullptr;      // set by casv_decode_beam once a line has finished
+    const int* live = beam ? m->skip_nact : nullptr;      // set by casv_decode_beam when skipping can pay
     // layer input: layer 1 takes the fed-back distribution itself (embedding folded into its weights,
     // pack_dec1), layer n > 1 the output of layer n-1 at this step
     auto xseg = [&](int n) {
@@ -368,7 +368,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
     gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W;
     gq.out = mkslot(m->wq.as<float>(), W);
     gq.step_ptr = step_ptr; gq.step_imm = step_imm;
-    gq.line_done = done; gq.done_group = m->skip_group;
+    gq.nact = live; gq.nact_group = m->skip_group;
     for (int n = 1; n < D; ++n) {
         GemmArgs g{};
         g.nseg = 2;
@@ -380,7 +380,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.c_in = mkseg(m->st_c[n].as<float>(), W, W, 0, prev);
         g.c_out = mkslot(m->st_c[n].as<float>(), W, RW, 1, 1);
         g.step_ptr = step_ptr; g.step_imm = step_imm;
-        g.line_done = done; g.done_group = m->skip_group;
+        g.nact = live; g.nact_group = m->skip_group;
         if (n == 1) {
             GemmBatch b{};
             b.g[0] = g; b.g[1] = gq; b.g[1].epi_plain = 1; b.count = 2;
@@ -397,7 +397,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         a.ctx = m->ctx.as<float>(); a.R = R; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
         a.step_ptr = step_ptr; a.step_imm = step_imm; a.apos = m->apos.as<double>(); a.amax1 = m->amax1.as<int>(); a.nrows = nullptr;
         a.u_line = (long long)T * W; a.u_time = W; a.enc_line = (long long)T * C; a.enc_time = C; a.win_out = nullptr;
-        a.line_done = done; a.done_group = m->skip_group;
+        a.nact = live; a.nact_group = m->skip_group;
         hipEvent_t ev{};
         const double win = 2.0 * m->cfg.window_width + 1;
         m->prof_begin(PC_ATTN, (double)R * win * (4.0 * W + 2.0 * C), 4.0 * R * (win * (W + C) + W + 2.0 * T + C), ev);
@@ -416,7 +416,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.c_in = mkseg(m->st_c[D].as<float>(), W, W, 0, prev);
         g.c_out = mkslot(m->st_c[D].as<float>(), W, RW, 1, 1);
         g.step_ptr = step_ptr; g.step_imm = step_imm;
-        g.line_done = done; g.done_group = m->skip_group;
+        g.nact = live; g.nact_group = m->skip_group;
         run_gemm(m, EPI_LSTM, g);
     }
     {   // tied output projection (seq2seq.py:379)
@@ -425,7 +425,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.Bt = m->E.as<float>(); g.M = R; g.N = V; g.Ktot = W;
         g.out = mkslot(m->logits.as<float>(), Vp);
         g.step_ptr = step_ptr; g.step_imm = step_imm;
-        g.line_done = done; g.done_group = m->skip_group;
+        g.nact = live; g.nact_group = m->skip_group;
         run_gemm(m, EPI_PLAIN, g);
     }
     {
@@ -433,7 +433,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         a.logits = m->logits.as<float>(); a.p_base = m->st_p.as<float>(); a.R = R; a.V = V;
         a.step_ptr = step_ptr; a.step_imm = step_imm; a.mode = mode; a.out_idx = o_idx; a.out_prob = o_prob; a.S = m->S;
         a.nan_flag = m->d_nan.as<int>();
-        a.line_done = done; a.done_group = m->skip_group;
+        a.nact = live; a.nact_group = m->skip_group;
         hipEvent_t ev{};
         m->prof_begin(PC_SOFTMAX, 4.0 * R * V, 8.0 * R * V, ev);
         launch_softmax(a, m->stream);
@@ -596,7 +596,10 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     p.threshold_in = bp->beam_threshold_in; p.rejection = bp->rejection_threshold; p.cost0 = bp->cost0; p.eos = m->eos;
     if ((long long)(S + 1) * R >= (1LL << 31)) return fail(CASV_ERR_ARG, "search too large: (S+1)*B*N overflows int32");
 
-    m->skip_done = nullptr; m->skip_group = 0;
+    // Tiles / rows without a live hypothesis are skipped by the step's kernels (their state is never read).  Worth the
+    // extra load per workgroup from the start when a line's N rows span whole tiles (beams fill up over the first
+    // steps), otherwise once a line has finished; not under graph replay, whose kernel arguments are fixed at capture.
+    m->skip_nact = (N >= 128 && !m->use_graph) ? m->b_nact.as<int>() : nullptr; m->skip_group = N;
     launch_beam_init(s, p, m->stream);
     const int* sp = m->d_step.as<int>();
     auto body = [&]() {
@@ -618,11 +621,9 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
         HIPCHK(hipMemcpyAsync(&active, m->b_active.p, 4, hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
         if (active <= 0) break;
-        // once a line has finished, the step's kernels skip tiles / rows whose lines are all finished (their state is
-        // never read again); not under graph replay, whose kernel arguments are fixed at capture
-        if (active < B && !m->use_graph) { m->skip_done = m->b_done.as<int>(); m->skip_group = N; }
+        if (active < B && !m->use_graph) m->skip_nact = m->b_nact.as<int>();
     }
-    m->skip_done = nullptr; m->skip_group = 0;
+    m->skip_nact = nullptr; m->skip_group = 0;
     BeamOut o{};
     o.idx = m->bo_idx.as<int>(); o.prob = m->bo_prob.as<float>(); o.len = m->bo_len.as<int>(); o.score = m->bo_score.as<double>();
     o.rejpos = m->bo_rej.as<int>(); o.align = out_align ? m->bo_align.as<float>() : nullptr; o.n_found = m->bo_found.as<int>();

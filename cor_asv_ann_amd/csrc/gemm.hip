@@ -63,11 +63,11 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
     }
     const int m0 = bm * BM, n0 = bn * BN;
     if (m0 >= g.M || bm * nbn + bn >= ((g.M + BM - 1) / BM) * nbn) return;
-    if (g.line_done) {      // every wave looks at the same flags: a uniform exit ahead of the first barrier
+    if (g.nact) {           // every wave looks at the same counts: a uniform exit ahead of the first barrier
         const int mlast = (m0 + BM < g.M ? m0 + BM : g.M) - 1;
-        const int l0 = m0 / g.done_group, l1 = mlast / g.done_group;
+        const int l0 = m0 / g.nact_group, l1 = mlast / g.nact_group;
         int alive = 0;
-        for (int l = l0 + lane; l <= l1; l += 64) alive |= g.line_done[l] == 0;
+        for (int l = l0 + lane; l <= l1; l += 64) alive |= g.nact[l] > (l == l0 ? m0 - l0 * g.nact_group : 0);
         if (!__any(alive)) return;
     }
 

@@ -31,11 +31,11 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
     const int bn = blockIdx.x % nbn, bm = blockIdx.x / nbn;      // consecutive workgroups (= different XCDs) take different B panels
     const int m0 = bm * SBM, n0 = bn * SBN;
     if (m0 >= g.M) return;
-    if (g.line_done) {      // every wave looks at the same flags: a uniform exit ahead of the first barrier
+    if (g.nact) {           // every wave looks at the same counts: a uniform exit ahead of the first barrier
         const int mlast = (m0 + SBM < g.M ? m0 + SBM : g.M) - 1;
-        const int l0 = m0 / g.done_group, l1 = mlast / g.done_group;
+        const int l0 = m0 / g.nact_group, l1 = mlast / g.nact_group;
         int alive = 0;
-        for (int l = l0 + lane; l <= l1; l += 64) alive |= g.line_done[l] == 0;
+        for (int l = l0 + lane; l <= l1; l += 64) alive |= g.nact[l] > (l == l0 ? m0 - l0 * g.nact_group : 0);
         if (!__any(alive)) return;
     }
 

@@ -356,18 +356,19 @@ def test_beam_chunking_under_a_memory_budget(monkeypatch):
         assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-def test_finished_lines_are_skipped_without_changing_results():
-    """Once a line's search has ended, the step's kernels skip tiles whose lines are all finished.  With lines of very
-    different length in one batch (the short ones finish tens of iterations before the long ones) the results must be
-    the oracle's, and bit for bit those of a run without skipping (graph replay never skips: its kernel arguments are
-    fixed at capture)."""
+@pytest.mark.parametrize('N,nshort,nlong', [(4, 40, 3), (128, 4, 2)])
+def test_dead_rows_are_skipped_without_changing_results(N, nshort, nlong):
+    """The step's kernels skip tiles / rows without a live hypothesis: lines whose search has ended (N = 4: the short
+    lines finish tens of iterations before the long ones) and, for wide beams (N = 128 rows per line = whole tiles), the
+    rows a beam has not filled yet.  The results must be the oracle's, and bit for bit those of a run without skipping
+    (graph replay never skips: its kernel arguments are fixed at capture)."""
     cfg = ModelConfig(depth=2, width=64, voc_size=96)
     weights = make_weights(cfg, emb_scale=14.0)
-    om = OracleModel(cfg, weights, batch_size=4)
-    long_lines, _ = make_lines(3, 60, 91, voc_size=96)
-    short_lines, _ = make_lines(40, 6, 92, voc_size=96)
-    lines = short_lines[:20] + long_lines + short_lines[20:]
-    s2s = _facade(cfg, weights, om.mapping, N=4)
+    om = OracleModel(cfg, weights, batch_size=N)
+    long_lines, _ = make_lines(nlong, 60 if N == 4 else 24, 91, voc_size=96)
+    short_lines, _ = make_lines(nshort, 6, 92, voc_size=96)
+    lines = short_lines[:nshort // 2] + long_lines + short_lines[nshort // 2:]
+    s2s = _facade(cfg, weights, om.mapping, N=N)
     got = s2s.correct_lines(lines, fast=False, greedy=False)
     s2s.engine.set_option('graph', 1)
     try:
