@@ -10,11 +10,12 @@
 // tile holds all four gates of 32 units and a wave's four 32x32 accumulator tiles hold, register for
 // register, the i/f/c/o pre-activations of the same (row, unit).
 //
-// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves, each wave 32 rows x 128 columns
+// Tiling: 128x128 block tile, BK = 16, 256 threads = 4 waves, each wave 32 rows x 128 columns
 // (4 x v_mfma_f32_32x32x2_f32 accumulators, exact fp32 = a k-ordered fmaf chain).  Operands are staged
-// K-contiguous in LDS with a +4-float row pad (144-B rows: ds_read_b128 is conflict-free for the 16-lane
+// K-contiguous in LDS with a +4-float row pad (80-B rows: ds_read_b128 is conflict-free for its 16-lane
 // groups) and double-buffered; each lane reads four consecutive k per ds_read_b128 and feeds them to
 // four MFMAs (the k order inside a tile is permuted identically for A and B, which a sum allows).
+// Small launches take the 32x128-tile variant of gemm_skinny.hip instead (plan_gemm; same values bit for bit).
 #include "common.h"
 
 namespace casv {
