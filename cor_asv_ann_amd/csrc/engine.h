@@ -79,6 +79,7 @@ struct casv_model {
     casv_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_inputs = nullptr;                       // marks the point where host input buffers have been consumed
     int W = 0, V = 0, Vp = 0, C = 0, D = 0;
     std::map<std::string, std::vector<float>> host;      // Keras-layout tensors
     std::map<std::string, size_t> expect;                // name -> element count

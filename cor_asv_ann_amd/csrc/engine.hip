@@ -49,6 +49,8 @@ extern "C" int casv_model_create(const casv_config* cfg, int device_id, casv_mod
     m->expect = expected_shapes(*cfg);
     hipError_t e = hipStreamCreate(&m->stream);
     if (e != hipSuccess) { delete m; return fail(CASV_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    e = hipEventCreateWithFlags(&m->ev_inputs, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipStreamDestroy(m->stream); delete m; return fail(CASV_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     m->enc.resize(m->D + 1); m->dec.resize(m->D + 1); m->st_h.resize(m->D + 1); m->st_c.resize(m->D + 1);
     *out = m;
     return CASV_OK;
@@ -73,6 +75,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     for (auto& b : m->st_c) b.release();
     (void)casv_train_release(m);
     for (auto e : m->prof.pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(m->ev_inputs);
     (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -201,6 +204,10 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
     HIPCHK(hipMemcpyAsync(m->d_val.p, val, BT * A * 4, hipMemcpyHostToDevice, m->stream));
     if (src_rej) HIPCHK(hipMemcpyAsync(m->d_srcrej.p, src_rej, BT * 4, hipMemcpyHostToDevice, m->stream));
     else HIPCHK(hipMemsetAsync(m->d_srcrej.p, 0xff, BT * 4, m->stream));
+    // The caller owns idx / val / src_rej and may release them as soon as this function returns (the encoder itself
+    // runs asynchronously): wait until the three copies have left the host buffers.
+    HIPCHK(hipEventRecord(m->ev_inputs, m->stream));
+    HIPCHK(hipEventSynchronize(m->ev_inputs));
     m->B = B; m->T = T; m->A = A;
 
     hipEvent_t ev{};

@@ -193,10 +193,11 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
     if (ntiles > 3) load_tile(g1, 3);
     __syncthreads();
     if (ntiles > 0) read_frags(f0, 0);
+    // The first steady-state step stores tile 2 into LDS buffer 0: every wave must have taken its fragments of tile 0
+    // out of it first.  (Without this barrier only the latency of the tile-2 global loads kept a fast wave's store
+    // behind a slow wave's read -- not enough once other kernels share the CU.)
+    __syncthreads();
 
-#ifndef CASV_EXP
-#define CASV_EXP 0
-#endif
     // Steady state (tiles kt+1..kt+4 exist, no conditionals): while the 32 MFMAs of tile kt issue from FC,
     //   LDS[kt&1] <- G (tile kt+2, requested two steps ago; the buffer's old content, tile kt, sits in FC)
     //   G <- global tile kt+4 ;  FN <- LDS[(kt+1)&1]
@@ -208,14 +209,12 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
         load_tile(G, (KT) + 4);                                                           \
         read_frags(FN, ((KT) + 1) & 1);                                                   \
         mma(FC);                                                                          \
-        if (!(CASV_EXP & 16)) {                                                           \
-            _Pragma("unroll") for (int q_ = 0; q_ < 18; ++q_) {                           \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                        \
-                __builtin_amdgcn_sched_group_barrier(0x320, 1, 0);                        \
-            }                                                                             \
-            __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);                           \
+        _Pragma("unroll") for (int q_ = 0; q_ < 18; ++q_) {                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                            \
+            __builtin_amdgcn_sched_group_barrier(0x320, 1, 0);                            \
         }                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);                               \
         __builtin_amdgcn_sched_barrier(0);   /* keep all 32 MFMAs in front of the barrier: by then the LDS ops have landed */ \
         __syncthreads();                                                                  \
     }
