@@ -563,9 +563,18 @@ class Sequence2Sequence(object):
                         line = ''.join(chunk_[0][0] if chunk_ else '' for chunk_ in input_line)
                     else:
                         line = input_line
-                    item = (line, [1.0] * len(line), 0, np.eye(len(line)).tolist() if alignments else [])
+                    item = (line, [1.0] * len(line), 0, self._identity_alignment(len(line)) if alignments else [])
                 results.append(item)
         return self._finish(lines, results)
+
+    def _identity_alignment(self, n):
+        """`np.eye(n).tolist()` of the beam fallback (seq2seq.py:834).  The rows are built once per length and
+        shared between the lines of that length (a fresh outer list per line): read-only in every caller."""
+        cache = self.__dict__.setdefault('_eye_cache', {})
+        rows = cache.get(n)
+        if rows is None:
+            rows = cache[n] = np.eye(n).tolist()
+        return list(rows)
 
     @staticmethod
     def _finish(lines, results):
