@@ -145,7 +145,6 @@ void launch_softmax(const SoftmaxArgs& a, hipStream_t stream);
 
 void launch_embed_sparse(const float* E, const int* idx, const float* val, float* x0,
                          int rows, int A, int V, int W, hipStream_t stream);
-void launch_fill_prev(int* prev, int R, int step_imm, const int* step_ptr, hipStream_t stream);
 void launch_advance_step(int* step_ptr, hipStream_t stream);
 void launch_scatter_rows(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,
                          int dst_row_mul, hipStream_t stream);

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs
     const int step = a.step_ptr ? *a.step_ptr : a.step_imm;
     const int ln = a.line ? a.line[r] : r / a.rows_per_line;
     const int T = a.T, W = a.W, C = a.C;
-    const float* ap = a.a_base + (long long)a.prev[r] * T;
+    const float* ap = a.a_base + (a.prev ? (long long)a.prev[r] : (long long)step * a.R + r) * T;
     float* aout = const_cast<float*>(a.a_base) + ((long long)(step + 1) * a.R + r) * T;
 
     double acc = 0.0;
@@ -222,15 +222,6 @@ __global__ __launch_bounds__(128) void embed_sparse_kernel(const float* __restri
 void launch_embed_sparse(const float* E, const int* idx, const float* val, float* x0, int rows, int A,
                          int V, int W, hipStream_t stream) {
     hipLaunchKernelGGL(embed_sparse_kernel, dim3(rows), dim3(128), 0, stream, E, idx, val, x0, rows, A, V, W);
-}
-
-__global__ void fill_prev_kernel(int* prev, int R, int step_imm, const int* step_ptr) {
-    const int step = step_ptr ? *step_ptr : step_imm;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < R) prev[r] = step * R + r;
-}
-void launch_fill_prev(int* prev, int R, int step_imm, const int* step_ptr, hipStream_t stream) {
-    hipLaunchKernelGGL(fill_prev_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, prev, R, step_imm, step_ptr);
 }
 
 __global__ void advance_step_kernel(int* step_ptr) { *step_ptr += 1; }

@@ -357,7 +357,12 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
                         int* o_idx, float* o_prob, const int* step_ptr, int step_imm) {
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
     const long long RW = (long long)R * W;
-    const int* prev = m->prev.as<int>();
+    // previous-step rows of the state stores: the beam gathers its parents' expansions through `prev`; without a beam
+    // row r of step t simply continues row r of step t-1 (slot arithmetic, no index array and no kernel to fill one)
+    const int* prev = beam ? m->prev.as<int>() : nullptr;
+    auto hseg = [&](float* base, int off) {
+        return beam ? mkseg(base, W, W, off, prev) : mkseg(base, W, W, off, nullptr, RW, 1, 0);
+    };
     const int* live = beam ? m->skip_nact : nullptr;      // set by casv_decode_beam when skipping can pay
     // layer input: layer 1 takes the fed-back distribution itself (embedding folded into its weights,
     // pack_dec1), layer n > 1 the output of layer n-1 at this step
@@ -371,7 +376,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
     // attention query of this step: h_{t-1} . W_a + b_UW (attention.py:539) -- depends only on the previous step, so it
     // shares the launch of layer 1 (a job with the plain epilogue) instead of waiting behind the lower layers
     GemmArgs gq{};
-    gq.nseg = 1; gq.a[0] = mkseg(m->st_h[D].as<float>(), W, W, 0, prev);
+    gq.nseg = 1; gq.a[0] = hseg(m->st_h[D].as<float>(), 0);
     gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W;
     gq.out = mkslot(m->wq.as<float>(), W);
     gq.step_ptr = step_ptr; gq.step_imm = step_imm;
@@ -380,11 +385,11 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         GemmArgs g{};
         g.nseg = 2;
         g.a[0] = xseg(n);
-        g.a[1] = mkseg(m->st_h[n].as<float>(), W, W, xwidth(n), prev);
+        g.a[1] = hseg(m->st_h[n].as<float>(), xwidth(n));
         g.Bt = m->dec[n].wt.as<float>(); g.bias = m->dec[n].bias.as<float>();
         g.M = R; g.N = 4 * W; g.Ktot = xwidth(n) + W;
         g.out = mkslot(m->st_h[n].as<float>(), W, RW, 1, 1);
-        g.c_in = mkseg(m->st_c[n].as<float>(), W, W, 0, prev);
+        g.c_in = hseg(m->st_c[n].as<float>(), 0);
         g.c_out = mkslot(m->st_c[n].as<float>(), W, RW, 1, 1);
         g.step_ptr = step_ptr; g.step_imm = step_imm;
         g.nact = live; g.nact_group = m->skip_group;
@@ -416,11 +421,11 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.nseg = 3;
         g.a[0] = xseg(D);
         g.a[1] = mkseg(m->ctx.as<float>(), C, C, xwidth(D));
-        g.a[2] = mkseg(m->st_h[D].as<float>(), W, W, xwidth(D) + C, prev);
+        g.a[2] = hseg(m->st_h[D].as<float>(), xwidth(D) + C);
         g.Bt = m->dec[D].wt.as<float>(); g.bias = m->dec[D].bias.as<float>();
         g.M = R; g.N = 4 * W; g.Ktot = xwidth(D) + C + W;
         g.out = mkslot(m->st_h[D].as<float>(), W, RW, 1, 1);
-        g.c_in = mkseg(m->st_c[D].as<float>(), W, W, 0, prev);
+        g.c_in = hseg(m->st_c[D].as<float>(), 0);
         g.c_out = mkslot(m->st_c[D].as<float>(), W, RW, 1, 1);
         g.step_ptr = step_ptr; g.step_imm = step_imm;
         g.nact = live; g.nact_group = m->skip_group;
@@ -468,7 +473,6 @@ extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, 
         HIPCHK(hipMemcpyAsync(m->st_c[n].p, states_in + (size_t)(2 * n - 1) * R * W, (size_t)R * W * 4, hipMemcpyHostToDevice, m->stream));
     }
     HIPCHK(hipMemcpyAsync(m->st_a.p, a_in, (size_t)R * T * 4, hipMemcpyHostToDevice, m->stream));
-    launch_fill_prev(m->prev.as<int>(), R, 0, nullptr, m->stream);
     launch_step(m, false, -1, m->d_line.as<int>(), 1, nullptr, nullptr, nullptr, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -528,7 +532,6 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     {
         StepRunner runner(m);
         if (int rc = runner.run(S, [&]() {
-                launch_fill_prev(m->prev.as<int>(), B, 0, sp, m->stream);
                 launch_step(m, false, mode, nullptr, 1, m->o_idx.as<int>(), m->o_prob.as<float>(), sp, 0);
             })) return rc;
     }

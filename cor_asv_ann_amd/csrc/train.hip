@@ -446,10 +446,9 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         const float* hprev = t == 0 ? h0t : top.hs + (long long)(t - 1) * B * W;
         float* wq = ts->WQ.as<float>() + (long long)t * B * W;
         { GemmArgs g = plain_gemm(hprev, W, B, W, ts->W_(ts->iWaT), W, ts->W_(ts->ibUW), wq, W); g.out_zeroed = 1; run_gemm(m, EPI_PLAIN, g); }
-        launch_fill_prev(ts->prev.as<int>(), B, t, nullptr, st);
         AttnArgs a{};
         a.wq = wq; a.u = ts->u.as<float>(); a.enc = enc_out; a.va = ts->W_(ts->iva); a.bv = ts->W_(ts->ibv);
-        a.a_base = ts->Ast.as<float>(); a.prev = ts->prev.as<int>(); a.line = nullptr; a.rows_per_line = 1;
+        a.a_base = ts->Ast.as<float>(); a.prev = nullptr; a.line = nullptr; a.rows_per_line = 1;
         a.ctx = ts->CTX.as<float>(); a.R = B; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
         a.step_imm = t; a.step_ptr = nullptr; a.apos = nullptr; a.amax1 = nullptr; a.nrows = nullptr;
         a.u_line = W; a.u_time = (long long)B * W; a.enc_line = C; a.enc_time = (long long)B * C;
