@@ -255,8 +255,8 @@ struct LayerBwd {
     const float* x; long long ldx; float* dX; long long ld_dx; int dx_accumulate;
 };
 
-// pointwise part of processing index k (gate derivatives -> dZ) and the data GEMM that carries dZ to the previous step
-static GemmArgs layer_backward_step(casv_model* m, const LayerBwd& a, int k) {
+// pointwise part of processing index k (gate derivatives -> dZ)
+static LstmBwdArgs layer_backward_pointwise(casv_model* m, const LayerBwd& a, int k) {
     TrainState* ts = m->train;
     TLayer& l = *a.l;
     const int W = m->W, B = ts->B;
@@ -270,8 +270,16 @@ static GemmArgs layer_backward_step(casv_model* m, const LayerBwd& a, int k) {
     if (k > 0) { p.c_prev = l.Cs.as<float>() + (long long)time_of(l, k - 1) * B * W; p.ld_cprev = W; }
     else { p.c_prev = a.c0; p.ld_cprev = W; }
     p.dc = a.dc; p.dz = l.Z.as<float>() + (long long)t * B * 4 * W; p.rows = B; p.W = W;
-    launch_lstm_bwd(p, m->stream);
-    GemmArgs g = plain_gemm(p.dz, 4 * W, B, 4 * W, l.wrT.as<float>(), l.kr, nullptr, l.dRec.as<float>() + (long long)t * B * W, W);
+    return p;
+}
+// ... and the data GEMM that carries dZ to the previous step
+static GemmArgs layer_backward_gemm(casv_model* m, const LayerBwd& a, int k) {
+    TrainState* ts = m->train;
+    TLayer& l = *a.l;
+    const int W = m->W, B = ts->B;
+    const int t = time_of(l, k);
+    GemmArgs g = plain_gemm(l.Z.as<float>() + (long long)t * B * 4 * W, 4 * W, B, 4 * W, l.wrT.as<float>(), l.kr, nullptr,
+                            l.dRec.as<float>() + (long long)t * B * W, W);
     g.out_zeroed = 1;           // casv_train_step clears dRec once per step
     return g;
 }
@@ -313,10 +321,14 @@ static int layers_backward(casv_model* m, const LayerBwd* a, int count) {
     }
     for (int i = 0; i < maxlen; ++i) {
         GemmBatch b{};
+        LstmBwdBatch pw{};
         for (int j = 0; j < count; ++j) {
             const int k = a[j].l->len - 1 - i;
-            if (k >= 0) b.g[b.count++] = layer_backward_step(m, a[j], k);
+            if (k < 0) continue;
+            pw.a[pw.count++] = layer_backward_pointwise(m, a[j], k);
+            b.g[b.count++] = layer_backward_gemm(m, a[j], k);
         }
+        launch_lstm_bwd_batch(pw, m->stream);
         run_gemm_batch(m, EPI_PLAIN, b);
     }
     for (int j = 0; j < count; ++j)

@@ -27,7 +27,9 @@ struct LstmBwdArgs {
     float* dz;                                               // [rows][4W] interleaved
     int rows, W;
 };
+struct LstmBwdBatch { LstmBwdArgs a[2]; int count; };     // independent layers walking backwards in lockstep: one launch
 void launch_lstm_bwd(const LstmBwdArgs& p, hipStream_t st);
+void launch_lstm_bwd_batch(const LstmBwdBatch& b, hipStream_t st);
 
 struct AttnBwdArgs {
     const float* dxh; long long ld_dxh; int ctx_off;         // dL/dx of the cell input; context part at ctx_off

@@ -163,7 +163,8 @@ void launch_softmax_ce(float* logits, const int* target, const float* weight, in
 
 // ---- LSTM cell backward, pointwise part ----
 // dh = a*mask_a + b + c ; gates/dz in the interleaved column order of the fused weight
-__global__ void lstm_bwd_kernel(const LstmBwdArgs p) {
+__global__ void lstm_bwd_kernel(const LstmBwdBatch batch) {
+    const LstmBwdArgs& p = batch.a[blockIdx.y];
     const int W = p.W;
     const long long n = (long long)p.rows * W;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -186,9 +187,16 @@ __global__ void lstm_bwd_kernel(const LstmBwdArgs p) {
         p.dc[r * W + u] = dct * fg;
     }
 }
+void launch_lstm_bwd_batch(const LstmBwdBatch& b, hipStream_t st) {
+    if (b.count < 1) return;
+    long long n = 0;
+    for (int j = 0; j < b.count; ++j) n = std::max(n, (long long)b.a[j].rows * b.a[j].W);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096), b.count), dim3(256), 0, st, b);
+}
 void launch_lstm_bwd(const LstmBwdArgs& p, hipStream_t st) {
-    const long long n = (long long)p.rows * p.W;
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, p);
+    LstmBwdBatch b{};
+    b.a[0] = p; b.count = 1;
+    launch_lstm_bwd_batch(b, st);
 }
 
 // ---- attention backward for one decoder time step (oracle/train.py; no gradient through the window
