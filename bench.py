@@ -31,7 +31,8 @@ LINE_SEED = 103
 # 128/sqrt(W) gives a peaky distribution (median p = 0.8) and the full 8-hypotheses x 2T-steps search the
 # metric is about ("Synthetic weights").
 EMB_SCALE = 128.0
-PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_HBM_BYTES_PER_S = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def make_model(device):
@@ -58,6 +59,15 @@ def survey_flop_per_char():
     f_row = 2 * V * W + (d - 1) * 16 * W * W + 2 * W * W + K * (4 * W + 2 * C) + 8 * W * (2 * W + C) + 2 * W * V
     f_enc = T * (32 * W * W + (24 * W * W if d >= 2 else 0) + 16 * W * W * max(d - 2, 0) + 2 * C * W)
     return (f_enc + N * 2 * T * f_row) / float(LENGTH)
+
+
+def survey_hbm_bytes_per_char():
+    """Q = Q_enc + N*S*Q_row per line (per-beam state in HBM, weights on chip), per corrected character."""
+    W, V, d, K, T, N = WIDTH, VOC, DEPTH, 11, LENGTH + 1, BEAM_N
+    C = 2 * W if d == 1 else W
+    q_row = 4 * (4 * d * W + K * (W + C) + 2 * V + 2 * T)
+    q_enc = 4 * T * (1 + 2 * 2 * W + 2 * W * max(d - 2, 0) + C + W)
+    return (q_enc + N * 2 * T * q_row) / float(LENGTH)
 
 
 def cpu_baseline(cfg, weights, lines, budget_s=20.0):
@@ -244,7 +254,10 @@ def main():
                          # the whole path priced with SURVEY.md section 8(d)'s algorithmic FLOP per corrected character
                          'whole_path': {'flop_per_char': survey_flop_per_char(),
                                         'achieved': chars / elapsed * survey_flop_per_char() / 1e12 / world,
-                                        'frac': chars / elapsed * survey_flop_per_char() / 1e12 / world / PEAK_F32_MFMA_TFLOPS}},
+                                        'frac': chars / elapsed * survey_flop_per_char() / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
+                                        # the other roofline of SURVEY 8(d): not the binding one at fp32 (AI = 262 FLOP/B)
+                                        'hbm_bytes_per_char': survey_hbm_bytes_per_char(),
+                                        'hbm_frac': chars / elapsed * survey_hbm_bytes_per_char() / world / PEAK_HBM_BYTES_PER_S}},
             'kernel_ms_per_step': {k: v['ms'] for k, v in others.items()},     # from one extra untimed step
         }
         if world == 1 and not args.no_cpu_baseline:
