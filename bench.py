@@ -36,7 +36,7 @@ PEAK_HBM_BYTES_PER_S = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def make_model(device):
-    from oracle.weights import ModelConfig, make_weights, make_vocabulary
+    from cor_asv_ann_amd.synthetic import ModelConfig, make_weights, make_vocabulary
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
     cfg = ModelConfig(depth=DEPTH, width=WIDTH, voc_size=VOC)
     weights = make_weights(cfg, emb_scale=EMB_SCALE)
@@ -97,7 +97,7 @@ def cpu_baseline(cfg, weights, lines, budget_s=20.0):
 def train_bench(args):
     """BASELINE configs[3]: depth 4, width 512, teacher-forced train step (forward + backward + clip + Adam) on 512
     lines of 100 characters (targets = sources with 5 % substitutions), dropout 0.2.  One GPU."""
-    from oracle.weights import ModelConfig, make_weights, make_lines
+    from cor_asv_ann_amd.synthetic import ModelConfig, make_weights, make_lines
     from cor_asv_ann_amd.engine import HipEngine
     B = 512
     cfg = ModelConfig(depth=DEPTH, width=WIDTH, voc_size=VOC)
@@ -176,7 +176,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from oracle.weights import make_lines
+    from cor_asv_ann_amd.synthetic import make_lines
     from cor_asv_ann_amd import sharding
     s2s, cfg, weights = make_model(local_rank)
     # weak scaling: the global job is world x 1024 lines, rank r decodes lines [r*1024, (r+1)*1024)
