@@ -712,13 +712,11 @@ class Sequence2Sequence(object):
 
     @staticmethod
     def _is_bad_pair(source_text, target_text):
-        """Training filter for hopeless OCR lines.  The reference delegates to
-        `Alignment.is_bad()` (lib/alignment.py:160-163, out of scope here); this stand-in uses the
-        standard-library matcher ratio with the same intent."""
+        """Training filter for hopeless OCR lines: the criterion of `Alignment.is_bad()` (lib/alignment.py:160-163) --
+        difflib's quick similarity bound below one half on a source line of more than 5 characters."""
         import difflib
-        if not source_text or not target_text:
-            return True
-        return difflib.SequenceMatcher(a=source_text, b=target_text, autojunk=False).ratio() < 0.5
+        matcher = difflib.SequenceMatcher(isjunk=None, a=source_text, b=target_text, autojunk=False)
+        return bool(matcher.quick_ratio() < 0.5 and len(source_text) > 5)
 
     def evaluate(self, filenames, fast=False, normalization='historic_latin', charmap=None, gt_level=1,
                  confusion=10, histogram=True):

@@ -199,3 +199,39 @@ def test_evaluate_uses_the_reference_metrics(tmp_path, monkeypatch):
     # 3 lines x (origin, greedy, beamed) x (characters, words); the padding line of the last batch is skipped
     assert len(calls) == 18 and all(c[2] == 'NFC' and c[3] == 2 for c in calls)
     assert ('abc\n', 'abd\n', 'NFC', 2) in calls and (('abc',), ('abd',), 'NFC', 2) in calls
+
+
+def test_gen_lines_pickle_formats_and_bad_line_filter(tmp_path):
+    """The three pickled source forms of seq2seq.py:947-961 (plain string, probability line, confusion network), the
+    missing-newline repair (:962-965), NFC normalisation (:979-980) and the training filter (:982-989)."""
+    records = [
+        ('abc\n', 'abd\n'),
+        ([('a', 0.9), ('b', 0.8), ('\n', 1.0)], 'ab\n'),
+        ([[('a', 0.6), ('o', 0.4)], [('b', 1.0)], [('\n', 1.0)]], 'ab\n'),
+        ([[('x', 1.0)]], 'x\n'),                      # no trailing newline: replaced by a bare end-of-line
+        ('', '\n'),
+    ]
+    pkl = tmp_path / 'a.pkl'
+    with open(pkl, 'wb') as f:
+        pickle.dump(records, f)
+    s2s = Sequence2Sequence()
+    s2s.batch_size = 8
+    (src, conf, tgt, names), = list(s2s.gen_lines([str(pkl)], repeat=False))
+    assert src[:5] == ['abc\n', 'ab\n', 'ab\n', '\n', '\n'] and tgt[:5] == ['abd\n', 'ab\n', 'ab\n', 'x\n', '\n']
+    assert conf[1] == [0.9, 0.8, 1.0] and conf[2] == records[2][0] and conf[3] == [[('\n', 1.0)]] and conf[4] == [[('\n', 1.0)]]
+    assert src[5:] == ['', '', ''] and conf[5:] == [[], [], []] and names[5:] == [None, None, None]
+    # NFC: decomposed input comes out composed
+    tsv = tmp_path / 'b.tsv'
+    tsv.write_text('äb\täb\n')
+    (src, _, tgt, _), = list(s2s.gen_lines([str(tsv)], repeat=False))
+    assert src[0] == 'äb\n' and tgt[0] == 'äb\n'
+    # training filter = Alignment.is_bad (lib/alignment.py:160-163): hopeless pairs are dropped only when training
+    assert Sequence2Sequence._is_bad_pair('qwertzuiop\n', 'asdfghjkl\n')
+    assert not Sequence2Sequence._is_bad_pair('qwert', 'asdfg')               # short lines are never dropped
+    assert not Sequence2Sequence._is_bad_pair('the quick brown\n', 'the quick brovvn\n')
+    bad = tmp_path / 'c.tsv'
+    bad.write_text('qwertzuiop\tasdfghjkl\ngood line\tgood lime\n')
+    (src, _, _, _), = list(s2s.gen_lines([str(bad)], repeat=False, train=True))
+    assert src[0] == 'good line\n' and src[1] == ''
+    (src, _, _, _), = list(s2s.gen_lines([str(bad)], repeat=False, train=False))
+    assert src[:2] == ['qwertzuiop\n', 'good line\n']
