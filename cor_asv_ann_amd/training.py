@@ -5,6 +5,8 @@ import signal
 
 import numpy as np
 
+from . import keras_h5
+
 
 def batch_to_indices(s2s, lines_source, lines_target, lines_conf):
     """The arrays of vectorize_lines (seq2seq.py:1020-1119) in index form: encoder (idx, val) (B,T,A),
@@ -103,7 +105,8 @@ def train_files(s2s, filenames, val_filenames=None):
             if nan or not np.isfinite(val_loss):
                 break
             weights = engine.train_weights()
-            np.savez('model.ckpt.weights-%02d-%.2f.npz' % (epoch + 1, val_loss), **weights)   # ModelCheckpoint
+            # ModelCheckpoint("model.ckpt.weights-{epoch:02d}-{val_loss:.2f}.h5", save_weights_only=True), seq2seq.py:621-622
+            keras_h5.write_model('model.ckpt.weights-%02d-%.2f.h5' % (epoch + 1, val_loss), s2s._config_dict(), weights)
             if val_loss < best:
                 best, best_weights, wait = val_loss, weights, 0
             else:

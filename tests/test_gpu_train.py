@@ -94,8 +94,18 @@ def test_facade_train_copy_task(tmp_path, monkeypatch):
     fast = s2s.correct_lines(test, fast=True, greedy=True)
     wfast = correct_lines(om, test, fast=True, greedy=True)
     assert fast[0] == wfast[0]
-    s2s.save(str(tmp_path / 'm.npz'))
+    s2s.save(str(tmp_path / 'm.h5'))                         # the reference's container
     other = Sequence2Sequence()
-    other.load_config(str(tmp_path / 'm.npz')); other.configure(); other.load_weights(str(tmp_path / 'm.npz'))
+    other.load_config(str(tmp_path / 'm.h5')); other.configure(); other.load_weights(str(tmp_path / 'm.h5'))
     other.batch_size = 4
     assert other.correct_lines(test, fast=True, greedy=True)[0] == fast[0]
+    # per-epoch checkpoints in the reference's naming and container (seq2seq.py:621-622); the best one is what train() kept
+    import glob
+    from cor_asv_ann_amd import hdf5
+    ckpts = sorted(glob.glob(str(tmp_path / 'model.ckpt.weights-*.h5')))
+    assert len(ckpts) == len([h for h in hist if np.isfinite(h['val_loss'])]) and all(hdf5.is_hdf5(c) for c in ckpts)
+    best = min(range(len(hist)), key=lambda i: hist[i]['val_loss'])
+    third = Sequence2Sequence()
+    third.load_config(ckpts[best]); third.configure(); third.load_weights(ckpts[best])
+    for k, v in s2s.get_weights().items():
+        assert np.array_equal(third.get_weights()[k], v), k
