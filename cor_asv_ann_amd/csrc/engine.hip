@@ -541,12 +541,20 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     int nanflag = 0;
     HIPCHK(hipMemcpyAsync(&nanflag, m->d_nan.p, 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    if (out_len)
-        for (int b = 0; b < B; ++b) {
-            int len = S;
-            if (mode == 1) for (int s = 0; s < S; ++s) if (out_idx[(size_t)b * S + s] == m->eos) { len = s + 1; break; }
-            out_len[b] = len;
-        }
+    // mode 1 stops a line at its end-of-line character (seq2seq.py:1344); np.nanargmax raises only if an all-NaN row
+    // turns up BEFORE that (the device marks such a step with a NaN probability) -- rows keep stepping in lockstep
+    // after their line has ended, and what they produce there is nobody's business
+    bool nan_before_end = false;
+    for (int b = 0; b < B; ++b) {
+        int len = S;
+        if (mode == 1)
+            for (int s = 0; s < S; ++s) {
+                const float pr = out_prob[(size_t)b * S + s];
+                if (pr != pr) { nan_before_end = true; len = s + 1; break; }
+                if (out_idx[(size_t)b * S + s] == m->eos) { len = s + 1; break; }
+            }
+        if (out_len) out_len[b] = len;
+    }
     if (out_align) {   // store_a slot s+1 row b -> (b, s, :)
         for (int s = 0; s < S; ++s)
             HIPCHK(hipMemcpy2DAsync(out_align + (size_t)s * T, (size_t)S * T * 4, m->st_a.as<float>() + (size_t)(s + 1) * B * T,
@@ -554,7 +562,8 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
         HIPCHK(hipStreamSynchronize(m->stream));
     }
     if (m->prof.on) m->prof.collect();
-    if (nanflag && mode == 1) return fail(CASV_ERR_NAN, "All-NaN slice encountered");
+    (void)nanflag;
+    if (nan_before_end && mode == 1) return fail(CASV_ERR_NAN, "All-NaN slice encountered");
     return CASV_OK;
 }
 

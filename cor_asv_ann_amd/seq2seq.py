@@ -527,15 +527,23 @@ class Sequence2Sequence(object):
         eng = self._require_engine()
         idx, val, _ = self._sparse_lines(lines, conf)
         B, T = idx.shape[:2]
-        if fast or greedy:
-            eng.encode(idx, val)
+        if T == 0:                  # nothing but padding lines
+            return self._finish(lines, [('', [], 0, []) for _ in range(B)])
         if fast:
+            eng.encode(idx, val)
             gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=alignments)
             nonpad = (idx >= 0).any(axis=(1, 2))
             return self._greedy_results(gi, gp, ga, nonpad)
+        # the per-line modes never decode the empty padding lines of a partial batch (seq2seq.py:815-816) -- an
+        # all-zero input row would also trip the greedy mode's NaN rule for the whole batch
+        live = [j for j, line in enumerate(lines) if line]
         if greedy:
-            results = self._sequence_greedy_results(eng, B)
-            return self._finish(lines, [r if lines[j] else ('', [], 0, []) for j, r in enumerate(results)])
+            results = [('', [], 0, []) for _ in range(B)]
+            if live:
+                eng.encode(idx[live], val[live])
+                for j, r in zip(live, self._sequence_greedy_results(eng, len(live))):
+                    results[j] = r
+            return self._finish(lines, results)
         # The search keeps every expansion's state on the device (nothing is recomputed, nothing crosses to the host):
         # S x (lines x N) rows of h, c per layer, scores and alignments.  Large beams (the reference's default
         # batch_size = 256 hypotheses per step) are therefore decoded in chunks of lines that fit a memory budget;
@@ -543,17 +551,14 @@ class Sequence2Sequence(object):
         per_line = 2 * T * self.batch_size * (2 * self.depth * self.width + self.voc_size + 32 + T) * 4
         budget = float(os.environ.get('CASV_BEAM_MEMORY_GB', '96')) * 2 ** 30
         chunk = int(max(1, min(B, budget // max(per_line, 1))))
-        results = []
-        for lo in range(0, B, chunk):
-            hi = min(B, lo + chunk)
-            eng.encode(idx[lo:hi], val[lo:hi])
+        results = [('', [], 0, []) for _ in range(B)]
+        for lo in range(0, len(live), chunk):
+            rows = live[lo:lo + chunk]
+            eng.encode(idx[rows], val[rows])
             res = eng.decode_beam(max_results=1, want_align=alignments, **self._beam_kwargs())
-            for j in range(lo, hi):
+            for k, j in enumerate(rows):
                 input_line = lines[j]
-                if not input_line:
-                    results.append(('', [], 0, []))
-                    continue
-                item = next(self._beam_results(res, j - lo, 1, T), None)
+                item = next(self._beam_results(res, k, 1, T), None)
                 if item is None:
                     # the generator of the reference raises StopIteration here (seq2seq.py:826-836)
                     self.logger.error('cannot beam-decode input line %d: "%s"', j, input_line)
@@ -564,7 +569,7 @@ class Sequence2Sequence(object):
                     else:
                         line = input_line
                     item = (line, [1.0] * len(line), 0, self._identity_alignment(len(line)) if alignments else [])
-                results.append(item)
+                results[j] = item
         return self._finish(lines, results)
 
     def _identity_alignment(self, n):

@@ -421,3 +421,25 @@ def test_results_do_not_depend_on_what_else_runs_on_the_gpu():
                     assert np.array_equal(a, b, equal_nan=True)
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize('mode', ['fast', 'greedy', 'beam'])
+def test_padding_lines_and_minimal_lines(mode):
+    """The empty lines that pad a partial batch (seq2seq.py:1011-1015) come back as ('', [], 0, []) and are never
+    decoded in the per-line modes (an all-zero input row would trip greedy's NaN rule for everybody); one-character
+    lines work."""
+    cfg = ModelConfig(depth=3, width=64, voc_size=16)
+    weights = make_weights(cfg, emb_scale=10.0)
+    om = OracleModel(cfg, weights, batch_size=4)
+    i_c = om.mapping[1]
+    lines = [i_c[3] + '\n', '', i_c[4] + i_c[5] + i_c[6] + i_c[7] + '\n', '', '']
+    s2s = _facade(cfg, weights, om.mapping, N=4)
+    fast, greedy = mode == 'fast', mode != 'beam'
+    want = correct_lines(om, lines, fast=fast, greedy=greedy)
+    got = s2s.correct_lines(lines, fast=fast, greedy=greedy)
+    assert got[0] == want[0]
+    for j in (1, 3, 4):
+        assert got[0][j] == '' and got[1][j] == [] and got[2][j] == 0 and got[3][j] == []
+    for j in (0, 2):
+        assert np.allclose(got[1][j], want[1][j], rtol=RT, atol=AT) and abs(got[2][j] - want[2][j]) < 1e-4
+    assert s2s.correct_lines(['', ''], fast=fast, greedy=greedy) == (['', ''], [[], []], [0, 0], [[], []])
