@@ -458,7 +458,7 @@ class Sequence2Sequence(object):
         idx, val = self._dense_to_sparse(encoder_input_data)
         eng.encode(idx, val)
         gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=True)
-        nonpad = (idx >= 0).any(axis=(1, 2))
+        nonpad = ((idx >= 0) & (val != 0)).any(axis=(1, 2))     # np.any(encoder_input_data[j]), seq2seq.py:1255
         lines, probs, scores, aligns = self._greedy_results(gi, gp, ga, nonpad)
         B, T = encoder_input_data.shape[:2]
         # the reference stores the fed-back softmax in a uint32 array (seq2seq.py:1237,1244): all zeros
@@ -532,7 +532,7 @@ class Sequence2Sequence(object):
         if fast:
             eng.encode(idx, val)
             gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=alignments)
-            nonpad = (idx >= 0).any(axis=(1, 2))
+            nonpad = ((idx >= 0) & (val != 0)).any(axis=(1, 2))     # np.any(encoder_input_data[j]), seq2seq.py:1255
             return self._greedy_results(gi, gp, ga, nonpad)
         # the per-line modes never decode the empty padding lines of a partial batch (seq2seq.py:815-816) -- an
         # all-zero input row would also trip the greedy mode's NaN rule for the whole batch
