@@ -109,3 +109,41 @@ def test_facade_train_copy_task(tmp_path, monkeypatch):
     third.load_config(ckpts[best]); third.configure(); third.load_weights(ckpts[best])
     for k, v in s2s.get_weights().items():
         assert np.array_equal(third.get_weights()[k], v), k
+
+
+def test_frozen_layers_do_not_train():
+    """After a transfer from a shallower model the hidden layers taken over stay fixed (`trainable = False`,
+    seq2seq.py:1206-1211): they receive no update and do not count in the clipping norm; everything else trains as
+    the oracle does with their gradients left out."""
+    from cor_asv_ann_amd.engine import HipEngine
+    d, W, V, B, L = 2, 32, 40, 4, 9
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    w = make_weights(cfg, emb_scale=3.0)
+    om = OracleModel(cfg, w)
+    src, sidx = make_lines(B, L, 1, voc_size=V)
+    tgt, _ = make_lines(B, L, 2, voc_size=V)
+    enc_in, dec_in, dec_out, wts = vectorize_lines(om, src, tgt)
+    frozen = ('enc1_', 'dec1_')
+    is_frozen = lambda k: k.startswith(frozen)
+    eng = HipEngine(d, W, V)
+    eng.set_weights(w)
+    eng.train_begin(frozen=frozen)
+    _, grads, _ = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, None)
+    want_norm = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for k, g in grads.items() if not is_frozen(k)))
+    _, gn = eng.train_step(sidx, None, _idx(dec_in), _idx(dec_out), wts, None, mode=2)
+    assert abs(gn - want_norm) < 1e-4 * want_norm
+    st = {'t': 0, 'm': {}, 'v': {}}
+    w2 = {k: v.copy() for k, v in w.items()}
+    for _ in range(2):
+        _, g2, _ = forward_backward(cfg, w2, enc_in, dec_in, dec_out, wts, None)
+        adam_step(w2, g2, st, frozen=frozen)
+        eng.train_step(sidx, None, _idx(dec_in), _idx(dec_out), wts, None, mode=1)
+    eng.train_end()
+    got = eng.get_weights()
+    for k in w:
+        if is_frozen(k):
+            assert np.array_equal(got[k], w[k]), k
+        else:
+            assert not np.array_equal(got[k], w[k]), k
+            assert np.abs(got[k] - w2[k]).max() < 5e-6, k
+    eng.close()
