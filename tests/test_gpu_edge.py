@@ -89,3 +89,40 @@ def test_array_level_entry_points():
     gb = [x for _, x in zip(range(3), s2s.decode_sequence_beam(source_seq=dense))]
     assert [a[0] for a in gb] == [a[0] for a in wb]
     assert all(abs(a[2] - b[2]) < 1e-4 for a, b in zip(gb, wb))
+
+
+def test_predict_over_files_with_a_partial_batch(tmp_path):
+    """`predict` (seq2seq.py:756-780): batches of `batch_size` lines per file set, the last one padded with '' / None;
+    `batch_size` is also the number of hypotheses per step of the beam (seq2seq.py:1414)."""
+    om, s2s = _pair(2, 32, 30, batch_size=4)
+    lines, _ = make_lines(6, 7, 3, voc_size=30)
+    txt = tmp_path / 'ocr.txt'
+    txt.write_text(''.join(lines))
+    out = list(s2s.predict([str(txt)], fast=False, greedy=False))
+    assert len(out) == 2 and out[1][0] == [str(txt), str(txt), None, None]
+    want = correct_lines(om, lines[:4], fast=False, greedy=False)[0] + correct_lines(om, lines[4:], fast=False, greedy=False)[0]
+    got = out[0][1] + out[1][1][:2]
+    assert got == want and out[1][1][2:] == ['', '']
+
+
+def test_vocabulary_growth_keeps_the_trained_rows(tmp_path):
+    """`map_files` on new data grows the vocabulary; `_reconfigure_for_mapping` (seq2seq.py:499-525) keeps every trained
+    tensor and the trained embedding rows, new rows are freshly initialised -- and the device model is rebuilt."""
+    om, s2s = _pair(2, 32, 12, batch_size=2)
+    old = s2s.get_weights()
+    line = ''.join(om.mapping[1][i] for i in (3, 4, 5)) + '\n'
+    before = s2s.correct_lines([line], fast=True, greedy=True)
+    tsv = tmp_path / 'new.tsv'
+    tsv.write_text('%sλ\t%sμ\n' % (line[:-1], line[:-1]))
+    s2s.map_files([str(tsv)])
+    assert s2s.voc_size == 15 and 'λ' in s2s.mapping[0]           # λ, μ and the tab of the TSV (seq2seq.py:571-577)
+    new = s2s.get_weights()
+    assert new['E'].shape == (15, 32) and np.array_equal(new['E'][:12], old['E'])
+    for k in old:
+        if k != 'E':
+            assert np.array_equal(new[k], old[k]), k
+    after = s2s.correct_lines([line, line[:-1] + 'λ\n'], fast=True, greedy=True)
+    cfg = ModelConfig(depth=2, width=32, voc_size=15)
+    om2 = OracleModel(cfg, new, mapping=s2s.mapping, batch_size=2)
+    want = correct_lines(om2, [line, line[:-1] + 'λ\n'], fast=True, greedy=True)
+    assert after[0] == want[0] and len(before[0]) == 1
