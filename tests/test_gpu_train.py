@@ -147,3 +147,47 @@ def test_frozen_layers_do_not_train():
             assert not np.array_equal(got[k], w[k]), k
             assert np.abs(got[k] - w2[k]).max() < 5e-6, k
     eng.close()
+
+
+def test_train_step_with_confidence_inputs():
+    """Encoder inputs that are not one-hot (probability lines, confusion networks: several weighted alternatives per
+    position, seq2seq.py:1067-1093): the embedding is a weighted sum of rows, and its gradient scatters back with the
+    same weights."""
+    from cor_asv_ann_amd.engine import HipEngine
+    d, W, V, B, L = 2, 32, 40, 4, 8
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    w = make_weights(cfg, emb_scale=3.0)
+    om = OracleModel(cfg, w)
+    rng = np.random.default_rng(8)
+    src, sidx = make_lines(B, L, 1, voc_size=V)
+    tgt, _ = make_lines(B, L, 2, voc_size=V)
+    _, dec_in, dec_out, wts = vectorize_lines(om, src, tgt)
+    T, A = L + 1, 3
+    idx = np.full((B, T, A), -1, np.int32)
+    val = np.zeros((B, T, A), np.float32)
+    idx[:, :, 0] = sidx
+    val[:, :, 0] = rng.uniform(0.3, 1.0, (B, T))
+    alt = rng.random((B, T)) < 0.5
+    idx[:, :, 1] = np.where(alt, rng.integers(2, V, (B, T)), -1)
+    val[:, :, 1] = np.where(alt, rng.uniform(0.05, 0.5, (B, T)), 0.0)
+    idx[0, 2, 2] = 5; val[0, 2, 2] = 0.1
+    idx[1, 3, :] = -1; val[1, 3, :] = 0.0                     # an all-zero position inside a line
+    enc_in = np.zeros((B, T, V), np.float32)
+    for b in range(B):
+        for t in range(T):
+            for a in range(A):
+                if idx[b, t, a] >= 0:
+                    enc_in[b, t, idx[b, t, a]] += val[b, t, a]
+    loss, grads, _ = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, None)
+    eng = HipEngine(d, W, V)
+    eng.set_weights(w)
+    eng.train_begin()
+    gl, gn = eng.train_step(idx, val, _idx(dec_in), _idx(dec_out), wts, None, mode=2)
+    onorm = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values()))
+    assert abs(gl - loss) < 2e-5 * abs(loss) and abs(gn - onorm) < 1e-4 * onorm
+    gg = eng.train_gradients()
+    for k in grads:
+        scale = max(np.abs(grads[k]).max(), 1e-6 * onorm)
+        assert np.abs(gg[k] - grads[k]).max() < 2e-3 * scale + 1e-7, k
+    eng.train_end()
+    eng.close()
