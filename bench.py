@@ -4,20 +4,26 @@ corrected chars/sec (whole node) at beam=8, depth-4 width-512, 100-char lines.
 
 One "step" = one pass of `Sequence2Sequence.correct_lines(..., fast=False, greedy=False)` (vectorise ->
 encode -> beamed decode -> strings) over one batch of 1024 synthetic 100-character lines per GPU
-(BASELINE.json configs[2]).  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
-decodes its own 1024 lines per step -- lines are independent, so the path shards with no data-path
-collective -- and one RCCL all-gather of the result records makes all decoded lines available on all
-ranks (BASELINE.json configs[4], weak scaling).
+(BASELINE.json configs[2]).  With N > 1 every rank (one process per GPU) decodes its own lines per step --
+lines are independent, so the path shards with no data-path collective -- and one RCCL all-gather of the
+result records makes all decoded lines available on all ranks (BASELINE.json configs[4], weak scaling).
+
+`python bench.py --gpus N` starts the N ranks itself (the parent never touches the GPU); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks already
+(RANK / LOCAL_RANK / WORLD_SIZE from the environment).
+
+Other workloads (`--workload`): c2 = greedy decode of BASELINE configs[1], c4 = train step of configs[3],
+c5 = configs[4]'s shape (8192 lines per GPU per step, decoded in 1024-line batches).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -33,18 +39,65 @@ LINE_SEED = 103
 EMB_SCALE = 128.0
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_HBM_BYTES_PER_S = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+METRIC = 'corrected chars/sec (whole node) at beam=8, depth-4 width-512, 100-char lines'
 
 
-def make_model(device):
+# ------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a WORLD_SIZE in the environment -> N child ranks of this script
+# ------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    """Start ranks 0..n-1 as child processes (this process has made no GPU call and makes none), hand
+    rank 0's JSON line through, exit non-zero if any rank fails.  Children are stopped by exact PID."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs[1:]):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        if procs[0].poll() is not None and failed is None:
+            break                     # rank 0 is done (its pipe is read below); the others follow
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write('bench.py: rank %d exited with code %s\n' % (failed, procs[failed].returncode))
+        return 1
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write('bench.py: rank exit codes %s\n' % codes)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------
+def make_model(device, depth=DEPTH, width=WIDTH, batch_size=BEAM_N, emb_scale=EMB_SCALE):
     from cor_asv_ann_amd.synthetic import ModelConfig, make_weights, make_vocabulary
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
-    cfg = ModelConfig(depth=DEPTH, width=WIDTH, voc_size=VOC)
-    weights = make_weights(cfg, emb_scale=EMB_SCALE)
+    cfg = ModelConfig(depth=depth, width=width, voc_size=VOC)
+    weights = make_weights(cfg, emb_scale=emb_scale)
     import logging
     logger = logging.getLogger('bench')
     logger.setLevel(logging.CRITICAL)     # lines without a finished hypothesis fall back to the input (seq2seq.py:826-836)
     s2s = Sequence2Sequence(logger=logger, device=device)   # and are logged as errors: hundreds per step with random weights
-    s2s.depth, s2s.width, s2s.batch_size = DEPTH, WIDTH, BEAM_N
+    s2s.depth, s2s.width, s2s.batch_size = depth, width, batch_size
     s2s.mapping, s2s.voc_size = make_vocabulary(VOC), VOC
     s2s.configure()
     s2s.set_weights(weights)
@@ -52,51 +105,60 @@ def make_model(device):
     return s2s, cfg, weights
 
 
-def survey_flop_per_char():
+def survey_flop_per_char(d=DEPTH, W=WIDTH, N=BEAM_N):
     """F = F_enc + N*S*F_row per line, divided by the L corrected characters."""
-    W, V, d, K, T, N = WIDTH, VOC, DEPTH, 11, LENGTH + 1, BEAM_N
+    V, K, T = VOC, 11, LENGTH + 1
     C = 2 * W if d == 1 else W
     f_row = 2 * V * W + (d - 1) * 16 * W * W + 2 * W * W + K * (4 * W + 2 * C) + 8 * W * (2 * W + C) + 2 * W * V
     f_enc = T * (32 * W * W + (24 * W * W if d >= 2 else 0) + 16 * W * W * max(d - 2, 0) + 2 * C * W)
     return (f_enc + N * 2 * T * f_row) / float(LENGTH)
 
 
-def survey_hbm_bytes_per_char():
+def survey_hbm_bytes_per_char(d=DEPTH, W=WIDTH, N=BEAM_N):
     """Q = Q_enc + N*S*Q_row per line (per-beam state in HBM, weights on chip), per corrected character."""
-    W, V, d, K, T, N = WIDTH, VOC, DEPTH, 11, LENGTH + 1, BEAM_N
+    V, K, T = VOC, 11, LENGTH + 1
     C = 2 * W if d == 1 else W
     q_row = 4 * (4 * d * W + K * (W + C) + 2 * V + 2 * T)
     q_enc = 4 * T * (1 + 2 * 2 * W + 2 * W * max(d - 2, 0) + C + W)
     return (q_enc + N * 2 * T * q_row) / float(LENGTH)
 
 
-def cpu_baseline(cfg, weights, lines, budget_s=20.0):
-    """The oracle in the reference's dataflow (per-character decoder call, dense-T attention, u recomputed
-    every step, per-line best-first search) on the host cores, on as many lines of the same workload as
-    fit the time budget."""
-    from oracle.decode import OracleModel, correct_lines
+def host_threads():
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+        return int(max([p.get('num_threads', 1) for p in threadpool_info()] or [1]))
     except Exception:
-        cores = os.cpu_count() or 1
-    om = OracleModel(cfg, weights, batch_size=BEAM_N, recompute_u=True)
-    correct_lines(om, lines[:1], fast=False, greedy=False)      # warm-up (BLAS threads, page-in)
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(cfg, weights, lines, batch_size, fast, budget_s=22.0, repeats=5):
+    """The oracle in the reference's dataflow (per-character decoder call, dense-T attention, u recomputed
+    every step, per-line best-first search / batched greedy loop) on the host cores: best of `repeats`
+    samples of the same workload, each sized to a share of the time budget."""
+    from oracle.decode import OracleModel, correct_lines
+    om = OracleModel(cfg, weights, batch_size=batch_size, recompute_u=True)
+    kw = dict(fast=True, greedy=True) if fast else dict(fast=False, greedy=False)
+    n0 = 8 if fast else 1
     t0 = time.perf_counter()
-    n = 0
-    while n < len(lines):
-        correct_lines(om, lines[n:n + 2], fast=False, greedy=False)
-        n += 2
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {'value': n * LENGTH / dt, 'unit': 'chars/s', 'cores': int(cores), 'kind': 'port',
-            'sample': '%d lines of the same workload (numpy fp32 oracle, reference dataflow), %.1f s' % (n, dt)}
+    correct_lines(om, lines[:n0], **kw)                      # warm-up (BLAS threads, page-in); also sizes the sample
+    per_line = (time.perf_counter() - t0) / n0
+    n = int(max(n0, min(len(lines), (budget_s / repeats) / max(per_line, 1e-6))))
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        correct_lines(om, lines[:n], **kw)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    return {'value': n * LENGTH / best, 'unit': 'chars/s', 'cores': host_threads(), 'kind': 'port',
+            'sample': 'best of %d runs over %d lines of the same workload (numpy fp32 oracle, reference dataflow: '
+                      'per-character decoder call, dense-T attention, u recomputed per step), %.1f s per run' % (repeats, n, best)}
 
 
+# ------------------------------------------------------------------------------------------------------
 def train_bench(args):
     """BASELINE configs[3]: depth 4, width 512, teacher-forced train step (forward + backward + clip + Adam) on 512
     lines of 100 characters (targets = sources with 5 % substitutions), dropout 0.2.  One GPU."""
+    import numpy as np
     from cor_asv_ann_amd.synthetic import ModelConfig, make_weights, make_lines
     from cor_asv_ann_amd.engine import HipEngine
     B = 512
@@ -140,7 +202,205 @@ def train_bench(args):
                    'last_loss': loss, 'last_grad_norm': norm},
         'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel (all GEMMs of the step)', 'achieved': fl / max(ms, 1e-9) / 1e9,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / max(ms, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS,
-                     'traffic': None, 'launches': pl['launches'] + pg['launches'] + ps['launches']}}))
+                     'traffic': None, 'launches': pl['launches'] + pg['launches'] + ps['launches'],
+                     # the whole step priced with SURVEY.md section 8(d)'s ~133 MFLOP per trained character
+                     'whole_path': {'flop_per_char': 133e6,
+                                    'frac': B * LENGTH * args.steps / elapsed * 133e6 / 1e12 / PEAK_F32_MFMA_TFLOPS}}}))
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------
+WORKLOADS = {
+    # name: (depth, width, lines per GPU per step, lines per decode call, hypotheses N, greedy?, emb_scale, dominant kernel class)
+    'c2': dict(depth=2, width=256, lines=256, batch=256, n=1, fast=True, emb=EMB_SCALE, seed=102,
+               text='BASELINE configs[1]: depth=2 width=256 V=256 greedy decode (decode_batch_greedy, 2T steps), '
+                    '256 lines x 100 chars per GPU per step'),
+    'c3': dict(depth=DEPTH, width=WIDTH, lines=LINES, batch=LINES, n=BEAM_N, fast=False, emb=EMB_SCALE, seed=LINE_SEED,
+               text='BASELINE configs[2]: depth=4 width=512 V=256 beamed decode (N=8 hypotheses/step, defaults otherwise), '
+                    '1024 lines x 100 chars per GPU per step'),
+    'c5': dict(depth=DEPTH, width=WIDTH, lines=8192, batch=LINES, n=BEAM_N, fast=False, emb=EMB_SCALE, seed=105,
+               text='BASELINE configs[4]: depth=4 width=512 V=256 beamed decode (N=8), 8192 lines x 100 chars per GPU per step '
+                    'in 1024-line batches, one all-gather of result records per step'),
+}
+
+
+def decode_bench(args):
+    import numpy as np
+    wl = WORKLOADS[args.workload]
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and 'WORLD_SIZE' in os.environ:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
+        return 2
+    dist = None
+    torch = None
+    backend = os.environ.get('CASV_BENCH_BACKEND', 'nccl')     # 'gloo' + CASV_BENCH_SAME_DEVICE=1: rehearsal of the
+    if os.environ.get('CASV_BENCH_SAME_DEVICE'):               # N-rank path on a one-GPU box (all ranks on device 0)
+        local_rank = 0
+    # CASV_BENCH_DRY_RUN=1: no device at all -- every rank echoes its input lines instead of decoding them.  Rehearses
+    # the launcher, sharding, record packing, all-gather and reporting on a CPU-only box; the line says "dry-run" and
+    # its value means nothing.
+    dry = bool(os.environ.get('CASV_BENCH_DRY_RUN'))
+    # CASV_BENCH_FORCE_DIST=1: take the multi-rank path (process group, barrier, all-gather, max-reduce) with ONE rank,
+    # to exercise the RCCL calls on a one-GPU box
+    dist_on = world > 1 or bool(os.environ.get('CASV_BENCH_FORCE_DIST'))
+    if dist_on:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
+
+    from cor_asv_ann_amd.synthetic import make_lines, make_vocabulary
+    from cor_asv_ann_amd import sharding
+    per_gpu, batch = (args.lines_per_gpu or wl['lines']), wl['batch']
+    # weak scaling: the global job is world x per_gpu lines, rank r decodes lines [r*per_gpu, (r+1)*per_gpu)
+    all_lines, _ = make_lines(per_gpu * world, LENGTH, wl['seed'], voc_size=VOC)
+    lo, hi = sharding.shard_bounds(len(all_lines), world, rank)
+    lines = all_lines[lo:hi]
+    S = 2 * (LENGTH + 1)
+    device = ('cuda:%d' % local_rank) if (dist_on and backend == 'nccl') else None
+    eng = None
+    if dry:
+        mapping = make_vocabulary(VOC)
+        lut = np.full(max(ord(c) for c in mapping[0] if c) + 2, -1, np.int32)
+        for c, i in mapping[0].items():
+            if c:
+                lut[ord(c)] = i
+        cfg = weights = None
+
+        def decode(chunk):
+            return chunk, [[1.0] * len(t) for t in chunk], [0.0] * len(chunk)
+        sync_dev = lambda: None
+    else:
+        s2s, cfg, weights = make_model(local_rank, wl['depth'], wl['width'], wl['n'], wl['emb'])
+        eng = s2s._require_engine()
+        if args.graph:
+            eng.set_option('graph', 1)
+        lut = s2s._codepoint_lut()
+
+        def decode(chunk):
+            out, probs, scores, _ = s2s.correct_lines(chunk, fast=wl['fast'], greedy=wl['fast'], alignments=False)
+            return out, probs, scores
+        sync_dev = eng.synchronize
+    t_gather = [0.0]
+
+    def step():
+        out_lines, probs, scores = [], [], []
+        for b0 in range(0, len(lines), batch):
+            o, p, s = decode(lines[b0:b0 + batch])
+            out_lines += o; probs += p; scores += s
+        if dist_on:
+            # fixed-width records (characters, probabilities, length, score) -> RCCL all-gather
+            t0 = time.perf_counter()
+            rec = sharding.records_from_lines(out_lines, probs, scores, lut, S)
+            got = sharding.all_gather_records(rec, len(all_lines), device=device)
+            t_gather[0] += time.perf_counter() - t0
+            return got
+        return out_lines
+
+    def sync():
+        sync_dev()
+        if dist_on:
+            if backend == 'nccl':
+                torch.cuda.synchronize()
+            dist.barrier()
+            if backend == 'nccl':
+                torch.cuda.synchronize()
+
+    dom = 'lstm_gemm' if args.workload != 'c2' else 'lstm_gemm_small'
+    for _ in range(args.warmup):
+        step()
+    if eng:
+        eng.profile(2 if dom == 'lstm_gemm' else 1)      # HIP events around the launches of the dominant kernel, on the library's stream
+    t_gather[0] = 0.0
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    sync_dev()
+    mine = time.perf_counter() - t0                       # this rank's own time, before it waits for the others
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, others = None, {}
+    if eng:
+        prof = eng.profile_read(dom)
+        eng.profile(1)                 # one extra, untimed step with events around every kernel class
+        step()
+        sync()
+        others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'lstm_gemm_small', 'gemm', 'attention', 'softmax', 'beam', 'embed')}
+        eng.profile(False)
+    per_rank = [mine]
+    gather_ms = 1e3 * t_gather[0] / max(args.steps, 1)
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device or 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tt = torch.zeros(world, dtype=torch.float64, device=device or 'cpu')
+        tt[rank] = mine
+        dist.all_reduce(tt)
+        per_rank = [float(x) for x in tt.cpu()]
+
+    result = None
+    if rank == 0:
+        chars = len(all_lines) * LENGTH * args.steps
+        fpc = survey_flop_per_char(wl['depth'], wl['width'], wl['n'])
+        qpc = survey_hbm_bytes_per_char(wl['depth'], wl['width'], wl['n'])
+        result = {
+            'metric': METRIC if args.workload in ('c3', 'c5') else
+                      'corrected chars/sec (1 GPU) greedy, depth-2 width-256, 100-char lines',
+            'value': chars / elapsed, 'unit': 'chars/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'dry-run (no decoding)' if dry else 'synthetic',
+            'config': {'workload': wl['text'] + ', 2T=%d steps max, synthetic weights seed 20250614 emb_scale=%g' % (S, wl['emb']),
+                       'lines_per_gpu': per_gpu, 'lines_per_decode_call': batch, 'line_length': LENGTH, 'beam_n': wl['n'],
+                       'parallelism': 'lines sharded x%d' % world, 'graph': bool(args.graph),
+                       'launcher': 'bench.py' if os.environ.get('CASV_BENCH_CHILD') else
+                                   ('torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ else 'direct')},
+            'ms_per_step_by_rank': [1e3 * x / args.steps for x in per_rank],
+            'gather_ms_per_step': gather_ms if dist_on else 0.0,
+        }
+        if dist_on:
+            result['gathered_records'] = int(last.shape[0])
+        if prof is not None:
+            achieved = prof['flops'] / max(prof['ms'], 1e-9) / 1e9            # TFLOP/s
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'lstm_gemm_traffic.json')) as f:
+                    traffic = json.load(f).get('hbm_bytes_per_launch') if args.workload != 'c2' else None
+            except Exception:
+                pass
+            result['roofline'] = {
+                'bound': 'mfma',
+                'kernel': 'gemm_kernel<EPI_LSTM, 1> (fused LSTM-cell GEMM, 128x128 tiles, fp32 MFMA)' if dom == 'lstm_gemm'
+                          else 'gemm_skinny_kernel<EPI_LSTM> (fused LSTM-cell GEMM, 32x128 tiles, fp32 MFMA)',
+                'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                'launches': prof['launches'], 'avg_launch_us': 1e3 * prof['ms'] / max(prof['launches'], 1),
+                'flops_per_launch': prof['flops'] / max(prof['launches'], 1),
+                # the whole path priced with SURVEY.md section 8(d)'s algorithmic FLOP per corrected character
+                'whole_path': {'flop_per_char': fpc,
+                               'achieved': chars / elapsed * fpc / 1e12 / world,
+                               'frac': chars / elapsed * fpc / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
+                               # the other roofline of SURVEY 8(d): not the binding one at fp32
+                               'hbm_bytes_per_char': qpc,
+                               'hbm_frac': chars / elapsed * qpc / world / PEAK_HBM_BYTES_PER_S}}
+            result['kernel_ms_per_step'] = {k: v['ms'] for k, v in others.items()}     # from one extra untimed step
+        if world == 1 and not args.no_cpu_baseline and not dry:
+            result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64], wl['n'] if not wl['fast'] else 256, wl['fast'])
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+    return 0
 
 
 def main():
@@ -150,124 +410,22 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', type=int, default=0, help='replay the decode step from a hipGraph')
-    ap.add_argument('--workload', default='c3', choices=['c3', 'c4'],
-                    help='c3 = beamed decode (the BASELINE metric, default); c4 = train step (BASELINE configs[3])')
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'],
+                    help='c3 = beamed decode (the BASELINE metric, default); c2 = greedy decode (configs[1]); '
+                         'c4 = train step (configs[3]); c5 = 8192 lines per GPU per step (configs[4])')
+    ap.add_argument('--lines-per-gpu', type=int, default=0, help='override the lines each GPU decodes per step')
     args = ap.parse_args()
-
+    if args.gpus < 1:
+        ap.error('--gpus must be positive')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        if args.workload == 'c4':
+            ap.error('the train step (c4) is a single-GPU workload')
+        os.environ['CASV_BENCH_CHILD'] = '1'
+        return launch_ranks(args.gpus, sys.argv[1:])
     if args.workload == 'c4':
         return train_bench(args)
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    torch = None
-    backend = os.environ.get('CASV_BENCH_BACKEND', 'nccl')     # 'gloo' + CASV_BENCH_SAME_DEVICE=1: rehearsal of the
-    if os.environ.get('CASV_BENCH_SAME_DEVICE'):               # N-rank path on a one-GPU box (all ranks on device 0)
-        local_rank = 0
-    # CASV_BENCH_FORCE_DIST=1: take the multi-rank path (process group, barrier, all-gather, max-reduce) with ONE rank,
-    # to exercise the RCCL calls on a one-GPU box (launch under torch.distributed.run --nproc-per-node 1)
-    dist_on = world > 1 or bool(os.environ.get('CASV_BENCH_FORCE_DIST'))
-    if dist_on:
-        import torch
-        import torch.distributed as dist
-        if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    from cor_asv_ann_amd.synthetic import make_lines
-    from cor_asv_ann_amd import sharding
-    s2s, cfg, weights = make_model(local_rank)
-    # weak scaling: the global job is world x 1024 lines, rank r decodes lines [r*1024, (r+1)*1024)
-    all_lines, _ = make_lines(LINES * world, LENGTH, LINE_SEED, voc_size=VOC)
-    lo, hi = sharding.shard_bounds(len(all_lines), world, rank)
-    lines = all_lines[lo:hi]
-    eng = s2s._require_engine()
-    if args.graph:
-        eng.set_option('graph', 1)
-    S = 2 * (LENGTH + 1)
-    device = ('cuda:%d' % local_rank) if (dist_on and backend == 'nccl') else None
-
-    def step():
-        out_lines, probs, scores, _ = s2s.correct_lines(lines, fast=False, greedy=False, alignments=False)
-        if dist_on:
-            # fixed-width records (characters, probabilities, length, score) -> RCCL all-gather
-            rec = sharding.records_from_lines(out_lines, probs, scores, s2s._codepoint_lut(), S)
-            return sharding.all_gather_records(rec, len(all_lines), device=device)
-        return out_lines
-
-    def sync():
-        eng.synchronize()
-        if dist_on:
-            if backend == 'nccl':
-                torch.cuda.synchronize()
-            dist.barrier()
-            if backend == 'nccl':
-                torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    eng.profile(2)                 # HIP events around every launch of the dominant kernel, on the library's stream
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_read('lstm_gemm')
-    eng.profile(1)                 # one extra, untimed step with events around every kernel class
-    step()
-    sync()
-    others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'lstm_gemm_small', 'gemm', 'attention', 'softmax', 'beam', 'embed')}
-    eng.profile(False)
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device or 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    result = None
-    if rank == 0:
-        chars = len(all_lines) * LENGTH * args.steps
-        achieved = prof['flops'] / max(prof['ms'], 1e-9) / 1e9            # TFLOP/s
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'lstm_gemm_traffic.json')) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
-        except Exception:
-            pass
-        result = {
-            'metric': 'corrected chars/sec (whole node) at beam=8, depth-4 width-512, 100-char lines',
-            'value': chars / elapsed, 'unit': 'chars/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: depth=4 width=512 V=256 beamed decode (N=8 hypotheses/step, '
-                                   'defaults otherwise), %d lines x %d chars per GPU per step, 2T=%d search iterations max, '
-                                   'synthetic weights seed 20250614 emb_scale=%g' % (LINES, LENGTH, S, EMB_SCALE),
-                       'lines_per_gpu': LINES, 'line_length': LENGTH, 'beam_n': BEAM_N, 'parallelism': 'lines sharded x%d' % world,
-                       'graph': bool(args.graph)},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<EPI_LSTM, 1> (fused LSTM-cell GEMM, 128x128 tiles, fp32 MFMA)',
-                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                         'launches': prof['launches'], 'avg_launch_us': 1e3 * prof['ms'] / max(prof['launches'], 1),
-                         'flops_per_launch': prof['flops'] / max(prof['launches'], 1),
-                         # the whole path priced with SURVEY.md section 8(d)'s algorithmic FLOP per corrected character
-                         'whole_path': {'flop_per_char': survey_flop_per_char(),
-                                        'achieved': chars / elapsed * survey_flop_per_char() / 1e12 / world,
-                                        'frac': chars / elapsed * survey_flop_per_char() / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
-                                        # the other roofline of SURVEY 8(d): not the binding one at fp32 (AI = 262 FLOP/B)
-                                        'hbm_bytes_per_char': survey_hbm_bytes_per_char(),
-                                        'hbm_frac': chars / elapsed * survey_hbm_bytes_per_char() / world / PEAK_HBM_BYTES_PER_S}},
-            'kernel_ms_per_step': {k: v['ms'] for k, v in others.items()},     # from one extra untimed step
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64])
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result))
+    return decode_bench(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -24,6 +24,23 @@ def pytest_sessionstart(session):
             sys.stderr.write('could not build the HIP library: %s\n' % err)
 
 
+def pytest_collection_modifyitems(config, items):
+    """A box without a GPU skips the gpu-marked tests (a missing or unloadable library is NOT a reason to skip: then
+    they run and fail loudly)."""
+    gpu_items = [it for it in items if it.get_closest_marker('gpu')]
+    if not gpu_items:
+        return
+    try:
+        import cor_asv_ann_amd._native as nv
+        ndev = nv.load().casv_device_count()
+    except Exception:
+        return
+    if ndev == 0:
+        skip = pytest.mark.skip(reason='no HIP device on this box')
+        for it in gpu_items:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')

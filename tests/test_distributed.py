@@ -96,3 +96,58 @@ def test_sharded_decode_equals_unsharded(tmp_path):
     assert idx.shape == g[5].shape and np.array_equal(idx, g[5])
     assert np.allclose(score, g[3], rtol=1e-5)
     assert sharding.records_to_strings(idx, length, m.mapping[1]) == g[1]
+
+
+def _run_bench(extra_env, *argv):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + list(argv), env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    return p.returncode, [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith('{')], p.stderr.decode()
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it) is two ranks: launcher, sharding, record
+    packing, all-gather and reporting rehearsed without a device (CASV_BENCH_DRY_RUN: ranks echo their lines)."""
+    code, lines, err = _run_bench({'CASV_BENCH_DRY_RUN': '1', 'CASV_BENCH_BACKEND': 'gloo'},
+                                  '--gpus', '2', '--steps', '2', '--warmup', '1', '--lines-per-gpu', '9')
+    assert code == 0, err
+    assert len(lines) == 1
+    out = lines[0]
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['gathered_records'] == 18
+    assert len(out['ms_per_step_by_rank']) == 2 and out['gather_ms_per_step'] > 0
+    assert out['config']['launcher'] == 'bench.py' and out['data'].startswith('dry-run')
+    assert out['value'] == pytest.approx(18 * 100 * 2 / (out['ms_per_step'] * 2e-3), rel=1e-6)
+
+
+def test_bench_fails_when_a_rank_fails():
+    """Without the dry-run switch the ranks need a GPU: on a CPU box every rank fails and so does the launcher
+    (no silent single-rank run, no fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('needs a box without a GPU')
+    code, lines, err = _run_bench({}, '--gpus', '2', '--steps', '1', '--warmup', '0', '--lines-per-gpu', '4')
+    assert code != 0 and not lines
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    code, lines, err = _run_bench({'CASV_BENCH_DRY_RUN': '1', 'WORLD_SIZE': '1', 'RANK': '0'}, '--gpus', '2', '--steps', '1')
+    assert code != 0 and not lines and 'WORLD_SIZE' in err
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """The real N-rank path of bench.py (two processes, each with its own model handle, decoding their shards on
+    the same card; gloo carries the gather because two RCCL ranks cannot share a device)."""
+    code, lines, err = _run_bench({'CASV_BENCH_BACKEND': 'gloo', 'CASV_BENCH_SAME_DEVICE': '1'},
+                                  '--gpus', '2', '--steps', '1', '--warmup', '1', '--lines-per-gpu', '64')
+    assert code == 0, err
+    out = lines[0]
+    assert out['n_gpus'] == 2 and out['gathered_records'] == 128 and out['data'] == 'synthetic'
+    assert out['roofline']['launches'] > 0 and out['value'] > 0
