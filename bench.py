@@ -79,7 +79,9 @@ def launch_ranks(n, argv):
         return 1
     out, _ = procs[0].communicate()
     codes = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    # rank 0 prints the one JSON line; anything else a library wrote to its stdout (gloo's connection notice) goes to stderr
+    for text in out.decode().splitlines():
+        (sys.stdout if text.startswith('{') else sys.stderr).write(text + '\n')
     sys.stdout.flush()
     if any(codes):
         sys.stderr.write('bench.py: rank exit codes %s\n' % codes)

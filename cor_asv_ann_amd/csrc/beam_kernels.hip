@@ -14,7 +14,8 @@
 
 namespace casv {
 
-constexpr int ROWMAX = 256;       // N <= 256
+
+constexpr int BEAM_SORT_CAP = 4096;    // new keys sorted in LDS at once; more are sorted in runs of this size and merged by rank
 
 __device__ __forceinline__ bool before(double ka, int ia, double kb, int ib) {
     if (ia == 0x7fffffff) return false;
@@ -38,7 +39,7 @@ __global__ void beam_init_kernel(const BeamState s, const BeamParams p) {
         s.f_n[line] = 0; s.f_total[line] = 0;
         s.nact[line] = 1; s.line_done[line] = 0; s.line_steps[line] = 0;
         s.beam_node[line * N] = 0;
-        if (line == 0) *s.active_lines = s.B;
+        if (line == 0) { s.active_lines[0] = s.B; s.active_lines[1] = 0; }
     }
     for (int i = threadIdx.x; i < N; i += blockDim.x) s.prev[line * N + i] = line * N;
     for (int i = threadIdx.x; i < N * Vp; i += blockDim.x) s.p_in[(long long)line * N * Vp + i] = 0.f;
@@ -51,10 +52,8 @@ void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t strea
 template <int VPL, int NWV>
 __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, const BeamParams p) {
     constexpr int NT = 64 * NWV;
-    // dynamic LDS: [npow2 new keys (f64)] [q_stage old keys (f64)] [npow2 new ids] [q_stage old ids]
+    // dynamic LDS: [sort_cap new keys (f64)] [q_stage old keys (f64)] [sort_cap new ids] [q_stage old ids] [7 x (N+1) row records]
     extern __shared__ __attribute__((aligned(16))) unsigned char beam_smem[];
-    __shared__ int r_count[ROWMAX], r_off[ROWMAX + 1], r_beampos[ROWMAX], r_rej[ROWMAX], r_srcpos[ROWMAX];
-    __shared__ int r_nan[ROWMAX], r_rejlate[ROWMAX];
     __shared__ int sh_nnew, sh_nb, sh_done;
     __shared__ int pop_id[64], pop_chr[64];
     __shared__ double pop_key[64];
@@ -63,14 +62,20 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
     const int step = *s.step_ptr;
     if (s.line_done[line]) return;
     const int N = p.N, V = s.V, Vp = (V + 31) & ~31, T = s.T, R = s.R;
-    const int CMAX = p.width_in + 1;
-    int npow_max = 1;
-    while (npow_max < N * CMAX) npow_max <<= 1;
+    const int CMAX = (p.width_in < V ? p.width_in : V) + 1;      // children per expansion: <= min(width_in, V) + the late rejection
+    const int cap = p.sort_cap;                    // new keys the LDS holds (a power of two)
     const int q_stage = p.q_stage;                 // entries of the old queue staged in LDS (0: search in HBM)
     double* s_key = reinterpret_cast<double*>(beam_smem);
-    double* o_key = s_key + npow_max;
+    double* o_key = s_key + cap;
     int* s_id = reinterpret_cast<int*>(o_key + q_stage);
-    int* o_id = s_id + npow_max;
+    int* o_id = s_id + cap;
+    int* r_count = o_id + q_stage;
+    int* r_off = r_count + (N + 1);
+    int* r_beampos = r_off + (N + 1);
+    int* r_rej = r_beampos + (N + 1);
+    int* r_srcpos = r_rej + (N + 1);
+    int* r_nan = r_srcpos + (N + 1);
+    int* r_rejlate = r_nan + (N + 1);
     const int nact = s.nact[line];
     const long long nbase = (long long)line * s.node_cap;
     if (tid == 0) s.line_steps[line] = step + 1;
@@ -157,10 +162,17 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
         for (int i = 0; i < nact; ++i) { r_off[i] = o; o += r_count[i]; }
         r_off[nact] = o;
         sh_nnew = o;
+        if (o > s.active_lines[1]) atomicMax(s.active_lines + 1, o);      // statistic: most new keys of any line and step
     }
     __syncthreads();
     const int nnew = sh_nnew;
     const int id0 = s.n_count[line];
+    // More new keys than the LDS holds (wide beams: N * (beam_width_in + 1) can reach 256 * 51 with the reference's
+    // settings): they go to a scratch array in HBM, are sorted in runs of `cap` and merged by rank (phase B).
+    const bool big = nnew > cap;
+    const long long gbase = (long long)line * s.g_cap;
+    double* g0k = s.g_key + 2 * gbase; int* g0i = s.g_id + 2 * gbase;          // unsorted, then sorted runs
+    double* g1k = g0k + s.g_cap; int* g1i = g0i + s.g_cap;                     // the merged order
 
     // ---------------- A2: iterative selection, node records, keys ----------------
     for (int i = wave; i < nact; i += NWV) {
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
         float vals[VPL];
 #pragma unroll
         for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; vals[k] = v < V ? sc[v] : -INFINITY; }
-        unsigned taken = 0;
+        unsigned long long taken = 0;
         int created = 0;
         const int total = beampos + r_rejlate[i];
         for (int ps = 1; ps <= total; ++ps) {
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
 #pragma unroll
                 for (int k = 0; k < VPL; ++k) {
                     const int v = lane + 64 * k;
-                    if (v < V && !((taken >> k) & 1u) && (bi < 0 || better(vals[k], v, bv, bi))) { bv = vals[k]; bi = v; }
+                    if (v < V && !((taken >> k) & 1ull) && (bi < 0 || better(vals[k], v, bv, bi))) { bv = vals[k]; bi = v; }
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
                     if (oi >= 0 && (bi < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
                 }
 #pragma unroll
-                for (int k = 0; k < VPL; ++k) if (lane + 64 * k == bi) taken |= 1u << k;
+                for (int k = 0; k < VPL; ++k) if (lane + 64 * k == bi) taken |= 1ull << k;
             } else {                                   // the rejection candidate beyond the beam width
                 bi = rej; bv = 0.f;
 #pragma unroll
@@ -220,8 +232,9 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
                 s.n_pos[g] = isrej ? (double)srcpos : pos;
                 s.n_is1[g] = isrej ? 1 : is1;
                 s.created[exp * CMAX + k] = (short)bi;
-                s_key[slot] = -(cum + p.cost0 * fabs((double)(len - T)));
-                s_id[slot] = id;
+                const double key = -(cum + p.cost0 * fabs((double)(len - T)));
+                if (big) { g0k[slot] = key; g0i[slot] = id; }
+                else { s_key[slot] = key; s_id[slot] = id; }
             }
             ++created;
         }
@@ -230,24 +243,58 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
     if (tid == 0) s.n_count[line] = id0 + nnew;
 
     // ---------------- B: sort the new nodes, merge with the queue, cap ----------------
-    int npow = 1;
-    while (npow < nnew) npow <<= 1;
-    for (int i = nnew + tid; i < npow; i += NT) { s_key[i] = 0.0; s_id[i] = 0x7fffffff; }
-    __syncthreads();
-    for (int k = 2; k <= npow; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow; i += NT) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-                    const double ka = s_key[i], kb = s_key[l];
-                    const int ia = s_id[i], ib = s_id[l];
-                    const bool sw = up ? before(kb, ib, ka, ia) : before(ka, ia, kb, ib);
-                    if (sw) { s_key[i] = kb; s_id[i] = ib; s_key[l] = ka; s_id[l] = ia; }
+    auto bitonic = [&](int npow) {          // s_key/s_id[0..npow) best first
+        for (int k = 2; k <= npow; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < npow; i += NT) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const bool up = (i & k) == 0;
+                        const double ka = s_key[i], kb = s_key[l];
+                        const int ia = s_id[i], ib = s_id[l];
+                        const bool sw = up ? before(kb, ib, ka, ia) : before(ka, ia, kb, ib);
+                        if (sw) { s_key[i] = kb; s_id[i] = ib; s_key[l] = ka; s_id[l] = ia; }
+                    }
                 }
+                __syncthreads();
+            }
+        }
+    };
+    if (!big) {
+        int npow = 1;
+        while (npow < nnew) npow <<= 1;
+        for (int i = nnew + tid; i < npow; i += NT) { s_key[i] = 0.0; s_id[i] = 0x7fffffff; }
+        __syncthreads();
+        bitonic(npow);
+    } else {
+        const int nruns = (nnew + cap - 1) / cap;
+        for (int run = 0; run < nruns; ++run) {
+            const int base = run * cap, nr = nnew - base < cap ? nnew - base : cap;
+            int npow = 1;
+            while (npow < nr) npow <<= 1;
+            for (int i = tid; i < npow; i += NT) {
+                s_key[i] = i < nr ? g0k[base + i] : 0.0; s_id[i] = i < nr ? g0i[base + i] : 0x7fffffff;
             }
             __syncthreads();
+            bitonic(npow);
+            for (int i = tid; i < nr; i += NT) { g0k[base + i] = s_key[i]; g0i[base + i] = s_id[i]; }
+            __syncthreads();
         }
+        // position in the merged order = position in the own run + rank in every other run (ids are unique: no ties)
+        for (int j = tid; j < nnew; j += NT) {
+            const double k = g0k[j]; const int id = g0i[j];
+            const int own = j / cap;
+            int pos = j - own * cap;
+            for (int run = 0; run < nruns; ++run) {
+                if (run == own) continue;
+                const int base = run * cap;
+                int lo = 0, hi = nnew - base < cap ? nnew - base : cap;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(g0k[base + mid], g0i[base + mid], k, id)) lo = mid + 1; else hi = mid; }
+                pos += lo;
+            }
+            g1k[pos] = k; g1i[pos] = id;
+        }
+        __syncthreads();
     }
     const int par = step & 1;
     const long long qstride = (long long)s.B * s.q_cap;
@@ -256,32 +303,33 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
     const int* oid = s.q_id + par * qstride + (long long)line * s.q_cap + qhead;
     double* nkey = s.q_key + (par ^ 1) * qstride + (long long)line * s.q_cap;
     int* nid = s.q_id + (par ^ 1) * qstride + (long long)line * s.q_cap;
-    const int qcap = 2 * T * N;                   // max_batches * batch_size (s2s:1531)
+    const int qcap = s.q_cap;                     // max_batches * batch_size (s2s:1531)
     const bool staged = qn_old <= q_stage;
     if (staged) {                                 // one coalesced pass instead of log2(n) dependent HBM probes
         for (int i = tid; i < qn_old; i += NT) { o_key[i] = okey[i]; o_id[i] = oid[i]; }
         __syncthreads();
     }
-    for (int i = tid; i < qn_old; i += NT) {      // old element i moves behind the new ones before it
-        const double k = staged ? o_key[i] : okey[i]; const int id = staged ? o_id[i] : oid[i];
-        int lo = 0, hi = nnew;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(s_key[mid], s_id[mid], k, id)) lo = mid + 1; else hi = mid; }
-        const int pos = i + lo;
-        if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
-        if (pos < 64) { pop_key[pos] = k; pop_id[pos] = id; }
-    }
-    for (int j = tid; j < nnew; j += NT) {
-        const double k = s_key[j]; const int id = s_id[j];
-        int lo = 0, hi = qn_old;
-        if (staged) {
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(o_key[mid], o_id[mid], k, id)) lo = mid + 1; else hi = mid; }
-        } else {
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(okey[mid], oid[mid], k, id)) lo = mid + 1; else hi = mid; }
+    // merge of the sorted new keys (in LDS, or in HBM for the wide case) with the old queue, by rank
+    auto merge = [&](const double* nk, const int* ni, const double* ok, const int* oi) {
+        for (int i = tid; i < qn_old; i += NT) {      // old element i moves behind the new ones before it
+            const double k = ok[i]; const int id = oi[i];
+            int lo = 0, hi = nnew;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(nk[mid], ni[mid], k, id)) lo = mid + 1; else hi = mid; }
+            const int pos = i + lo;
+            if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
+            if (pos < 64) { pop_key[pos] = k; pop_id[pos] = id; }
         }
-        const int pos = j + lo;
-        if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
-        if (pos < 64) { pop_key[pos] = k; pop_id[pos] = id; }
-    }
+        for (int j = tid; j < nnew; j += NT) {
+            const double k = nk[j]; const int id = ni[j];
+            int lo = 0, hi = qn_old;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(ok[mid], oi[mid], k, id)) lo = mid + 1; else hi = mid; }
+            const int pos = j + lo;
+            if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
+            if (pos < 64) { pop_key[pos] = k; pop_id[pos] = id; }
+        }
+    };
+    if (!big) { if (staged) merge(s_key, s_id, o_key, o_id); else merge(s_key, s_id, okey, oid); }
+    else { if (staged) merge(g1k, g1i, o_key, o_id); else merge(g1k, g1i, okey, oid); }
     __threadfence_block();
     __syncthreads();
     const int qn = (qn_old + nnew) < qcap ? (qn_old + nnew) : qcap;
@@ -313,7 +361,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
             } else {
                 if (nb == 0) b0 = key;
                 s.beam_node[line * N + nb] = id;
-                if (nb < ROWMAX) r_count[nb] = id;      // r_count is free now: ids of the popped nodes
+                r_count[nb] = id;                       // r_count is free now: ids of the popped nodes
                 ++nb;
             }
             ++h;
@@ -340,9 +388,8 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
             const int k = s.n_k[nbase + id];
             const float* src = s.p_base + (long long)exp * Vp;
             const short* cr = s.created + (long long)exp * CMAX;
-            const int zi = lane < k ? (int)cr[lane] : -1;
             for (int v = lane; v < Vp; v += 64) pin[v] = src[v];
-            if (zi >= 0) pin[zi] = 0.f;
+            for (int q = lane; q < k; q += 64) pin[(int)cr[q]] = 0.f;       // behind the copy, in program order of one wave
             if (lane == 0) s.prev[r] = exp;
         } else {
             for (int v = lane; v < Vp; v += 64) pin[v] = 0.f;
@@ -350,30 +397,37 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
         }
     }
 }
-size_t beam_lds_bytes(int N, int width_in, int q_cap, int* q_stage) {
-    int npow = 1;
-    while (npow < N * (width_in + 1)) npow <<= 1;
-    const size_t base = (size_t)npow * 12;
+// LDS plan of one launch: sort capacity (new keys held at once), staged entries of the old queue, bytes.
+size_t beam_lds_bytes(int N, int width_in, int V, int q_cap, int* sort_cap, int* q_stage) {
+    const int cm = (width_in < V ? width_in : V) + 1;
+    const size_t rows = (size_t)7 * (N + 1) * 4;
+    int cap = 1;
+    while (cap < N * cm && cap < BEAM_SORT_CAP) cap <<= 1;
+    while (cap > 256 && rows + (size_t)cap * 12 > 56 * 1024) cap >>= 1;
+    const size_t base = rows + (size_t)cap * 12;
+    *sort_cap = cap;
     *q_stage = ((size_t)q_cap * 12 + base <= 56 * 1024) ? q_cap : 0;
     return base + (size_t)(*q_stage) * 12 + 16;
 }
 void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream) {
-    int q_stage = 0;
-    const size_t lds = beam_lds_bytes(p.N, p.width_in, s.q_cap, &q_stage);
+    int q_stage = 0, sort_cap = 0;
+    const size_t lds = beam_lds_bytes(p.N, p.width_in, s.V, s.q_cap, &sort_cap, &q_stage);
     BeamParams pp = p;
-    pp.q_stage = q_stage;
+    pp.q_stage = q_stage; pp.sort_cap = sort_cap;
     const int vpl = (s.V + 63) / 64;
     const bool wide = p.N >= 8;          // eight waves: one hypothesis row per wave at the default N = 8
 #define CASV_BEAM_LAUNCH(VPL_, NWV_) hipLaunchKernelGGL((beam_step_kernel<VPL_, NWV_>), dim3(s.B), dim3(64 * NWV_), lds, stream, s, pp)
     if (vpl <= 4) { if (wide) CASV_BEAM_LAUNCH(4, 8); else CASV_BEAM_LAUNCH(4, 4); }
     else if (vpl <= 8) { if (wide) CASV_BEAM_LAUNCH(8, 8); else CASV_BEAM_LAUNCH(8, 4); }
-    else { if (wide) CASV_BEAM_LAUNCH(16, 8); else CASV_BEAM_LAUNCH(16, 4); }
+    else if (vpl <= 16) { if (wide) CASV_BEAM_LAUNCH(16, 8); else CASV_BEAM_LAUNCH(16, 4); }
+    else if (vpl <= 32) { if (wide) CASV_BEAM_LAUNCH(32, 8); else CASV_BEAM_LAUNCH(32, 4); }
+    else { if (wide) CASV_BEAM_LAUNCH(64, 8); else CASV_BEAM_LAUNCH(64, 4); }
 #undef CASV_BEAM_LAUNCH
 }
 
 // Results, best first (seq2seq.py:1538-1544): walk the trie from each finished node to the root.
 __global__ void beam_extract_kernel(const BeamState s, const BeamParams p, const BeamOut o) {
-    __shared__ int chain[1024];
+    extern __shared__ int chain[];              // S node ids
     const int line = blockIdx.x / p.max_results, k = blockIdx.x % p.max_results;
     const int tid = threadIdx.x;
     const long long nbase = (long long)line * s.node_cap;
@@ -385,7 +439,7 @@ __global__ void beam_extract_kernel(const BeamState s, const BeamParams p, const
     const int len = s.n_len[nbase + fnode] - 1;
     if (tid == 0) {
         int cur = fnode;
-        for (int j = len - 1; j >= 0 && j < 1024; --j) { chain[j] = cur; cur = s.n_parent[nbase + cur]; }
+        for (int j = len - 1; j >= 0; --j) { if (j < s.S) chain[j] = cur; cur = s.n_parent[nbase + cur]; }
         o.len[ob] = len;
         o.score[ob] = s.n_cum[nbase + fnode] / (double)len;
     }
@@ -407,7 +461,7 @@ __global__ void beam_extract_kernel(const BeamState s, const BeamParams p, const
     }
 }
 void launch_beam_extract(const BeamState& s, const BeamParams& p, const BeamOut& o, hipStream_t stream) {
-    hipLaunchKernelGGL(beam_extract_kernel, dim3(s.B * p.max_results), dim3(256), 0, stream, s, p, o);
+    hipLaunchKernelGGL(beam_extract_kernel, dim3(s.B * p.max_results), dim3(256), (size_t)s.S * 4, stream, s, p, o);
 }
 
 }  // namespace casv

@@ -153,7 +153,8 @@ void launch_scatter_rows(const float* src, int src_ld, float* dst, int dst_ld, i
 struct BeamParams {
     int N, width_in, width_out, max_results;
     double threshold_in, rejection, cost0;
-    int q_stage;   // set by launch_beam_step
+    int q_stage;   // set by launch_beam_step: entries of the old queue staged in LDS
+    int sort_cap;  // set by launch_beam_step: new keys sorted in LDS at once
     int eos;       // vocabulary index of the end-of-line character
 };
 
@@ -170,6 +171,8 @@ struct BeamState {
     // queue: two buffers [2][B][q_cap] of (key, node id) sorted best-first (step parity selects the live one);
     // q_n[0..B) = entries, q_n[B..2B) = offset of the first entry after the last pop
     double* q_key; int* q_id; int* q_n;
+    // scratch for steps that create more keys than the LDS sorts at once: [B][2][g_cap]
+    double* g_key; int* g_id; int g_cap;
     // finals
     double* f_key; int* f_id; int* f_n; int* f_total;
     // current beam
@@ -177,7 +180,7 @@ struct BeamState {
     int* nact;                  // [B] active rows of the current step
     int* line_done;             // [B]
     int* line_steps;            // [B]
-    int* active_lines;          // [1]
+    int* active_lines;          // [0] lines still searching, [1] statistic: most new keys of any line in any step
     // step io
     int* prev;                  // [R]
     float* p_in;                // [R][V]

@@ -18,6 +18,10 @@
 
 using namespace casv;
 
+// Limits of the boundary (documented in include/cor_asv_ann_hip.h)
+constexpr int CASV_MAX_T = 4096;        // characters per line (positions of the encoder); decode steps S <= 2 * CASV_MAX_T
+constexpr int CASV_MAX_BEAM_N = 1024;   // hypotheses per line and step
+
 inline thread_local char g_err[512] = "";
 inline int fail(int code, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
@@ -100,7 +104,7 @@ struct casv_model {
     DevBuf o_idx, o_prob, o_align;
     // beam
     DevBuf b_parent, b_chr, b_prob, b_cum, b_len, b_exp, b_k, b_rejpos, b_pos, b_is1, b_count, b_created;
-    DevBuf b_qkey, b_qid, b_qn, b_fkey, b_fid, b_fn, b_ftotal, b_beamnode, b_nact, b_done, b_steps, b_active;
+    DevBuf b_gkey, b_gid, b_qkey, b_qid, b_qn, b_fkey, b_fid, b_fn, b_ftotal, b_beamnode, b_nact, b_done, b_steps, b_active;
     DevBuf bo_idx, bo_prob, bo_len, bo_score, bo_rej, bo_align, bo_found, bo_nsteps;
     // training session (train.hip)
     TrainState* train = nullptr;
@@ -109,6 +113,7 @@ struct casv_model {
     bool use_graph = false;
     const int* skip_nact = nullptr;                       // beam decode: live rows per line, handed to the step's kernels when
     int skip_group = 0;                                   // skipping can pay (wide beams, or a line has finished); rows per line
+    int stat_beam_max_new = 0;                            // last beam decode: most new hypotheses of one line in one step
     Prof prof;
 
     void prof_begin(int cls, double fl, double by, hipEvent_t& a) {

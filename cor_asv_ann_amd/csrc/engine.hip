@@ -36,7 +36,7 @@ extern "C" int casv_model_create(const casv_config* cfg, int device_id, casv_mod
                     "deep_bidirectional_encoder, bridge_dense, lm_loss/lm_predict, stateful must be off)");
     if (cfg->depth < 1 || cfg->depth > 8) return fail(CASV_ERR_ARG, "depth %d out of range 1..8", cfg->depth);
     if (cfg->width < 32 || cfg->width % 32) return fail(CASV_ERR_ARG, "width %d must be a positive multiple of 32", cfg->width);
-    if (cfg->voc_size < 2 || cfg->voc_size > 1024) return fail(CASV_ERR_ARG, "voc_size %d out of range 2..1024", cfg->voc_size);
+    if (cfg->voc_size < 2 || cfg->voc_size > 4096) return fail(CASV_ERR_ARG, "voc_size %d out of range 2..4096", cfg->voc_size);
     if (cfg->window_width < 1 || cfg->window_width > 5) return fail(CASV_ERR_ARG, "window_width %d out of range 1..5", cfg->window_width);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -65,7 +65,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
         &m->hfin, &m->u, &m->st_a, &m->st_p, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
         &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->b_parent, &m->b_chr, &m->b_prob,
         &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos, &m->b_pos, &m->b_is1, &m->b_count, &m->b_created,
-        &m->b_qkey, &m->b_qid, &m->b_qn, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_beamnode, &m->b_nact,
+        &m->b_gkey, &m->b_gid, &m->b_qkey, &m->b_qid, &m->b_qn, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_beamnode, &m->b_nact,
         &m->b_done, &m->b_steps, &m->b_active, &m->bo_idx, &m->bo_prob, &m->bo_len, &m->bo_score,
         &m->bo_rej, &m->bo_align, &m->bo_found, &m->bo_nsteps};
     for (DevBuf* b : bufs) b->release();
@@ -186,7 +186,7 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
     if (!m || !idx || !val) return fail(CASV_ERR_ARG, "null argument");
     if (!m->committed) return fail(CASV_ERR_STATE, "weights not committed");
     if (B < 1 || T < 1 || A < 1) return fail(CASV_ERR_ARG, "bad shape B=%d T=%d A=%d", B, T, A);
-    if (2 * T > 1024) return fail(CASV_ERR_ARG, "line length %d exceeds the supported maximum of 512", T);
+    if (T > CASV_MAX_T) return fail(CASV_ERR_ARG, "line length %d exceeds the supported maximum of %d", T, CASV_MAX_T);
     HIPCHK(hipSetDevice(m->device));
     const int W = m->W, C = m->C, D = m->D;
     const size_t BT = (size_t)B * T;
@@ -519,7 +519,7 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (!m || !out_idx || !out_prob) return fail(CASV_ERR_ARG, "null argument");
     if (!m->encoded) return fail(CASV_ERR_STATE, "casv_encode must run first");
     if (mode != 0 && mode != 1) return fail(CASV_ERR_ARG, "mode must be 0 or 1");
-    if (S < 1 || S > 1024) return fail(CASV_ERR_ARG, "S=%d out of range", S);
+    if (S < 1 || S > 2 * CASV_MAX_T) return fail(CASV_ERR_ARG, "S=%d out of range 1..%d", S, 2 * CASV_MAX_T);
     HIPCHK(hipSetDevice(m->device));
     const int B = m->B, T = m->T;
     if (int rc = ensure_session(m, B, S)) return rc;
@@ -572,19 +572,22 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
                                 int32_t* n_found, int32_t* n_steps) {
     if (!m || !bp || !out_idx || !out_prob || !out_len || !out_score || !n_found) return fail(CASV_ERR_ARG, "null argument");
     if (!m->encoded) return fail(CASV_ERR_STATE, "casv_encode must run first");
-    const int N = bp->batch_size, CM = bp->beam_width_in + 1;
-    if (N < 1 || N > 256) return fail(CASV_ERR_ARG, "batch_size (hypotheses per step) %d out of range 1..256", N);
-    if (bp->beam_width_in < 1 || bp->beam_width_in > 63) return fail(CASV_ERR_ARG, "beam_width_in %d out of range 1..63", bp->beam_width_in);
-    if ((long long)N * CM > 4096) return fail(CASV_ERR_ARG, "batch_size * (beam_width_in + 1) = %d exceeds 4096", N * CM);
+    const int N = bp->batch_size;
+    if (N < 1 || N > CASV_MAX_BEAM_N) return fail(CASV_ERR_ARG, "batch_size (hypotheses per step) %d out of range 1..%d", N, CASV_MAX_BEAM_N);
+    if (bp->beam_width_in < 1) return fail(CASV_ERR_ARG, "beam_width_in %d must be positive", bp->beam_width_in);
+    // children per expansion: at most min(beam_width_in, V) inside the beam plus the rejection candidate beyond it
+    const int CM = (bp->beam_width_in < m->V ? bp->beam_width_in : m->V) + 1;
     if (bp->max_results < 1 || bp->max_results > 64) return fail(CASV_ERR_ARG, "max_results out of range 1..64");
-    if (S < 1 || S > 1024) return fail(CASV_ERR_ARG, "S=%d out of range", S);
+    if (S < 1 || S > 2 * CASV_MAX_T) return fail(CASV_ERR_ARG, "S=%d out of range 1..%d", S, 2 * CASV_MAX_T);
+    if (1LL + (long long)S * N * CM >= (1LL << 31) || (long long)(S + 1) * m->B * N >= (1LL << 31))
+        return fail(CASV_ERR_ARG, "search too large: S * batch_size * (beam_width_in + 1) nodes per line overflow int32 (decode fewer lines or steps per call)");
     HIPCHK(hipSetDevice(m->device));
     const int B = m->B, T = m->T, R = B * N, MR = bp->max_results;
     if (int rc = ensure_session(m, R, S)) return rc;
     if (int rc = init_root(m, N)) return rc;
     BeamState s{};
     s.B = B; s.T = T; s.V = m->V; s.S = S; s.R = R;
-    s.node_cap = 1 + S * N * CM; s.q_cap = 2 * T * N; s.f_cap = 64;
+    s.node_cap = 1 + S * N * CM; s.q_cap = 2 * T * N; s.f_cap = 64; s.g_cap = N * CM;
     const size_t NC = (size_t)B * s.node_cap;
 #define ENS(buf, bytes) if (int rc = (buf).ensure(bytes)) return rc;
     ENS(m->b_parent, NC * 4) ENS(m->b_chr, NC * 4) ENS(m->b_prob, NC * 4) ENS(m->b_cum, NC * 8) ENS(m->b_len, NC * 4)
@@ -594,6 +597,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     ENS(m->b_fkey, (size_t)B * s.f_cap * 8) ENS(m->b_fid, (size_t)B * s.f_cap * 4) ENS(m->b_fn, (size_t)B * 4) ENS(m->b_ftotal, (size_t)B * 4)
     ENS(m->b_beamnode, (size_t)R * 4) ENS(m->b_nact, (size_t)B * 4) ENS(m->b_done, (size_t)B * 4)
     ENS(m->b_steps, (size_t)B * 4) ENS(m->b_active, 16)
+    ENS(m->b_gkey, (size_t)2 * B * s.g_cap * 8) ENS(m->b_gid, (size_t)2 * B * s.g_cap * 4)
     const size_t OR = (size_t)B * MR;
     ENS(m->bo_idx, OR * S * 4) ENS(m->bo_prob, OR * S * 4) ENS(m->bo_len, OR * 4) ENS(m->bo_score, OR * 8) ENS(m->bo_rej, OR * S * 4)
     ENS(m->bo_found, (size_t)B * 4) ENS(m->bo_nsteps, (size_t)B * 4)
@@ -604,6 +608,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     s.n_rejpos = m->b_rejpos.as<int>(); s.n_pos = m->b_pos.as<double>(); s.n_is1 = m->b_is1.as<int>();
     s.n_count = m->b_count.as<int>(); s.created = m->b_created.as<short>();
     s.q_key = m->b_qkey.as<double>(); s.q_id = m->b_qid.as<int>(); s.q_n = m->b_qn.as<int>();
+    s.g_key = m->b_gkey.as<double>(); s.g_id = m->b_gid.as<int>();
     s.f_key = m->b_fkey.as<double>(); s.f_id = m->b_fid.as<int>(); s.f_n = m->b_fn.as<int>(); s.f_total = m->b_ftotal.as<int>();
     s.beam_node = m->b_beamnode.as<int>(); s.nact = m->b_nact.as<int>();
     s.line_done = m->b_done.as<int>(); s.line_steps = m->b_steps.as<int>(); s.active_lines = m->b_active.as<int>();
@@ -613,7 +618,6 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     BeamParams p{};
     p.N = N; p.width_in = bp->beam_width_in; p.width_out = bp->beam_width_out; p.max_results = MR;
     p.threshold_in = bp->beam_threshold_in; p.rejection = bp->rejection_threshold; p.cost0 = bp->cost0; p.eos = m->eos;
-    if ((long long)(S + 1) * R >= (1LL << 31)) return fail(CASV_ERR_ARG, "search too large: (S+1)*B*N overflows int32");
 
     // Tiles / rows without a live hypothesis are skipped by the step's kernels (their state is never read).  Worth the
     // extra load per workgroup from the start when a line's N rows span whole tiles (beams fill up over the first
@@ -660,9 +664,17 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     if (out_align) HIPCHK(hipMemcpyAsync(out_align, o.align, OR * S * T * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(n_found, o.n_found, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
     if (n_steps) HIPCHK(hipMemcpyAsync(n_steps, o.n_steps, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(&m->stat_beam_max_new, m->b_active.as<int>() + 1, 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->prof.on) m->prof.collect();
     return CASV_OK;
+}
+
+extern "C" int casv_get_stat(casv_model* m, const char* key, int64_t* value) {
+    if (!m || !key || !value) return fail(CASV_ERR_ARG, "null argument");
+    if (!strcmp(key, "beam_max_new_keys")) { *value = m->stat_beam_max_new; return CASV_OK; }
+    if (!strcmp(key, "beam_sort_capacity")) { *value = 4096; return CASV_OK; }
+    return fail(CASV_ERR_ARG, "unknown statistic '%s'", key);
 }
 
 extern "C" int casv_profile(casv_model* m, int32_t enable) {

@@ -217,5 +217,10 @@ class HipEngine(object):
     def set_option(self, key, value):
         nv.check(self.lib.casv_set_option(self.handle, key.encode(), int(value)))
 
+    def stat(self, key):
+        v = c_int64()
+        nv.check(self.lib.casv_get_stat(self.handle, key.encode(), byref(v)))
+        return v.value
+
     def synchronize(self):
         nv.check(self.lib.casv_synchronize(self.handle))

@@ -548,7 +548,9 @@ class Sequence2Sequence(object):
         # S x (lines x N) rows of h, c per layer, scores and alignments.  Large beams (the reference's default
         # batch_size = 256 hypotheses per step) are therefore decoded in chunks of lines that fit a memory budget;
         # lines are independent, so chunking does not change any result.
-        per_line = 2 * T * self.batch_size * (2 * self.depth * self.width + self.voc_size + 32 + T) * 4
+        # plus the trie: up to min(beam_width_in, V) + 1 child records of 60 bytes per expansion
+        children = min(self.beam_width_in, self.voc_size) + 1
+        per_line = 2 * T * self.batch_size * ((2 * self.depth * self.width + self.voc_size + 32 + T) * 4 + 60 * children)
         budget = float(os.environ.get('CASV_BEAM_MEMORY_GB', '96')) * 2 ** 30
         chunk = int(max(1, min(B, budget // max(per_line, 1))))
         results = [('', [], 0, []) for _ in range(B)]

@@ -10,7 +10,15 @@
  * Conventions: every function returns 0 on success and a negative casv_status otherwise;
  * the message is available from casv_last_error() (thread-local).  The caller owns all
  * host buffers (C-contiguous, float32 / int32 / float64 as declared); the library owns
- * all device memory and its HIP stream.  A handle is bound to one HIP device and is not
+ * all device memory and its HIP stream.
+ *
+ * Limits (CASV_ERR_ARG beyond them; the reference itself has none but host memory): depth 1..8, width a
+ * multiple of 32, vocabulary 2..4096, line length T <= 4096 positions (decode steps S <= 2T <= 8192),
+ * hypotheses per line and step (batch_size) <= 1024, beam_width_in >= 1 (values above the vocabulary size act like
+ * the vocabulary size), at most 64 results per line, and S * batch_size * (min(beam_width_in, V) + 1) < 2^31
+ * hypotheses per line.  A search keeps every expansion's state on the device: casv_decode_beam needs about
+ * 2T * batch_size * (8 * depth * width + 4 * (V + T) + 60 * (beam_width_in + 1)) bytes per line
+ * (CASV_ERR_NOMEM if the device cannot hold them -- decode fewer lines per call; the Python facade does that).  A handle is bound to one HIP device and is not
  * thread-safe (the reference runs single-threaded: wrapper/transcode.py:46 max_workers=1).
  * No C++ exceptions and no callbacks cross this boundary.
  */
@@ -158,6 +166,10 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
  * "tile" (process-wide; alias "skinny") = tile shape of the GEMM launches: -1 by size (default), 0 always 128x128,
  * 1 always 32x128 -- a measurement/test switch, the values computed are the same bit for bit. */
 int casv_set_option(casv_model* m, const char* key, int64_t value);
+/* Statistics of the last call (tests): "beam_max_new_keys" = most child hypotheses one line created in one search
+ * iteration of the last casv_decode_beam; "beam_sort_capacity" = how many of them are sorted in LDS at once (more are
+ * sorted in runs and merged by rank). */
+int casv_get_stat(casv_model* m, const char* key, int64_t* value);
 int casv_synchronize(casv_model* m);
 
 #ifdef __cplusplus

@@ -170,9 +170,11 @@ def test_argument_errors_are_reported():
     _, idx = make_lines(2, 5, 1, voc_size=16)
     eng.encode(idx)
     with pytest.raises(NativeError):
-        eng.decode_beam(batch_size=300)             # N out of range
+        eng.decode_beam(batch_size=1025)            # N out of range
     with pytest.raises(NativeError):
-        eng.decode_beam(batch_size=256, beam_width_in=50)    # N * (width + 1) > 4096
+        eng.decode_beam(batch_size=4, beam_width_in=0)
+    res = eng.decode_beam(batch_size=256, beam_width_in=50)    # the reference's test settings: legal (tests/test_gpu_limits.py)
+    assert res['n_steps'].max() <= 12
     eng.close()
 
 
@@ -227,6 +229,49 @@ def test_graph_replay_equals_eager():
     assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])
     for k in ('idx', 'len', 'score', 'n_found', 'n_steps'):
         assert np.array_equal(a[1][k], b[1][k])
+    eng.close()
+
+
+def test_decoder_step_at_full_width_rows():
+    """Three teacher-forced decoder steps at the metric's row count: R = 8192 rows (1024 lines x 8 hypotheses), depth 4,
+    width 512 -- the shape at which the launcher takes 128x128 tiles in XCD-aware order with the three-segment
+    [x | context | h] operand -- compared directly with the oracle (not via the 32x128 kernel)."""
+    cfg = ModelConfig(depth=4, width=512, voc_size=256)
+    weights = make_weights(cfg, emb_scale=32.0)
+    B, L, N = 1024, 20, 8
+    R, T, W, V = B * N, L + 1, cfg.width, cfg.voc_size
+    lines, idx = make_lines(B, L, 103)
+    eng = _engine(cfg, weights)
+    eng.encode(idx)
+    om = OracleModel(cfg, weights)
+    enc_in, _, _, _ = vectorize_lines(om, lines, [[] for _ in lines])
+    enc = om.encode(enc_in)
+    got_enc, got_states = eng.encoder_outputs()
+    assert np.allclose(got_enc, enc[0], rtol=RT, atol=AT)
+    rng = np.random.default_rng(8)
+    line = np.repeat(np.arange(B), N).astype(np.int32)
+    # every row has its own state: the line's encoder states plus a perturbation, a random input distribution and a
+    # random (normalised) alignment over a few neighbouring positions
+    states = [np.repeat(s, N, axis=0) + rng.normal(0, 0.1, (R, W)).astype(np.float32) for s in enc[1:-1]]
+    logits = rng.normal(0, 2.0, (R, V)).astype(np.float32)
+    p_in = np.exp(logits - logits.max(axis=1, keepdims=True)); p_in /= p_in.sum(axis=1, keepdims=True)
+    a_in = np.zeros((R, T), np.float32)
+    pos = rng.integers(0, T - 2, R)
+    for k in range(3):
+        a_in[np.arange(R), pos + k] = rng.random(R).astype(np.float32) + 0.1
+    a_in /= a_in.sum(axis=1, keepdims=True)
+    enc_rows = enc[0][line]
+    u_rows = enc_rows @ weights['att_U']
+    st_in = states + [a_in]
+    for s in range(3):
+        want_p, want_st = om.step(p_in, enc_rows, st_in, u=u_rows)
+        probs, st = eng.decoder_step(line, p_in, st_in[:-1], st_in[-1])
+        assert np.allclose(probs, want_p, rtol=RT, atol=AT), s
+        for n in range(2 * cfg.depth):
+            assert np.allclose(st[n], want_st[n], rtol=RT, atol=2 * AT), (s, n)
+        assert np.allclose(st[-1], want_st[-1], rtol=RT, atol=AT), s
+        assert (probs.argmax(axis=1) == want_p.argmax(axis=1)).mean() > 0.999
+        p_in, st_in = want_p, want_st
     eng.close()
 
 

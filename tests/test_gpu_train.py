@@ -191,3 +191,38 @@ def test_train_step_with_confidence_inputs():
         assert np.abs(gg[k] - grads[k]).max() < 2e-3 * scale + 1e-7, k
     eng.train_end()
     eng.close()
+
+
+def test_c4_full_size_step_equals_oracle(golden_dir):
+    """BASELINE configs[3] at full size (depth 4, width 512, V 256, 512 lines x 100 characters, dropout masks): the
+    shapes at which the launcher picks the 128x128 two-wave-group split-K recurrent GEMMs, the atomics split-K and the
+    whole-sequence weight-gradient GEMMs.  Expected values come from the oracle through a committed fixture
+    (tests/golden/make_c4_golden.py; the numpy oracle needs minutes for this step)."""
+    import os
+    from cor_asv_ann_amd.engine import HipEngine
+    from tests.golden.make_c4_golden import DEPTH, WIDTH, VOC, c4_inputs, sample_positions
+    with np.load(os.path.join(golden_dir, 'c4_train_step.npz')) as f:
+        g = {k: f[k] for k in f.files}
+    cfg = ModelConfig(depth=DEPTH, width=WIDTH, voc_size=VOC)
+    w = make_weights(cfg, emb_scale=4.0)
+    sidx, dec_in, dec_out, wts, masks = c4_inputs()
+    eng = HipEngine(DEPTH, WIDTH, VOC)
+    eng.set_weights(w)
+    eng.train_begin()
+    loss, norm = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
+    assert abs(loss - float(g['loss'])) < 2e-5 * abs(float(g['loss'])), (loss, float(g['loss']))
+    assert abs(norm - float(g['grad_norm'])) < 1e-4 * float(g['grad_norm']), (norm, float(g['grad_norm']))
+    grads = eng.train_gradients()
+    onorm = float(g['grad_norm'])
+    for k, got in grads.items():
+        flat = got.ravel()
+        want = g['sample/' + k]
+        scale = max(float(g['max/' + k]), 1e-6 * onorm)
+        assert np.abs(flat[sample_positions(k, flat.size)] - want).max() < 2e-3 * scale + 1e-7, k
+        tnorm = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        assert abs(tnorm - float(g['norm/' + k])) < 1e-3 * float(g['norm/' + k]) + 1e-6 * onorm, k
+    # a second evaluation of the same step: float atomics may reorder sums, nothing else may move
+    loss2, norm2 = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
+    assert abs(loss2 - loss) < 1e-6 * abs(loss) and abs(norm2 - norm) < 1e-5 * norm
+    eng.train_end()
+    eng.close()
