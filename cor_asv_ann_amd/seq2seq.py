@@ -729,15 +729,10 @@ class Sequence2Sequence(object):
                  confusion=10, histogram=True):
         """Character/word error rates of source (OCR), greedy and beamed output against the target (seq2seq.py:651-754).
 
-        The decoding runs here; the metrics are the reference's own `Alignment` / `Edits` / `splitwords`
-        (`ocrd_cor_asv_ann/lib/alignment.py`, outside the path this package replaces): they are imported from the
-        reference package, which a drop-in installation has."""
+        Decoding runs on the device; alignment, normalisation and the running statistics are this package's own
+        (`metrics.py`, restating lib/alignment.py:140-486) -- nothing is imported from the reference."""
         assert self.status == 2
-        try:
-            from ocrd_cor_asv_ann.lib.alignment import Alignment, Edits, splitwords
-        except ImportError as err:
-            raise NotImplementedError('evaluate() needs the reference\'s metrics (ocrd_cor_asv_ann.lib.alignment: Alignment, '
-                                      'Edits, splitwords), which this package does not replace: %s' % err)
+        from .metrics import Alignment, Edits, splitwords
         names = ('origin', 'greedy', 'beamed')
         c_counts = {k: Edits(self.logger, histogram=histogram) for k in names}
         w_counts = {k: Edits(self.logger) for k in names}
@@ -782,7 +777,7 @@ class Sequence2Sequence(object):
             self.logger.info('ppl %s: %.3f', k, math.exp(c_counts[k].score / max(c_counts[k].length, 1)))
         for what, counts in (('CER', c_counts), ('WER', w_counts)):
             for k in names:
-                self.logger.info('%s %s: %.3f±%.3f', what, labels[k].strip(), counts[k].mean, math.sqrt(counts[k].varia))
+                self.logger.info('%s %-7s %.3f±%.3f', what, labels[k].strip() + ':', counts[k].mean, math.sqrt(counts[k].varia))
 
     def train(self, filenames, val_filenames=None):
         from .training import train_files
