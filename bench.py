@@ -289,7 +289,7 @@ def decode_bench(args):
         lut = s2s._codepoint_lut()
 
         def decode(chunk):
-            out, probs, scores, _ = s2s.correct_lines(chunk, fast=wl['fast'], greedy=wl['fast'], alignments=False)
+            out, probs, scores, al = s2s.correct_lines(chunk, fast=wl['fast'], greedy=wl['fast'], alignments=bool(args.alignments))
             return out, probs, scores
         sync_dev = eng.synchronize
     t_gather = [0.0]
@@ -363,7 +363,7 @@ def decode_bench(args):
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'dry-run (no decoding)' if dry else 'synthetic',
             'config': {'workload': wl['text'] + ', 2T=%d steps max, synthetic weights seed 20250614 emb_scale=%g' % (S, wl['emb']),
                        'lines_per_gpu': per_gpu, 'lines_per_decode_call': batch, 'line_length': LENGTH, 'beam_n': wl['n'],
-                       'parallelism': 'lines sharded x%d' % world, 'graph': bool(args.graph),
+                       'parallelism': 'lines sharded x%d' % world, 'graph': bool(args.graph), 'alignments': bool(args.alignments),
                        'launcher': 'bench.py' if os.environ.get('CASV_BENCH_CHILD') else
                                    ('torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ else 'direct')},
             'ms_per_step_by_rank': [1e3 * x / args.steps for x in per_rank],
@@ -416,6 +416,8 @@ def main():
                     help='c3 = beamed decode (the BASELINE metric, default); c2 = greedy decode (configs[1]); '
                          'c4 = train step (configs[3]); c5 = 8192 lines per GPU per step (configs[4])')
     ap.add_argument('--lines-per-gpu', type=int, default=0, help='override the lines each GPU decodes per step')
+    ap.add_argument('--alignments', type=int, default=0,
+                    help='1 = also return the soft alignments (window form), as the OCR-D processor asks for (wrapper/transcode.py:110-115)')
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error('--gpus must be positive')

@@ -39,7 +39,7 @@ __global__ void beam_init_kernel(const BeamState s, const BeamParams p) {
         s.f_n[line] = 0; s.f_total[line] = 0;
         s.nact[line] = 1; s.line_done[line] = 0; s.line_steps[line] = 0;
         s.beam_node[line * N] = 0;
-        if (line == 0) { s.active_lines[0] = s.B; s.active_lines[1] = 0; }
+        if (line == 0) { s.active_lines[0] = s.B; s.active_lines[1] = 0; s.active_lines[2] = 0; s.active_lines[3] = 0; }
     }
     for (int i = threadIdx.x; i < N; i += blockDim.x) s.prev[line * N + i] = line * N;
     for (int i = threadIdx.x; i < N * Vp; i += blockDim.x) s.p_in[(long long)line * N * Vp + i] = 0.f;
@@ -372,6 +372,16 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
         if (ftot != s.f_total[line]) { s.f_n[line] = fn; s.f_total[line] = ftot; }
         s.q_n[line] = qn - h; s.q_n[s.B + line] = h;
         sh_nb = nb; sh_done = done;
+        if (!done && N <= 16) {       // statistic: rows of the next step and how many different parent expansions they continue
+            int distinct = 0;
+            for (int a = 0; a < nb; ++a) {
+                const int ea = s.n_exp[nbase + r_count[a]];
+                bool seen = false;
+                for (int b = 0; b < a; ++b) seen |= s.n_exp[nbase + r_count[b]] == ea;
+                distinct += seen ? 0 : 1;
+            }
+            atomicAdd(s.active_lines + 2, nb); atomicAdd(s.active_lines + 3, distinct);
+        }
         if (done) { s.line_done[line] = 1; s.nact[line] = 0; atomicSub(s.active_lines, 1); }
         else s.nact[line] = nb;
     }
@@ -460,6 +470,49 @@ __global__ void beam_extract_kernel(const BeamState s, const BeamParams p, const
         }
     }
 }
+// The same walk for the window form of the alignments: a rejection step is the one-hot row at its source position
+// (seq2seq.py:1495), every other step the window the attention kernel recorded for the node's expansion.
+__global__ void beam_extract_sparse_kernel(const BeamState s, const BeamParams p, const BeamOut o, const SparseAlignOut sp) {
+    extern __shared__ int chain[];
+    const int line = blockIdx.x / p.max_results, k = blockIdx.x % p.max_results;
+    const int tid = threadIdx.x;
+    const long long nbase = (long long)line * s.node_cap;
+    const long long ob = (long long)blockIdx.x;
+    if (k >= s.f_n[line]) return;
+    const int fnode = s.f_id[(long long)line * s.f_cap + k];
+    const int len = s.n_len[nbase + fnode] - 1;
+    if (tid == 0) {
+        int cur = fnode;
+        for (int j = len - 1; j >= 0; --j) { if (j < s.S) chain[j] = cur; cur = s.n_parent[nbase + cur]; }
+    }
+    __syncthreads();
+    for (int j = tid; j < len && j < s.S; j += blockDim.x) {
+        const int nd = chain[j];
+        const int rp = s.n_rejpos[nbase + nd];
+        const long long exp = s.n_exp[nbase + nd];
+        float* w = sp.w + (ob * s.S + j) * sp.K;
+        int lo;
+        if (rp >= 0) {
+            lo = rp;
+            for (int q = 0; q < sp.K; ++q) w[q] = q == 0 ? 1.0f : 0.0f;
+        } else {
+            const int win = sp.win_store[exp];
+            if (win < 0) {
+                lo = -1;
+                for (int q = 0; q < sp.K; ++q) w[q] = __builtin_nanf("");
+            } else {
+                lo = win & 0xffff;
+                const int cnt = win >> 16;
+                for (int q = 0; q < sp.K; ++q) w[q] = (q < cnt && lo + q < s.T) ? o.a_base[exp * s.T + lo + q] : 0.0f;
+            }
+        }
+        sp.lo[ob * s.S + j] = lo;
+    }
+}
+void launch_beam_extract_sparse(const BeamState& s, const BeamParams& p, const BeamOut& o, const SparseAlignOut& sp, hipStream_t stream) {
+    hipLaunchKernelGGL(beam_extract_sparse_kernel, dim3(s.B * p.max_results), dim3(256), (size_t)s.S * 4, stream, s, p, o, sp);
+}
+
 void launch_beam_extract(const BeamState& s, const BeamParams& p, const BeamOut& o, hipStream_t stream) {
     hipLaunchKernelGGL(beam_extract_kernel, dim3(s.B * p.max_results), dim3(256), (size_t)s.S * 4, stream, s, p, o);
 }

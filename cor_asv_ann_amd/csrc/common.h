@@ -124,6 +124,7 @@ struct AttnArgs {
     int nact_group;
     long long u_line, u_time, enc_line, enc_time;   // element strides of u / enc by line and by position
     int* win_out;           // optional [R]: window of this step, s_lo | cnt << 16 (train step backward)
+    int* win_store;         // optional [(S+1)*R]: the same per output slot (decode: sparse form of the alignment store)
 };
 void launch_attention(const AttnArgs& a, hipStream_t stream);
 
@@ -196,5 +197,9 @@ struct BeamOut {
     const float* a_base;
 };
 void launch_beam_extract(const BeamState& s, const BeamParams& p, const BeamOut& o, hipStream_t stream);
+// Window form of the alignments: (lo, K weights) per result row and step; lo = -1 marks an all-NaN row.
+struct SparseAlignOut { int* lo; float* w; int K; const int* win_store; };
+void launch_beam_extract_sparse(const BeamState& s, const BeamParams& p, const BeamOut& o, const SparseAlignOut& sp, hipStream_t stream);
+void launch_greedy_extract_sparse(const float* a_base, const int* win_store, int B, int S, int T, const SparseAlignOut& sp, hipStream_t stream);
 
 }  // namespace casv

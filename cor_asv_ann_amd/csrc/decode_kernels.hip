@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs
         if (a.apos) a.apos[r] = cnt <= 0 ? (double)nanv : pos;
         if (a.amax1) a.amax1[r] = (amax == 1.0f) ? 1 : 0;
         if (a.win_out) a.win_out[r] = cnt > 0 ? (s_lo | (cnt << 16)) : 0;
+        if (a.win_store) a.win_store[(long long)(step + 1) * a.R + r] = cnt > 0 ? (s_lo | (cnt << 16)) : -1;
     }
 }
 
@@ -222,6 +223,29 @@ __global__ __launch_bounds__(128) void embed_sparse_kernel(const float* __restri
 void launch_embed_sparse(const float* E, const int* idx, const float* val, float* x0, int rows, int A,
                          int V, int W, hipStream_t stream) {
     hipLaunchKernelGGL(embed_sparse_kernel, dim3(rows), dim3(128), 0, stream, E, idx, val, x0, rows, A, V, W);
+}
+
+// (lo, K weights) of decode step s of line b from the alignment store (slot s+1, row b) -- decode_batch_greedy's
+// per-step alignments (seq2seq.py:1249,1262) without the T-wide rows
+__global__ void greedy_extract_sparse_kernel(const float* a_base, const int* win_store, int B, int S, int T, SparseAlignOut sp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (b, s)
+    if (i >= B * S) return;
+    const int b = i / S, s = i % S;
+    const long long slot = (long long)(s + 1) * B + b;
+    const int win = win_store[slot];
+    float* w = sp.w + (long long)i * sp.K;
+    if (win < 0) {
+        sp.lo[i] = -1;
+        for (int k = 0; k < sp.K; ++k) w[k] = __builtin_nanf("");
+        return;
+    }
+    const int lo = win & 0xffff, cnt = win >> 16;
+    sp.lo[i] = lo;
+    for (int k = 0; k < sp.K; ++k) w[k] = (k < cnt && lo + k < T) ? a_base[slot * T + lo + k] : 0.0f;
+}
+void launch_greedy_extract_sparse(const float* a_base, const int* win_store, int B, int S, int T, const SparseAlignOut& sp,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(greedy_extract_sparse_kernel, dim3((B * S + 255) / 256), dim3(256), 0, stream, a_base, win_store, B, S, T, sp);
 }
 
 __global__ void advance_step_kernel(int* step_ptr) { *step_ptr += 1; }

@@ -101,7 +101,10 @@ struct casv_model {
     int R = 0, S = 0;
     std::vector<DevBuf> st_h, st_c;
     DevBuf st_a, st_p, ctx, wq, logits, prev, pin, apos, amax1, d_step, d_line, d_nan;
-    DevBuf o_idx, o_prob, o_align;
+    DevBuf o_idx, o_prob, o_align, st_win, sp_lo, sp_w;
+    // what the last decode call left on the device (casv_get_alignments_sparse): 0 nothing, 1 greedy, 2 beam
+    int last_decode = 0, last_S = 0, last_rows = 0;
+    BeamState last_beam{}; BeamParams last_beam_params{};
     // beam
     DevBuf b_parent, b_chr, b_prob, b_cum, b_len, b_exp, b_k, b_rejpos, b_pos, b_is1, b_count, b_created;
     DevBuf b_gkey, b_gid, b_qkey, b_qid, b_qn, b_fkey, b_fid, b_fn, b_ftotal, b_beamnode, b_nact, b_done, b_steps, b_active;
@@ -113,7 +116,8 @@ struct casv_model {
     bool use_graph = false;
     const int* skip_nact = nullptr;                       // beam decode: live rows per line, handed to the step's kernels when
     int skip_group = 0;                                   // skipping can pay (wide beams, or a line has finished); rows per line
-    int stat_beam_max_new = 0;                            // last beam decode: most new hypotheses of one line in one step
+    int stat_beam[3] = {0, 0, 0};                         // last beam decode: most new hypotheses of one line in one step; rows stepped
+                                                          // and distinct parent expansions among them (N <= 16 only)
     Prof prof;
 
     void prof_begin(int cls, double fl, double by, hipEvent_t& a) {

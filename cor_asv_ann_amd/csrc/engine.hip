@@ -63,7 +63,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     DevBuf* bufs[] = {&m->E, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
         &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->Hc, &m->cfin,
         &m->hfin, &m->u, &m->st_a, &m->st_p, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
-        &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->b_parent, &m->b_chr, &m->b_prob,
+        &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->st_win, &m->sp_lo, &m->sp_w, &m->b_parent, &m->b_chr, &m->b_prob,
         &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos, &m->b_pos, &m->b_is1, &m->b_count, &m->b_created,
         &m->b_gkey, &m->b_gid, &m->b_qkey, &m->b_qid, &m->b_qn, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_beamnode, &m->b_nact,
         &m->b_done, &m->b_steps, &m->b_active, &m->bo_idx, &m->bo_prob, &m->bo_len, &m->bo_score,
@@ -209,6 +209,7 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
     HIPCHK(hipEventRecord(m->ev_inputs, m->stream));
     HIPCHK(hipEventSynchronize(m->ev_inputs));
     m->B = B; m->T = T; m->A = A;
+    m->last_decode = 0;
 
     hipEvent_t ev{};
     m->prof_begin(PC_EMBED, 2.0 * BT * A * W, 4.0 * BT * W * (A + 1), ev);
@@ -323,6 +324,7 @@ static int ensure_session(casv_model* m, int R, int S) {
     }
     if (int rc = m->st_a.ensure(slots * T * 4)) return rc;
     if (int rc = m->st_p.ensure(slots * Vp * 4)) return rc;
+    if (int rc = m->st_win.ensure(slots * 4)) return rc;
     if (int rc = m->ctx.ensure((size_t)R * C * 4)) return rc;
     if (int rc = m->wq.ensure((size_t)R * W * 4)) return rc;
     if (int rc = m->logits.ensure((size_t)R * Vp * 4)) return rc;
@@ -409,6 +411,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         a.ctx = m->ctx.as<float>(); a.R = R; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
         a.step_ptr = step_ptr; a.step_imm = step_imm; a.apos = m->apos.as<double>(); a.amax1 = m->amax1.as<int>(); a.nrows = nullptr;
         a.u_line = (long long)T * W; a.u_time = W; a.enc_line = (long long)T * C; a.enc_time = C; a.win_out = nullptr;
+        a.win_store = m->st_win.as<int>();
         a.nact = live; a.nact_group = m->skip_group;
         hipEvent_t ev{};
         const double win = 2.0 * m->cfg.window_width + 1;
@@ -562,6 +565,7 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
         HIPCHK(hipStreamSynchronize(m->stream));
     }
     if (m->prof.on) m->prof.collect();
+    m->last_decode = 1; m->last_S = S; m->last_rows = B;
     (void)nanflag;
     if (nan_before_end && mode == 1) return fail(CASV_ERR_NAN, "All-NaN slice encountered");
     return CASV_OK;
@@ -664,15 +668,43 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     if (out_align) HIPCHK(hipMemcpyAsync(out_align, o.align, OR * S * T * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(n_found, o.n_found, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
     if (n_steps) HIPCHK(hipMemcpyAsync(n_steps, o.n_steps, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(&m->stat_beam_max_new, m->b_active.as<int>() + 1, 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(m->stat_beam, m->b_active.as<int>() + 1, 12, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->prof.on) m->prof.collect();
+    m->last_decode = 2; m->last_S = S; m->last_rows = (int)OR; m->last_beam = s; m->last_beam_params = p;
+    return CASV_OK;
+}
+
+extern "C" int casv_get_alignments_sparse(casv_model* m, int32_t K, int32_t* out_lo, float* out_w) {
+    if (!m || !out_lo || !out_w) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->last_decode) return fail(CASV_ERR_STATE, "no decode call to take alignments from");
+    if (K < 2 * m->cfg.window_width + 1 || K > 64) return fail(CASV_ERR_ARG, "K=%d: need at least 2*window_width+1 = %d weights per step (at most 64)", K, 2 * m->cfg.window_width + 1);
+    HIPCHK(hipSetDevice(m->device));
+    const size_t n = (size_t)m->last_rows * m->last_S;
+    if (int rc = m->sp_lo.ensure(n * 4)) return rc;
+    if (int rc = m->sp_w.ensure(n * K * 4)) return rc;
+    SparseAlignOut sp{m->sp_lo.as<int>(), m->sp_w.as<float>(), K, m->st_win.as<int>()};
+    if (m->last_decode == 1) {
+        launch_greedy_extract_sparse(m->st_a.as<float>(), m->st_win.as<int>(), m->last_rows, m->last_S, m->T, sp, m->stream);
+    } else {
+        HIPCHK(hipMemsetAsync(sp.lo, 0, n * 4, m->stream));
+        HIPCHK(hipMemsetAsync(sp.w, 0, n * K * 4, m->stream));
+        BeamOut o{};
+        o.a_base = m->st_a.as<float>();
+        launch_beam_extract_sparse(m->last_beam, m->last_beam_params, o, sp, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_lo, sp.lo, n * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(out_w, sp.w, n * K * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
     return CASV_OK;
 }
 
 extern "C" int casv_get_stat(casv_model* m, const char* key, int64_t* value) {
     if (!m || !key || !value) return fail(CASV_ERR_ARG, "null argument");
-    if (!strcmp(key, "beam_max_new_keys")) { *value = m->stat_beam_max_new; return CASV_OK; }
+    if (!strcmp(key, "beam_max_new_keys")) { *value = m->stat_beam[0]; return CASV_OK; }
+    if (!strcmp(key, "beam_rows")) { *value = m->stat_beam[1]; return CASV_OK; }
+    if (!strcmp(key, "beam_distinct_parents")) { *value = m->stat_beam[2]; return CASV_OK; }
     if (!strcmp(key, "beam_sort_capacity")) { *value = 4096; return CASV_OK; }
     return fail(CASV_ERR_ARG, "unknown statistic '%s'", key);
 }

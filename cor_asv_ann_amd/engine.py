@@ -48,6 +48,7 @@ class HipEngine(object):
         self.lib = nv.load()
         self.depth, self.width, self.voc_size = int(depth), int(width), int(voc_size)
         self.ctx_width = 2 * self.width if self.depth == 1 else self.width
+        self.window_width = int(window_width)
         cfg = nv.Config(self.depth, self.width, self.voc_size, int(window_width), int(bool(residual_connections)),
                         int(bool(deep_bidirectional_encoder)), int(bool(bridge_dense)), int(bool(lm)),
                         int(bool(stateful)))
@@ -135,9 +136,12 @@ class HipEngine(object):
         idx = np.empty((self.B, S), np.int32)
         prob = np.empty((self.B, S), np.float32)
         length = np.empty((self.B,), np.int32)
-        align = np.empty((self.B, S, self.T), np.float32) if want_align else None
+        sparse = want_align == 'sparse'        # (lo, w) windows instead of (B, S, T) rows
+        align = np.empty((self.B, S, self.T), np.float32) if want_align and not sparse else None
         nv.check(self.lib.casv_decode_greedy(self.handle, int(mode), S, nv.ptr(idx), nv.ptr(prob), nv.ptr(length),
                                              nv.ptr(align)))
+        if sparse:
+            align = self.alignments_sparse(self.B, S)
         return idx, prob, length, align
 
     def decode_beam(self, batch_size=8, beam_width_in=15, beam_threshold_in=0.2, beam_width_out=16,
@@ -150,11 +154,13 @@ class HipEngine(object):
         out = {'idx': np.empty((n, S), np.int32), 'prob': np.empty((n, S), np.float32),
                'len': np.empty((n,), np.int32), 'score': np.empty((n,), np.float64),
                'rej': np.empty((n, S), np.int32),
-               'align': np.empty((n, S, self.T), np.float32) if want_align else None,
+               'align': np.empty((n, S, self.T), np.float32) if want_align and want_align != 'sparse' else None,
                'n_found': np.empty((self.B,), np.int32), 'n_steps': np.empty((self.B,), np.int32)}
         nv.check(self.lib.casv_decode_beam(self.handle, byref(p), S, nv.ptr(out['idx']), nv.ptr(out['prob']),
                                            nv.ptr(out['len']), nv.ptr(out['score']), nv.ptr(out['rej']),
                                            nv.ptr(out['align']), nv.ptr(out['n_found']), nv.ptr(out['n_steps'])))
+        if want_align == 'sparse':
+            out['align_sparse'] = self.alignments_sparse(n, S)
         return out
 
     # -- training ------------------------------------------------------------------------------
@@ -216,6 +222,14 @@ class HipEngine(object):
 
     def set_option(self, key, value):
         nv.check(self.lib.casv_set_option(self.handle, key.encode(), int(value)))
+
+    def alignments_sparse(self, rows, steps, K=None):
+        """Window form of the last decode call's soft alignments: (lo int32 (rows, S), w float32 (rows, S, K))."""
+        K = int(K or 2 * self.window_width + 1)
+        lo = np.empty((rows, steps), np.int32)
+        w = np.empty((rows, steps, K), np.float32)
+        nv.check(self.lib.casv_get_alignments_sparse(self.handle, K, nv.ptr(lo), nv.ptr(w)))
+        return lo, w
 
     def stat(self, key):
         v = c_int64()

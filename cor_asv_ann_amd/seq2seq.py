@@ -21,6 +21,7 @@ from . import GAP
 from . import _native as nv
 from . import hdf5, keras_h5
 from .engine import HipEngine, weight_shapes
+from .realign import SparseAlignment
 
 _UNSUPPORTED = ('residual_connections', 'deep_bidirectional_encoder', 'bridge_dense', 'lm_loss',
                 'lm_predict', 'scheduled_sampling', 'stateful')
@@ -447,8 +448,18 @@ class Sequence2Sequence(object):
             probs.append(list(p))
             with np.errstate(divide='ignore'):
                 scores.append(float(np.sum(-np.log(p), dtype=np.float64)) / n)
-            aligns.append([align[j, k] for k in range(n)] if align is not None else [])
+            aligns.append(self._alignment_rows(align, j, n))
         return lines, probs, scores, aligns
+
+    def _alignment_rows(self, align, j, n):
+        """Alignment of result row j, first n steps: a SparseAlignment view over the window form, the reference's list
+        of T-wide rows for a dense array, [] when alignments were not requested."""
+        if align is None:
+            return []
+        if isinstance(align, tuple):
+            lo, w = align
+            return SparseAlignment(lo[j, :n], w[j, :n], self.engine.T)
+        return [align[j, k] for k in range(n)]
 
     def decode_batch_greedy(self, encoder_input_data):
         """seq2seq.py:1215-1286: all lines at once, 2T steps, argmax without index 0, soft feedback.
@@ -475,9 +486,9 @@ class Sequence2Sequence(object):
         eng.encode(idx, val)
         return self._sequence_greedy_results(eng, 1)[0]
 
-    def _sequence_greedy_results(self, eng, B):
+    def _sequence_greedy_results(self, eng, B, want_align=True):
         try:
-            gi, gp, gl, ga = eng.decode_greedy(mode=1, want_align=True)
+            gi, gp, gl, ga = eng.decode_greedy(mode=1, want_align=want_align)
         except nv.NativeError as err:
             if err.code == nv.CASV_ERR_NAN:
                 raise ValueError('All-NaN slice encountered')   # what np.nanargmax raises, seq2seq.py:1335
@@ -488,7 +499,7 @@ class Sequence2Sequence(object):
             p = gp[j, :n]
             with np.errstate(divide='ignore', invalid='ignore'):
                 score = float(np.sum(-np.log(p), dtype=np.float64)) / n
-            out.append((self._chars(gi[j, :n]), list(p), score, [ga[j, k] for k in range(n)]))
+            out.append((self._chars(gi[j, :n]), list(p), score, self._alignment_rows(ga, j, n)))
         return out
 
     def _beam_results(self, res, j, max_results, T):
@@ -497,7 +508,7 @@ class Sequence2Sequence(object):
             n = int(res['len'][r])
             if n == 0:
                 return
-            aligns = [res['align'][r, s] for s in range(n)] if res['align'] is not None else []
+            aligns = self._alignment_rows(res.get('align_sparse', res['align']), r, n)
             yield (self._chars(res['idx'][r, :n]), res['prob'][r, :n].tolist(), float(res['score'][r]), aligns)
 
     def _beam_kwargs(self):
@@ -520,18 +531,22 @@ class Sequence2Sequence(object):
 
     def correct_lines(self, lines, conf=None, fast=True, greedy=True, alignments=True):
         """seq2seq.py:782-842.  Each line must end in a newline.  Returns (lines, probability lists,
-        scores, alignments).  `alignments=False` (an extension) skips copying the soft alignments."""
+        scores, alignments).  The alignment of a line is a `SparseAlignment`: a list-like view (`alignment[j][i]`, `len`,
+        iteration, `numpy.asarray`) over the window form the device returns -- 12 instead of T floats per character cross
+        PCIe, and `realign.alignment2path` consumes the windows directly.  Extensions: `alignments=False` skips the soft
+        alignments altogether, `alignments='dense'` returns the reference's lists of T-wide numpy rows."""
         assert not fast or greedy, "cannot decode in fast mode with beam search enabled"
         if not lines:
             return [], [], [], []
         eng = self._require_engine()
+        want_align = False if not alignments else (True if alignments == 'dense' else 'sparse')
         idx, val, _ = self._sparse_lines(lines, conf)
         B, T = idx.shape[:2]
         if T == 0:                  # nothing but padding lines
             return self._finish(lines, [('', [], 0, []) for _ in range(B)])
         if fast:
             eng.encode(idx, val)
-            gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=alignments)
+            gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=want_align)
             nonpad = ((idx >= 0) & (val != 0)).any(axis=(1, 2))     # np.any(encoder_input_data[j]), seq2seq.py:1255
             return self._greedy_results(gi, gp, ga, nonpad)
         # the per-line modes never decode the empty padding lines of a partial batch (seq2seq.py:815-816) -- an
@@ -541,7 +556,7 @@ class Sequence2Sequence(object):
             results = [('', [], 0, []) for _ in range(B)]
             if live:
                 eng.encode(idx[live], val[live])
-                for j, r in zip(live, self._sequence_greedy_results(eng, len(live))):
+                for j, r in zip(live, self._sequence_greedy_results(eng, len(live), want_align)):
                     results[j] = r
             return self._finish(lines, results)
         # The search keeps every expansion's state on the device (nothing is recomputed, nothing crosses to the host):
@@ -557,7 +572,7 @@ class Sequence2Sequence(object):
         for lo in range(0, len(live), chunk):
             rows = live[lo:lo + chunk]
             eng.encode(idx[rows], val[rows])
-            res = eng.decode_beam(max_results=1, want_align=alignments, **self._beam_kwargs())
+            res = eng.decode_beam(max_results=1, want_align=want_align, **self._beam_kwargs())
             for k, j in enumerate(rows):
                 input_line = lines[j]
                 item = next(self._beam_results(res, k, 1, T), None)
@@ -570,7 +585,8 @@ class Sequence2Sequence(object):
                         line = ''.join(chunk_[0][0] if chunk_ else '' for chunk_ in input_line)
                     else:
                         line = input_line
-                    item = (line, [1.0] * len(line), 0, self._identity_alignment(len(line)) if alignments else [])
+                    item = (line, [1.0] * len(line), 0, [] if not alignments else
+                            (self._identity_alignment(len(line)) if alignments == 'dense' else SparseAlignment.identity(len(line))))
                 results[j] = item
         return self._finish(lines, results)
 

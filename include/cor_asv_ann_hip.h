@@ -119,6 +119,15 @@ int casv_decode_beam(casv_model* m, const casv_beam_params* p, int32_t S,
                      int32_t* out_idx, float* out_prob, int32_t* out_len, double* out_score,
                      int32_t* out_rej, float* out_align, int32_t* n_found, int32_t* n_steps);
 
+/* The soft alignments of the LAST casv_decode_greedy / casv_decode_beam call in window form, for the post-decode
+ * re-alignment of wrapper/transcode.py:126,279-349 (which skips entries <= 1/V anyway, transcode.py:316): the attention
+ * of attention.py:553-571 is zero outside a window of <= 2*window_width+1 positions, so step s of result row n is
+ * out_lo[n*S+s] = first position of the window (-1: the row is all NaN, the window fell off the line) and
+ * out_w[(n*S+s)*K + k] = weight at position lo+k (zeros beyond the window; a rejection step of the beam is the one-hot
+ * row at its source position, seq2seq.py:1495).  Rows and S as in the decode call (greedy: B rows; beam: B*max_results;
+ * steps beyond a result's length are zero).  12 instead of T floats per step cross PCIe.  K >= 2*window_width+1. */
+int casv_get_alignments_sparse(casv_model* m, int32_t K, int32_t* out_lo, float* out_w);
+
 /* Adam(clipnorm) of seq2seq.py:496 (Keras defaults: lr 1e-3, beta 0.9/0.999, epsilon 1e-7, clipnorm 5). */
 typedef struct {
     float lr, beta1, beta2, epsilon, clipnorm;
@@ -168,7 +177,8 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 /* Statistics of the last call (tests): "beam_max_new_keys" = most child hypotheses one line created in one search
  * iteration of the last casv_decode_beam; "beam_sort_capacity" = how many of them are sorted in LDS at once (more are
- * sorted in runs and merged by rank). */
+ * sorted in runs and merged by rank); "beam_rows" / "beam_distinct_parents" = hypothesis rows stepped after the first
+ * iteration and the number of different parent expansions they continue (siblings share a parent; batch_size <= 16). */
 int casv_get_stat(casv_model* m, const char* key, int64_t* value);
 int casv_synchronize(casv_model* m);
 

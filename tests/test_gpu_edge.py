@@ -126,3 +126,38 @@ def test_vocabulary_growth_keeps_the_trained_rows(tmp_path):
     om2 = OracleModel(cfg, new, mapping=s2s.mapping, batch_size=2)
     want = correct_lines(om2, [line, line[:-1] + 'λ\n'], fast=True, greedy=True)
     assert after[0] == want[0] and len(before[0]) == 1
+
+
+def test_sparse_alignments_equal_dense_and_feed_the_realignment():
+    """f3: `correct_lines` returns the soft alignments in window form (SparseAlignment).  Rows materialise to exactly
+    the dense rows (all three decode modes, incl. rejection steps of the beam = one-hot rows), the Viterbi path of
+    wrapper/transcode.py:279-349 computed on the windows equals the dense cell-by-cell restatement on the dense rows,
+    and 12 instead of T floats per character cross PCIe."""
+    from cor_asv_ann_amd.realign import SparseAlignment, alignment2path
+    from oracle.realign import alignment2path as oracle_path
+    om, s2s = _pair(2, 64, 96, es=12.0, batch_size=4)
+    cfg = om.cfg
+    lines, _ = make_lines(6, 30, 31, voc_size=96)
+    lines[2] = lines[2][:9] + '\n'
+    for fast, greedy in ((True, True), (False, False), (False, True)):
+        try:
+            dense = s2s.correct_lines(lines, fast=fast, greedy=greedy, alignments='dense')
+        except ValueError:
+            continue                                    # per-line greedy: index 0 won a step (the reference raises too)
+        sparse = s2s.correct_lines(lines, fast=fast, greedy=greedy)
+        assert dense[0] == sparse[0]
+        for j, line in enumerate(lines):
+            sp, de = sparse[3][j], dense[3][j]
+            assert isinstance(sp, SparseAlignment) and len(sp) == len(de) == len(sparse[0][j])
+            if len(de):
+                assert np.array_equal(np.asarray(sp), np.asarray(de), equal_nan=True), (fast, greedy, j)
+                assert sp.w.shape[1] == 11 and sp.w.nbytes + sp.lo.nbytes < 0.5 * np.asarray(de).nbytes
+                i_max, j_max = len(line), len(sparse[0][j])
+                want = oracle_path(de, i_max, j_max, 1. / cfg.voc_size)
+                got = alignment2path(sp, i_max, j_max, 1. / cfg.voc_size)
+                assert got[0] == want[0] and abs(got[1] - want[1]) < 1e-4
+    # against the oracle's alignments as well
+    want = correct_lines(om, lines, fast=True, greedy=True)
+    got = s2s.correct_lines(lines, fast=True, greedy=True)
+    for j in range(len(lines)):
+        assert np.allclose(np.asarray(got[3][j]), np.asarray(want[3][j]), atol=1e-4)
