@@ -202,4 +202,27 @@ struct SparseAlignOut { int* lo; float* w; int K; const int* win_store; };
 void launch_beam_extract_sparse(const BeamState& s, const BeamParams& p, const BeamOut& o, const SparseAlignOut& sp, hipStream_t stream);
 void launch_greedy_extract_sparse(const float* a_base, const int* win_store, int B, int S, int T, const SparseAlignOut& sp, hipStream_t stream);
 
+// ---- persistent small-batch decoder (persist.hip) ----
+struct PersistLayer {
+    const float* w;        // [W/16 unit groups][4 gates][16 units][Kt], K of every 16-tile in MFMA-group order
+    const float* bias;     // [W/16][4][16]
+    int Kt;
+};
+struct PersistArgs {
+    int R, D, W, V, Vp, C, T, S, mode;
+    PersistLayer layer[8];
+    const float* wa; const float* bUW;     // attention query weights [W][W] (packed K order), bias
+    const float* e;                        // tied output projection [Vp][W] (packed K order; rows >= V are zero)
+    float* h[8]; float* c[8];              // state stores [(S+1)*R][W], slot s+1 = outputs of step s
+    float* ctx;                            // [(S+1)*R][C]
+    float* wq;                             // [(S+1)*R][W]
+    float* logits;                         // [(S+1)*R][Vp]
+    AttnArgs att;                          // u, enc, v_a, b_v, alignment store, window store (wq / ctx are set per step)
+    int* out_idx; float* out_prob; int* nan_flag;
+    unsigned* counters;                    // persist_counter_bytes(); zeroed ahead of the launch
+    int g_lstm, g_att, g_plain;            // workgroups per role
+};
+size_t persist_counter_bytes(int R, int D);
+void launch_persist_decode(const PersistArgs& pa, hipStream_t stream);
+
 }  // namespace casv

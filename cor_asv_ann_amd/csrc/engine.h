@@ -75,7 +75,10 @@ struct Prof {
     }
 };
 
-struct LstmW { DevBuf wt, bias; int kin = 0; };   // packed [4W][kin + W], gate-interleaved
+struct LstmW {
+    DevBuf wt, bias; int kin = 0;     // packed [4W][kin + W], gate-interleaved
+    DevBuf pw, pbias;                 // decoder layers: the same values in the persistent decoder's layout (persist.hip)
+};
 
 struct TrainState;
 
@@ -90,6 +93,10 @@ struct casv_model {
     bool committed = false;
     // packed device weights
     DevBuf E, WaT, bUW, va, bv, UT;
+    DevBuf WaP, EP;                                       // query / output projection in the persistent decoder's K order
+    DevBuf p_ctx, p_wq, p_logits, p_counters;             // persistent decoder: slot-indexed hand-off buffers, counters
+    int persist_mode = -1;                                // -1 by size, 0 never, 1 always (greedy decode of small batches)
+    int ncu = 0;
     LstmW enc_fw, enc_bw;
     std::vector<LstmW> enc, dec;                         // enc[n] for layer n>=2 at index n; dec[n] n=1..D
     // encoder session

@@ -44,6 +44,7 @@ extern "C" int casv_model_create(const casv_config* cfg, int device_id, casv_mod
     HIPCHK(hipSetDevice(device_id));
     casv_model* m = new casv_model();
     m->cfg = *cfg; m->device = device_id;
+    { hipDeviceProp_t prop{}; if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) m->ncu = prop.multiProcessorCount; }
     m->W = cfg->width; m->V = cfg->voc_size; m->Vp = (cfg->voc_size + 31) & ~31; m->D = cfg->depth;
     m->C = cfg->depth == 1 ? 2 * cfg->width : cfg->width;
     m->expect = expected_shapes(*cfg);
@@ -70,7 +71,8 @@ extern "C" void casv_model_destroy(casv_model* m) {
         &m->bo_rej, &m->bo_align, &m->bo_found, &m->bo_nsteps};
     for (DevBuf* b : bufs) b->release();
     for (auto& l : m->enc) { l.wt.release(); l.bias.release(); }
-    for (auto& l : m->dec) { l.wt.release(); l.bias.release(); }
+    for (auto& l : m->dec) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
+    for (DevBuf* b : {&m->WaP, &m->EP, &m->p_ctx, &m->p_wq, &m->p_logits, &m->p_counters}) b->release();
     for (auto& b : m->st_h) b.release();
     for (auto& b : m->st_c) b.release();
     (void)casv_train_release(m);
@@ -99,9 +101,31 @@ extern "C" int casv_get_weight(casv_model* m, const char* name, float* out, int6
     return CASV_OK;
 }
 
+// K order inside every 16-k tile for the persistent decoder's v_mfma_f32_16x16x4_f32: position 4*kg + q holds the k that
+// k group kg contracts in instruction q -- the groups visit k in the order of the 32x32x2 chain of gemm.hip (persist.hip).
+static const int kPersistK[4][4] = {{0, 4, 1, 5}, {2, 6, 3, 7}, {8, 12, 9, 13}, {10, 14, 11, 15}};
+static void persist_permute_row(const float* src, float* dst, int K) {
+    for (int kt = 0; kt < K / 16; ++kt)
+        for (int kg = 0; kg < 4; ++kg)
+            for (int q = 0; q < 4; ++q) dst[kt * 16 + 4 * kg + q] = src[kt * 16 + kPersistK[q][kg]];
+}
+// [4W][Kt] gate-interleaved rows ((u/32)*128 + g*32 + u%32) -> [W/16][4][16][Kt] with permuted K; bias likewise
+static int pack_persist(casv_model* m, LstmW& dst, const std::vector<float>& wt, const std::vector<float>& bias, int Kt) {
+    const int W = m->W;
+    std::vector<float> pw((size_t)4 * W * Kt), pb(4 * W);
+    for (int u = 0; u < W; ++u)
+        for (int g = 0; g < 4; ++g) {
+            const int n = (u / 32) * 128 + g * 32 + (u % 32), rowp = ((u / 16) * 4 + g) * 16 + (u % 16);
+            persist_permute_row(&wt[(size_t)n * Kt], &pw[(size_t)rowp * Kt], Kt);
+            pb[rowp] = bias[n];
+        }
+    if (int rc = upload(dst.pw, pw)) return rc;
+    return upload(dst.pbias, pb);
+}
+
 // Keras (in,4W) kernel + (W,4W) recurrent kernel + (4W) bias -> [4W][in+W] rows in the
 // gate-interleaved order n = (u/32)*128 + g*32 + u%32, K contiguous.
-static int pack_lstm(casv_model* m, LstmW& dst, const std::string& prefix, int kin) {
+static int pack_lstm(casv_model* m, LstmW& dst, const std::string& prefix, int kin, bool decoder = false) {
     const int W = m->W, Kt = kin + W;
     const auto& K = m->host[prefix + "_K"]; const auto& R = m->host[prefix + "_R"]; const auto& b = m->host[prefix + "_b"];
     std::vector<float> wt((size_t)4 * W * Kt), bias(4 * W);
@@ -114,6 +138,7 @@ static int pack_lstm(casv_model* m, LstmW& dst, const std::string& prefix, int k
             bias[n] = b[col];
         }
     dst.kin = kin;
+    if (decoder) if (int rc = pack_persist(m, dst, wt, bias, Kt)) return rc;
     if (int rc = upload(dst.wt, wt)) return rc;
     return upload(dst.bias, bias);
 }
@@ -145,6 +170,7 @@ static int pack_dec1(casv_model* m, LstmW& dst, const std::string& prefix, int k
             bias[n] = b[col];
         }
     dst.kin = Vp + kextra;
+    if (int rc = pack_persist(m, dst, wt, bias, Kt)) return rc;
     if (int rc = upload(dst.wt, wt)) return rc;
     return upload(dst.bias, bias);
 }
@@ -164,8 +190,8 @@ extern "C" int casv_commit_weights(casv_model* m) {
         if (int rc = pack_dec1(m, m->dec[1], "dec1", C)) return rc;
     } else {
         if (int rc = pack_dec1(m, m->dec[1], "dec1", 0)) return rc;
-        for (int n = 2; n < D; ++n) if (int rc = pack_lstm(m, m->dec[n], "dec" + std::to_string(n), W)) return rc;
-        if (int rc = pack_lstm(m, m->dec[D], "dec" + std::to_string(D), W + C)) return rc;
+        for (int n = 2; n < D; ++n) if (int rc = pack_lstm(m, m->dec[n], "dec" + std::to_string(n), W, true)) return rc;
+        if (int rc = pack_lstm(m, m->dec[D], "dec" + std::to_string(D), W + C, true)) return rc;
     }
     const auto& Wa = m->host["att_Wa"]; const auto& U = m->host["att_U"];
     std::vector<float> wat((size_t)W * W), ut((size_t)W * C);
@@ -173,6 +199,14 @@ extern "C" int casv_commit_weights(casv_model* m) {
     for (int j = 0; j < W; ++j) for (int c = 0; c < C; ++c) ut[(size_t)j * C + c] = U[(size_t)c * W + j];
     if (int rc = upload(m->WaT, wat)) return rc;
     if (int rc = upload(m->UT, ut)) return rc;
+    {   // the persistent decoder's copies: K permuted per 16-tile, output rows padded to Vp with zeros
+        const int V = m->V, Vp = m->Vp;
+        std::vector<float> wap((size_t)W * W), ep((size_t)Vp * W, 0.f);
+        for (int j = 0; j < W; ++j) persist_permute_row(&wat[(size_t)j * W], &wap[(size_t)j * W], W);
+        for (int v = 0; v < V; ++v) persist_permute_row(&E[(size_t)v * W], &ep[(size_t)v * W], W);
+        if (int rc = upload(m->WaP, wap)) return rc;
+        if (int rc = upload(m->EP, ep)) return rc;
+    }
     if (int rc = upload(m->bUW, m->host["att_bUW"])) return rc;
     if (int rc = upload(m->va, m->host["att_va"])) return rc;
     if (int rc = upload(m->bv, m->host["att_bv"])) return rc;
@@ -517,6 +551,56 @@ struct StepRunner {
     }
 };
 
+// All S greedy steps in ONE launch of the persistent decoder (persist.hip): small batches, where the per-step kernels are
+// bound by launch and memory latency.  Same results bit for bit (tested), same state / alignment / window stores.
+static bool persist_applies(const casv_model* m, int B) {
+    if (m->persist_mode == 0 || m->prof.on) return false;          // the profiler times the per-step kernels
+    if (m->ncu < 64 || m->D > 8) return false;
+    return m->persist_mode == 1 ? B <= 4096 : B <= 512;
+}
+static int decode_greedy_persistent(casv_model* m, int mode, int S) {
+    const int W = m->W, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
+    const size_t slots = (size_t)(S + 1) * R;
+    if (int rc = m->p_ctx.ensure(slots * C * 4)) return rc;
+    if (int rc = m->p_wq.ensure(slots * W * 4)) return rc;
+    if (int rc = m->p_logits.ensure(slots * Vp * 4)) return rc;
+    const size_t cbytes = persist_counter_bytes(R, D);
+    if (int rc = m->p_counters.ensure(cbytes)) return rc;
+    HIPCHK(hipMemsetAsync(m->p_counters.p, 0, cbytes, m->stream));
+    PersistArgs pa{};
+    pa.R = R; pa.D = D; pa.W = W; pa.V = m->V; pa.Vp = Vp; pa.C = C; pa.T = T; pa.S = S; pa.mode = mode;
+    for (int n = 1; n <= D; ++n) {
+        pa.layer[n - 1].w = m->dec[n].pw.as<float>(); pa.layer[n - 1].bias = m->dec[n].pbias.as<float>();
+        pa.layer[n - 1].Kt = m->dec[n].kin + W;
+        pa.h[n - 1] = m->st_h[n].as<float>(); pa.c[n - 1] = m->st_c[n].as<float>();
+    }
+    pa.wa = m->WaP.as<float>(); pa.bUW = m->bUW.as<float>(); pa.e = m->EP.as<float>();
+    pa.ctx = m->p_ctx.as<float>(); pa.wq = m->p_wq.as<float>(); pa.logits = m->p_logits.as<float>();
+    AttnArgs a{};
+    a.u = m->u.as<float>(); a.enc = m->enc_out; a.va = m->va.as<float>(); a.bv = m->bv.as<float>();
+    a.a_base = m->st_a.as<float>(); a.prev = nullptr; a.line = nullptr; a.rows_per_line = 1;
+    a.R = R; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
+    a.u_line = (long long)T * W; a.u_time = W; a.enc_line = (long long)T * C; a.enc_time = C;
+    a.win_store = m->st_win.as<int>();
+    pa.att = a;
+    pa.out_idx = m->o_idx.as<int>(); pa.out_prob = m->o_prob.as<float>(); pa.nan_flag = m->d_nan.as<int>();
+    pa.counters = m->p_counters.as<unsigned>();
+    const int nrb = (R + 15) / 16, nug = W / 16;
+    const int nq4 = (W / 16 + 3) / 4, nl4 = (Vp / 16 + 3) / 4;
+    const int ncu = m->ncu;
+    pa.g_lstm = std::min(nrb * nug, ncu);
+    pa.g_att = std::min(nrb * 4, std::max(ncu / 8, 8));
+    pa.g_plain = std::min(nrb * (nq4 + nl4), std::max(ncu / 4, 8));
+    launch_persist_decode(pa, m->stream);
+    HIPCHK(hipGetLastError());
+    unsigned aborted = 0;
+    HIPCHK(hipMemcpyAsync(&aborted, m->p_counters.as<unsigned>() + (size_t)nrb * (D + 3) * 32, 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (aborted) return fail(CASV_ERR_HIP, "persistent decoder: a hand-off wait ran out (workgroups not co-resident?); "
+                             "set option 'persistent' to 0 for the per-step kernels");
+    return 0;
+}
+
 extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_t* out_idx, float* out_prob,
                                   int32_t* out_len, float* out_align) {
     if (!m || !out_idx || !out_prob) return fail(CASV_ERR_ARG, "null argument");
@@ -532,7 +616,9 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     HIPCHK(hipMemsetAsync(m->o_idx.p, 0, (size_t)B * S * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->o_prob.p, 0, (size_t)B * S * 4, m->stream));
     const int* sp = m->d_step.as<int>();
-    {
+    if (persist_applies(m, B)) {
+        if (int rc = decode_greedy_persistent(m, mode, S)) return rc;
+    } else {
         StepRunner runner(m);
         if (int rc = runner.run(S, [&]() {
                 launch_step(m, false, mode, nullptr, 1, m->o_idx.as<int>(), m->o_prob.as<float>(), sp, 0);
@@ -781,6 +867,10 @@ extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N
 extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
     if (!m || !key) return fail(CASV_ERR_ARG, "null argument");
     if (!strcmp(key, "graph")) { m->use_graph = value != 0; return CASV_OK; }
+    if (!strcmp(key, "persistent")) {
+        if (value < -1 || value > 1) return fail(CASV_ERR_ARG, "persistent must be -1 (by batch size), 0 (per-step kernels) or 1 (always)");
+        m->persist_mode = (int)value; return CASV_OK;
+    }
     if (!strcmp(key, "eos")) {
         if (value < 0 || value >= m->V) return fail(CASV_ERR_ARG, "eos index %lld outside the vocabulary", (long long)value);
         m->eos = (int)value; return CASV_OK;

@@ -1,0 +1,411 @@
+// Persistent decoder for small batches: ONE launch runs all S greedy decode steps (seq2seq.py:1215-1354) of up to a few
+// hundred rows, where a step is a handful of short dependent GEMMs and the launch-per-kernel path is bound by launch and
+// memory latency (BASELINE configs[1]: 256 rows, depth 2, width 256 -- 5 launches of ~20 us per character).
+//
+// Decomposition.  Rows are cut into blocks of 16, hidden units into groups of 16.  Workgroups (256 threads, all
+// co-resident) have fixed roles for the whole launch:
+//   LSTM  one tile = (layer, row block, unit group): 16 rows x 16 units x 4 gates, wave g = gate g, one
+//         v_mfma_f32_16x16x4_f32 accumulator per wave over the FULL K range [x | ctx | h], then the cell (common.h) --
+//         gate pre-activations meet in LDS, h', c' go to the slot of the next step;
+//   ATT   four rows of a row block, one wave per row: attention_row (row_kernels.h), the same code the per-step kernel runs;
+//   PLAIN four 16x16 column tiles of the attention query h.W_a (for the NEXT step) or of the logits h.E^T.
+// The softmax is not a phase of its own: every layer-1 tile recomputes max / sum / argmax of its 16 rows from the logits
+// (a few KB) and turns logits into the fed-back distribution while it loads them as its A operand; the tile of unit group 0
+// also emits the step's character and probability.
+//
+// Numerics are those of the per-step kernels, bit for bit: the 16x16x4 MFMA contracts four k per instruction as an
+// ordered fmaf chain, and its k groups are fed in the order {0,4,1,5},{2,6,3,7},{8,12,9,13},{10,14,11,15} of every
+// 16-k tile -- the order in which gemm.hip / gemm_skinny.hip's 32x32x2 chain visits them (measured identical on random
+// data, and identical to a scalar fmaf chain on the host); cell, attention and softmax are the shared functions.  A row
+// therefore decodes to the same characters and probabilities whichever path its batch takes (tested).
+//
+// Hand-offs (MI355X: 8 XCDs with private L2s, per-CU L1s): every buffer that crosses workgroups is indexed by the step
+// (slot s + 1 holds the outputs of step s), so no address is rewritten and none is read before it was written.
+// Producers store the payload write-through (sc1), drain (s_waitcnt vmcnt(0) in every storing wave), meet at the
+// workgroup barrier, and ONE lane adds to the row block's monotonic counter (agent scope).  Consumers: one lane polls the
+// counters it needs (relaxed, agent scope, s_sleep between polls, bounded), then ONE agent-scope acquire, a barrier, and
+// plain loads.  Counters only grow (target = tiles per step x steps done) and are zeroed by a memset ahead of the launch.
+// A spin that runs out sets the abort word; every other wait sees it and the launch drains.
+#include "common.h"
+#include "row_kernels.h"
+#include <math.h>
+
+namespace casv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PDEPTH = 8;                       // K tiles in flight per wave (16 k each)
+constexpr unsigned PERSIST_SPIN_LIMIT = 40u * 1000u * 1000u;   // polls before a wait gives up (seconds)
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Dep { const unsigned* c; unsigned target; };
+
+// One lane waits until every counter has reached its target, then the workgroup acquires.  false = aborted.
+__device__ __forceinline__ bool wait_deps(const Dep d0, const Dep d1, const Dep d2, unsigned* abort_w, int* s_ok) {
+    if (threadIdx.x == 0) {
+        int good = 1;
+        unsigned spins = 0;
+        for (;;) {
+            const bool ready = (!d0.c || ld_agent(d0.c) >= d0.target) && (!d1.c || ld_agent(d1.c) >= d1.target) &&
+                               (!d2.c || ld_agent(d2.c) >= d2.target);
+            if (ready) break;
+            ++spins;
+            if ((spins & 255u) == 0 && ld_agent(abort_w)) { good = 0; break; }
+            if (spins > PERSIST_SPIN_LIMIT) {
+                __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_ok = good;
+    }
+    __syncthreads();
+    const int ok = *s_ok;
+    __syncthreads();
+    return ok != 0;
+}
+
+// Every wave has stored its share write-through; one lane signals for the workgroup.
+__device__ __forceinline__ void publish(unsigned* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A operand of one wave: up to three K segments of natural-layout rows; segment kind 1 = logits turned into the
+// fed-back distribution on the fly.
+struct ASeg { const float* p; int tiles; };
+
+struct RowStat { float m, sum; int nan0; };   // softmax statistics of one row; nan0: mode 1 wrote NaN over p[0]
+
+// The K loop of one wave: acc += A[16 rows][K] . B[16 cols][K]^T in the k order of the module comment.
+// `lane` supplies row / column (lane & 15) and k group (lane >> 4); `b` points at this lane's packed weight row + 4 * kg.
+template <bool SOFTMAX0>
+__device__ __forceinline__ f32x4 k_loop(const ASeg s0, const ASeg s1, const ASeg s2, const float* __restrict__ b,
+                                        const int kt_begin, const int lane, const RowStat st, const int V, const int mode) {
+    const int kg = lane >> 4;
+    const bool lo = lane < 32;
+    const int c0 = s0.tiles, c1 = s0.tiles + s1.tiles, nt = s0.tiles + s1.tiles + s2.tiles;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (kt_begin >= nt) return acc;
+    f32x4 fa[PDEPTH], fb[PDEPTH];
+    auto load = [&](f32x4& a, f32x4& bq, int kt) {
+        kt = kt < nt ? kt : nt - 1;                               // past the end: a valid, unused re-load
+        const float* pa = kt < c0 ? s0.p + (long long)kt * 16 : (kt < c1 ? s1.p + (long long)(kt - c0) * 16 : s2.p + (long long)(kt - c1) * 16);
+        a = *reinterpret_cast<const f32x4*>(pa);
+        bq = *reinterpret_cast<const f32x4*>(b + (long long)kt * 16);
+    };
+    auto mma = [&](f32x4 a, const f32x4 bq, const int kt) {
+        if (SOFTMAX0 && kt < c0) {                                // logits -> softmax (decode_kernels.hip: expf(x - m) / sum)
+            const int v0 = kt * 16 + 4 * kg;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pv = (v0 + j) < V ? expf(a[j] - st.m) / st.sum : 0.0f;
+                if (mode == 1 && st.nan0 && v0 + j == 0) pv = __builtin_nanf("");
+                a[j] = pv;
+            }
+        }
+        // natural chunk (k = 4kg .. 4kg+3) -> the k of this lane's group in the four instructions of the tile
+        const float snd0 = lo ? a[1] : a[0], snd1 = lo ? a[3] : a[2];
+        const float rcv0 = __shfl_xor(snd0, 32, 64), rcv1 = __shfl_xor(snd1, 32, 64);
+        const float a0 = lo ? a[0] : rcv0, a1 = lo ? a[2] : rcv1, a2 = lo ? rcv0 : a[1], a3 = lo ? rcv1 : a[3];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bq[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bq[3], acc, 0, 0, 0);
+    };
+#pragma unroll
+    for (int q = 0; q < PDEPTH; ++q) load(fa[q], fb[q], kt_begin + q);
+    int kt = kt_begin;
+    for (; kt + PDEPTH <= nt; kt += PDEPTH) {
+#pragma unroll
+        for (int q = 0; q < PDEPTH; ++q) {
+            mma(fa[q], fb[q], kt + q);
+            load(fa[q], fb[q], kt + PDEPTH + q);
+        }
+    }
+    const int rest = nt - kt;
+#pragma unroll
+    for (int q = 0; q < PDEPTH - 1; ++q)
+        if (rest > q) mma(fa[q], fb[q], kt + q);
+    return acc;
+}
+
+// Softmax statistics + greedy pick (the arithmetic of softmax_kernel, decode_kernels.hip: per-lane partial results over
+// v = lane, lane + 64, ... in ascending order, then the same butterflies) of FOUR rows by one wave.  The rows are
+// independent, so their loads, transcendentals and shuffles interleave; every row's numbers are what the one-row kernel
+// computes.  VPL = vocabulary entries per lane held in registers (V <= 64 * VPL).
+template <int VPL>
+__device__ __forceinline__ void row_stats4(const float* const (&x)[4], const int V, const int mode, const int lane,
+                                           const bool (&emit)[4], int* const (&out_idx)[4], float* const (&out_prob)[4],
+                                           int* nan_flag, RowStat (&st)[4]) {
+    float xv[4][VPL];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; xv[i][k] = v < V ? x[i][v] : 0.0f; }
+    float m[4], nan[4], sum[4], best[4], p0[4];
+    int bidx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m[i] = -INFINITY; nan[i] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+            if (lane + 64 * k < V) { m[i] = fmaxf(m[i], xv[i][k]); nan[i] += (xv[i][k] != xv[i][k]) ? 1.0f : 0.0f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m[i] = fmaxf(m[i], __shfl_xor(m[i], o, 64)); nan[i] += __shfl_xor(nan[i], o, 64); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (nan[i] > 0.0f) m[i] = __builtin_nanf("");
+        sum[i] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+            if (lane + 64 * k < V) { xv[i][k] = expf(xv[i][k] - m[i]); sum[i] += xv[i][k]; }     // xv now holds exp(x - m)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum[i] += __shfl_xor(sum[i], o, 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        best[i] = -INFINITY; bidx[i] = 0x7fffffff; p0[i] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int v = lane + 64 * k;
+            const float pv = v < V ? xv[i][k] / sum[i] : 0.0f;
+            if (v == 0) p0[i] = pv;
+            if (v >= 1 && v < V && pv > best[i]) { best[i] = pv; bidx[i] = v; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ob = __shfl_xor(best[i], o, 64);
+            const int oi = __shfl_xor(bidx[i], o, 64);
+            if (ob > best[i] || (ob == best[i] && oi < bidx[i])) { best[i] = ob; bidx[i] = oi; }
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float p00 = __shfl(p0[i], 0, 64);
+        st[i].m = m[i]; st[i].sum = sum[i]; st[i].nan0 = 0;
+        int idx = bidx[i]; float pr = best[i];
+        if (bidx[i] == 0x7fffffff) {                              // every candidate NaN: numpy raises here
+            if (emit[i] && lane == 0 && nan_flag) atomicOr(nan_flag, 1);
+            idx = 1; pr = __builtin_nanf("");
+        } else if (mode == 1) {
+            if (p00 >= best[i] && p00 == p00) st[i].nan0 = 1;    // seq2seq.py:1334: NaN over index 0, stays in the feedback
+        }
+        if (emit[i] && lane == 0) { *out_idx[i] = idx; *out_prob[i] = pr; }
+    }
+}
+
+// the same for one row of any vocabulary size (values re-read from memory in every pass)
+__device__ __forceinline__ RowStat row_stats(const float* __restrict__ x, const int V, const int Vp, const int mode, const int lane,
+                                             const bool emit, int* out_idx, float* out_prob, int* nan_flag) {
+    float m = -INFINITY;
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+    float anynan = 0.0f;
+    for (int v = lane; v < V; v += 64) anynan += (x[v] != x[v]) ? 1.0f : 0.0f;
+    m = wave_max(m);
+    if (wave_sum(anynan) > 0.0f) m = __builtin_nanf("");
+    float sum = 0.0f;
+    for (int v = lane; v < V; v += 64) sum += expf(x[v] - m);
+    sum = wave_sum(sum);
+    float best = -INFINITY; int bidx = 0x7fffffff;
+    float p0 = 0.0f;
+    for (int v = lane; v < Vp; v += 64) {
+        const float pv = v < V ? expf(x[v] - m) / sum : 0.0f;
+        if (v == 0) p0 = pv;
+        if (v >= 1 && v < V && pv > best) { best = pv; bidx = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    p0 = __shfl(p0, 0, 64);
+    RowStat st; st.m = m; st.sum = sum; st.nan0 = 0;
+    int idx = bidx; float pr = best;
+    if (bidx == 0x7fffffff) {
+        if (emit && lane == 0 && nan_flag) atomicOr(nan_flag, 1);
+        idx = 1; pr = __builtin_nanf("");
+    } else if (mode == 1) {
+        if (p0 >= best && p0 == p0) st.nan0 = 1;             // seq2seq.py:1334: NaN over index 0, stays in the feedback
+    }
+    if (emit && lane == 0) { *out_idx = idx; *out_prob = pr; }
+    return st;
+}
+
+__global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArgs pa) {
+    __shared__ float s_gate[4][16 * 16];
+    __shared__ float s_m[16], s_sum[16];
+    __shared__ int s_nan0[16];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = pa.R, D = pa.D, W = pa.W, V = pa.V, Vp = pa.Vp, C = pa.C, S = pa.S;
+    const int NRB = (R + 15) / 16, NUG = W / 16;
+    const int NQ4 = (W / 16 + 3) / 4, NL4 = (Vp / 16 + 3) / 4;         // query / logits tasks per row block (4 column tiles each)
+    const int NCNT = D + 3;
+    unsigned* const cnt = pa.counters;
+    unsigned* const abort_w = pa.counters + (long long)NRB * NCNT * 32;
+    auto counter = [&](int rb, int kind) { return cnt + ((long long)rb * NCNT + kind) * 32; };   // kind: 0..D-1 layers, D ctx, D+1 logits, D+2 query
+    const long long RW = (long long)R * W;
+    const int g = blockIdx.x;
+
+    if (g < pa.g_lstm) {
+        // ------------------------------------------------------------------ LSTM tiles
+        const int NT = NRB * NUG;
+        for (int s = 0; s <= S; ++s) {
+            for (int n = 1; n <= D; ++n) {
+                if (s == S && n > 1) break;
+                for (int t = g; t < NT; t += pa.g_lstm) {
+                    const int rb = t / NUG, ug = t % NUG;
+                    if (s == S && ug != 0) continue;               // after the last step: only the outputs of its logits
+                    const bool top = n == D, first = n == 1;
+                    Dep dx{nullptr, 0}, dc{nullptr, 0}, dh{nullptr, 0};
+                    if (first) { if (s > 0) dx = Dep{counter(rb, D + 1), (unsigned)(s * NL4)}; }
+                    else dx = Dep{counter(rb, n - 2), (unsigned)((s + 1) * NUG)};
+                    if (s < S) {
+                        if (top) dc = Dep{counter(rb, D), (unsigned)((s + 1) * 4)};
+                        if (s > 0) dh = Dep{counter(rb, n - 1), (unsigned)(s * NUG)};
+                    }
+                    if (!wait_deps(dx, dc, dh, abort_w, &s_ok)) return;
+                    RowStat st{0.f, 1.f, 0};
+                    if (first && s > 0) {
+                        // softmax statistics of the 16 rows from the logits of step s-1; unit group 0 reports the character
+                        const float* lg = pa.logits + (long long)s * R * Vp;
+                        const float* xr[4]; bool emit[4]; int* oi[4]; float* op[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int rr = rb * 16 + wave * 4 + i;
+                            const int r = rr < R ? rr : R - 1;
+                            xr[i] = lg + (long long)r * Vp; emit[i] = ug == 0 && rr < R;
+                            oi[i] = pa.out_idx + (long long)r * S + (s - 1); op[i] = pa.out_prob + (long long)r * S + (s - 1);
+                        }
+                        RowStat q[4];
+                        if (V <= 256) row_stats4<4>(xr, V, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
+                        else if (V <= 512) row_stats4<8>(xr, V, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
+                        else if (V <= 1024) row_stats4<16>(xr, V, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
+                        else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) q[i] = row_stats(xr[i], V, Vp, pa.mode, lane, emit[i], oi[i], op[i], pa.nan_flag);
+                        }
+                        if (lane == 0) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { s_m[wave * 4 + i] = q[i].m; s_sum[wave * 4 + i] = q[i].sum; s_nan0[wave * 4 + i] = q[i].nan0; }
+                        }
+                        __syncthreads();
+                        st.m = s_m[lane & 15]; st.sum = s_sum[lane & 15]; st.nan0 = s_nan0[lane & 15];
+                        __syncthreads();
+                    }
+                    if (s == S) continue;
+                    const PersistLayer& L = pa.layer[n - 1];
+                    int row = rb * 16 + (lane & 15); row = row < R ? row : R - 1;
+                    const int kg4 = 4 * (lane >> 4);
+                    ASeg s0, s1{nullptr, 0}, s2;
+                    int kt_begin = 0;
+                    if (first) { s0 = ASeg{pa.logits + (long long)s * R * Vp + (long long)row * Vp + kg4, Vp / 16}; if (s == 0) kt_begin = Vp / 16; }
+                    else s0 = ASeg{pa.h[n - 2] + (long long)(s + 1) * RW + (long long)row * W + kg4, W / 16};
+                    if (top) s1 = ASeg{pa.ctx + ((long long)(s + 1) * R + row) * C + kg4, C / 16};
+                    s2 = ASeg{pa.h[n - 1] + (long long)s * RW + (long long)row * W + kg4, W / 16};
+                    const float* b = L.w + ((long long)((ug * 4 + wave) * 16 + (lane & 15))) * L.Kt + kg4;
+                    // previous cell state of this thread's (row, unit) -- issued ahead of the K loop
+                    const int erow = rb * 16 + (tid >> 4), eu = ug * 16 + (tid & 15);
+                    const int erow_c = erow < R ? erow : R - 1;
+                    const float cprev = pa.c[n - 1][(long long)s * RW + (long long)erow_c * W + eu];
+                    f32x4 acc;
+                    if (first) acc = k_loop<true>(s0, s1, s2, b, kt_begin, lane, st, V, pa.mode);
+                    else acc = k_loop<false>(s0, s1, s2, b, kt_begin, lane, st, V, pa.mode);
+                    // gate g of (row = 4*(lane>>4) + reg, unit = lane & 15) -> LDS; thread (row, unit) runs the cell
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s_gate[wave][((lane >> 4) * 4 + q) * 16 + (lane & 15)] = acc[q];
+                    __syncthreads();
+                    const int e = tid;
+                    const float* bias = L.bias + (long long)ug * 64 + (tid & 15);
+                    const float zi = s_gate[0][e] + bias[0], zf = s_gate[1][e] + bias[16], zg = s_gate[2][e] + bias[32], zo = s_gate[3][e] + bias[48];
+                    const LstmCellOut cell = lstm_cell(zi, zf, zg, zo, cprev);
+                    if (erow < R) {
+                        pa.c[n - 1][(long long)(s + 1) * RW + (long long)erow * W + eu] = cell.c;      // read back by this workgroup only
+                        store_sc1(pa.h[n - 1] + (long long)(s + 1) * RW + (long long)erow * W + eu, cell.h);
+                    }
+                    publish(counter(rb, n - 1));
+                }
+            }
+        }
+        return;
+    }
+    if (g < pa.g_lstm + pa.g_att) {
+        // ------------------------------------------------------------------ attention rows
+        const int ga = g - pa.g_lstm;
+        for (int s = 0; s < S; ++s) {
+            for (int t = ga; t < NRB * 4; t += pa.g_att) {
+                const int rb = t >> 2, q = t & 3;
+                if (!wait_deps(Dep{counter(rb, D + 2), (unsigned)((s + 1) * NQ4)}, Dep{nullptr, 0}, Dep{nullptr, 0}, abort_w, &s_ok)) return;
+                const int r = rb * 16 + q * 4 + wave;
+                if (r < R) {
+                    AttnArgs a = pa.att;
+                    a.wq = pa.wq + (long long)s * RW;
+                    a.ctx = pa.ctx + (long long)(s + 1) * R * C;
+                    attention_row<true>(a, r, s, lane);
+                }
+                publish(counter(rb, D));
+            }
+        }
+        return;
+    }
+    {
+        // ------------------------------------------------------------------ plain tiles: query of the next step, logits
+        const int gp = g - pa.g_lstm - pa.g_att;
+        const int per_rb = NQ4 + NL4;
+        for (int s = -1; s < S; ++s) {                             // s = -1: the query of step 0 from the initial state
+            for (int t = gp; t < NRB * per_rb; t += pa.g_plain) {
+                const int rb = t / per_rb, k = t % per_rb;
+                const bool query = k < NQ4;
+                if (s < 0 && !query) continue;
+                if (s == S - 1 && query) continue;                 // no step follows the last one
+                if (s >= 0) { if (!wait_deps(Dep{counter(rb, D - 1), (unsigned)((s + 1) * NUG)}, Dep{nullptr, 0}, Dep{nullptr, 0}, abort_w, &s_ok)) return; }
+                const int ct = (query ? k : k - NQ4) * 4 + wave;               // this wave's 16-column tile
+                const int nct = query ? W / 16 : Vp / 16;
+                int row = rb * 16 + (lane & 15); row = row < R ? row : R - 1;
+                const int kg4 = 4 * (lane >> 4);
+                if (ct < nct) {
+                    const ASeg s0{pa.h[D - 1] + (long long)(s + 1) * RW + (long long)row * W + kg4, W / 16};
+                    const float* b = (query ? pa.wa : pa.e) + ((long long)(ct * 16 + (lane & 15))) * W + kg4;
+                    const f32x4 acc = k_loop<false>(s0, ASeg{nullptr, 0}, ASeg{nullptr, 0}, b, 0, lane, RowStat{0.f, 1.f, 0}, V, 0);
+                    const int col = ct * 16 + (lane & 15);
+                    const float bias = query ? pa.bUW[col] : 0.0f;
+                    float* out = query ? pa.wq + (long long)(s + 1) * RW : pa.logits + (long long)(s + 1) * R * Vp;
+                    const int ld = query ? W : Vp;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int orow = rb * 16 + (lane >> 4) * 4 + q;
+                        if (orow < R) store_sc1(out + (long long)orow * ld + col, acc[q] + bias);
+                    }
+                }
+                publish(counter(rb, query ? D + 2 : D + 1));
+            }
+        }
+    }
+}
+
+size_t persist_counter_bytes(int R, int D) {
+    const size_t nrb = (R + 15) / 16;
+    return (nrb * (D + 3) * 32 + 32) * sizeof(unsigned);
+}
+
+void launch_persist_decode(const PersistArgs& pa, hipStream_t stream) {
+    hipLaunchKernelGGL(persist_decode_kernel, dim3(pa.g_lstm + pa.g_att + pa.g_plain), dim3(256), 0, stream, pa);
+}
+
+}  // namespace casv

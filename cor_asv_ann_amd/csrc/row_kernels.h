@@ -1,0 +1,145 @@
+// Row-level device functions shared by the per-step kernels (decode_kernels.hip) and the persistent decoder
+// (persist.hip): one 64-lane wave owns one decoder row, all reductions are shuffle butterflies with a fixed order, so a
+// row's result depends neither on the batch it sits in nor on which kernel ran it.
+#pragma once
+#include "common.h"
+#include <math.h>
+
+namespace casv {
+
+// write-through store (global_store ... sc1): payload handed to another workgroup inside a launch
+__device__ __forceinline__ void store_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention.py:526-575.  Only the <= 2*window+1 positions that survive the window mask are evaluated
+// (the reference evaluates all T and multiplies by a 0/1 mask, attention.py:540-569: same values).
+//   t' = sum_s a_prev[s]*s + 1 (float64 accumulate, rounded once to fp32 -- see oracle/model.py)
+//   keep s with |t' - s| <= window ; e[s] = exp(tanh(wq + u[s]).v_a + b_v) ; a' = e / sum e
+//   ctx = sum_s a'[s] * enc[s]
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXWIN = 11;
+constexpr int ATT_ROWS = 8;      // rows (waves) per workgroup: the N=8 hypotheses of one line share u/enc rows in L1
+
+// One decoder row r at `step` (reads alignment slot `step` or the parent's, writes slot step + 1).  HANDOFF: the context
+// vector goes out with write-through stores (another workgroup of the same launch consumes it).
+template <bool HANDOFF>
+__device__ __forceinline__ void attention_row(const AttnArgs& a, const int r, const int step, const int lane) {
+    const int ln = a.line ? a.line[r] : r / a.rows_per_line;
+    const int T = a.T, W = a.W, C = a.C;
+    const float* ap = a.a_base + (a.prev ? (long long)a.prev[r] : (long long)step * a.R + r) * T;
+    float* aout = const_cast<float*>(a.a_base) + ((long long)(step + 1) * a.R + r) * T;
+
+    double acc = 0.0;
+    for (int s = lane; s < T; s += 64) acc += (double)ap[s] * (double)s;
+    const float tp = (float)(wave_sum_d(acc) + 1.0);
+    const float win = (float)a.window;
+
+    int s_lo = 0, s_hi = -1;                    // empty unless t' is a number
+    if (tp == tp && fabsf(tp) < 1.0e9f) {
+        int lo = (int)floorf(tp - win) - 1, hi = (int)floorf(tp + win) + 1;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > T - 1 ? T - 1 : hi;
+        s_lo = T; s_hi = -1;
+        for (int s = lo; s <= hi; ++s)
+            if (fabsf(tp - (float)s) <= win) { s_lo = s < s_lo ? s : s_lo; s_hi = s; }
+    }
+    const int cnt = s_hi - s_lo + 1;            // <= MAXWIN
+
+    const float4* wq4 = reinterpret_cast<const float4*>(a.wq + (long long)r * W);
+    const float4* va4 = reinterpret_cast<const float4*>(a.va);
+    const float* ub = a.u + (long long)ln * a.u_line;
+    const float bv = a.bv[0];
+    const int W4 = W >> 2;
+    // The kernel is latency-bound (one decoder row per wave slot), so all window rows are requested
+    // together: loads are unconditional on clamped row indices, positions past the window get weight 0.
+    float e[MAXWIN];
+#pragma unroll
+    for (int i = 0; i < MAXWIN; ++i) e[i] = 0.0f;
+    for (int j = lane; j < W4; j += 64) {
+        float4 uu[MAXWIN];
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i) {
+            int sidx = s_lo + i; sidx = sidx < T ? sidx : T - 1;
+            uu[i] = reinterpret_cast<const float4*>(ub + (long long)sidx * a.u_time)[j];
+        }
+        const float4 q = wq4[j], v = va4[j];
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i) {
+            e[i] += fast_tanh(q.x + uu[i].x) * v.x;
+            e[i] += fast_tanh(q.y + uu[i].y) * v.y;
+            e[i] += fast_tanh(q.z + uu[i].z) * v.z;
+            e[i] += fast_tanh(q.w + uu[i].w) * v.w;
+        }
+    }
+    float denom = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXWIN; ++i) {
+        const float sc = wave_sum(e[i]) + bv;
+        e[i] = i < cnt ? expf(sc) : 0.0f;
+        denom += e[i];
+    }
+    const float nanv = __builtin_nanf("");
+    float amax = 0.0f;
+    double pos = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXWIN; ++i) {
+        if (i < cnt) {
+            e[i] = e[i] / denom;
+            amax = fmaxf(amax, e[i]);
+            pos += (double)e[i] * (double)(s_lo + i);
+        }
+    }
+    for (int s = lane; s < T; s += 64) {
+        float v = 0.0f;
+        if (cnt <= 0) v = nanv;                 // 0/0 everywhere, as in the reference
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i)
+            if (i < cnt && s == s_lo + i) v = e[i];
+        aout[s] = v;
+    }
+    const float* eb = a.enc + (long long)ln * a.enc_line;
+    float4* ctx4 = reinterpret_cast<float4*>(a.ctx + (long long)r * C);
+    const int C4 = C >> 2;
+    for (int c = lane; c < C4; c += 64) {
+        float4 x[MAXWIN];
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i) {
+            int sidx = s_lo + i; sidx = sidx < T ? sidx : T - 1;
+            x[i] = reinterpret_cast<const float4*>(eb + (long long)sidx * a.enc_time)[c];
+        }
+        float4 v = cnt <= 0 ? make_float4(nanv, nanv, nanv, nanv) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i)
+            if (i < cnt) { v.x += e[i] * x[i].x; v.y += e[i] * x[i].y; v.z += e[i] * x[i].z; v.w += e[i] * x[i].w; }
+        if (HANDOFF) {
+            float* dst = reinterpret_cast<float*>(ctx4 + c);
+            store_sc1(dst, v.x); store_sc1(dst + 1, v.y); store_sc1(dst + 2, v.z); store_sc1(dst + 3, v.w);
+        } else {
+            ctx4[c] = v;
+        }
+    }
+    if (lane == 0) {
+        if (a.apos) a.apos[r] = cnt <= 0 ? (double)nanv : pos;
+        if (a.amax1) a.amax1[r] = (amax == 1.0f) ? 1 : 0;
+        if (a.win_out) a.win_out[r] = cnt > 0 ? (s_lo | (cnt << 16)) : 0;
+        if (a.win_store) a.win_store[(long long)(step + 1) * a.R + r] = cnt > 0 ? (s_lo | (cnt << 16)) : -1;
+    }
+}
+
+}  // namespace casv

