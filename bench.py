@@ -317,11 +317,11 @@ def decode_bench(args):
             if backend == 'nccl':
                 torch.cuda.synchronize()
 
-    dom = 'lstm_gemm' if args.workload != 'c2' else 'lstm_gemm_small'
+    dom = 'lstm_gemm' if args.workload != 'c2' else 'persist'
     for _ in range(args.warmup):
         step()
     if eng:
-        eng.profile(2 if dom == 'lstm_gemm' else 1)      # HIP events around the launches of the dominant kernel, on the library's stream
+        eng.profile(2)      # HIP events around the launches of the dominant kernel, on the library's stream
     t_gather[0] = 0.0
     sync()
     t0 = time.perf_counter()
@@ -337,7 +337,7 @@ def decode_bench(args):
         eng.profile(1)                 # one extra, untimed step with events around every kernel class
         step()
         sync()
-        others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'lstm_gemm_small', 'gemm', 'attention', 'softmax', 'beam', 'embed')}
+        others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'lstm_gemm_small', 'gemm', 'attention', 'softmax', 'beam', 'embed', 'persist')}
         eng.profile(False)
     per_rank = [mine]
     gather_ms = 1e3 * t_gather[0] / max(args.steps, 1)
@@ -382,7 +382,8 @@ def decode_bench(args):
             result['roofline'] = {
                 'bound': 'mfma',
                 'kernel': 'gemm_kernel<EPI_LSTM, 1> (fused LSTM-cell GEMM, 128x128 tiles, fp32 MFMA)' if dom == 'lstm_gemm'
-                          else 'gemm_skinny_kernel<EPI_LSTM> (fused LSTM-cell GEMM, 32x128 tiles, fp32 MFMA)',
+                          else 'persist_decode_kernel (all 2T greedy steps of the batch in one launch: 16x16x4 fp32-MFMA tiles, '
+                               'row-block hand-offs between workgroups)',
                 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                 'launches': prof['launches'], 'avg_launch_us': 1e3 * prof['ms'] / max(prof['launches'], 1),

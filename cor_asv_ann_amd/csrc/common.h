@@ -210,6 +210,7 @@ struct PersistLayer {
 };
 struct PersistArgs {
     int R, D, W, V, Vp, C, T, S, mode;
+    int lda;                               // row stride of the staged activation rows in LDS: widest K of any task + 4
     PersistLayer layer[8];
     const float* wa; const float* bUW;     // attention query weights [W][W] (packed K order), bias
     const float* e;                        // tied output projection [Vp][W] (packed K order; rows >= V are zero)
@@ -221,8 +222,10 @@ struct PersistArgs {
     int* out_idx; float* out_prob; int* nan_flag;
     unsigned* counters;                    // persist_counter_bytes(); zeroed ahead of the launch
     int g_lstm, g_att, g_plain;            // workgroups per role
+    unsigned long long* prof;              // diagnostic build only (CASV_PERSIST_PROF): 32 tick sums, see persist.hip
 };
 size_t persist_counter_bytes(int R, int D);
-void launch_persist_decode(const PersistArgs& pa, hipStream_t stream);
+size_t persist_lds_bytes(const PersistArgs& pa);
+int launch_persist_decode(const PersistArgs& pa, hipStream_t stream);   // -1: the staged rows do not fit the LDS
 
 }  // namespace casv

@@ -50,9 +50,10 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum ProfClass { PC_LSTM = 0, PC_GEMM, PC_ATTN, PC_SOFTMAX, PC_BEAM, PC_EMBED, PC_LSTM_SMALL, PC_COUNT };
+enum ProfClass { PC_LSTM = 0, PC_GEMM, PC_ATTN, PC_SOFTMAX, PC_BEAM, PC_EMBED, PC_LSTM_SMALL, PC_PERSIST, PC_COUNT };
 // "lstm_gemm" = the 128x128-tile fused LSTM GEMM (the dominant kernel); "lstm_gemm_small" = its 32x128-tile variant
-inline const char* kProfNames[PC_COUNT] = {"lstm_gemm", "gemm", "attention", "softmax", "beam", "embed", "lstm_gemm_small"};
+// "persist" = the persistent small-batch decoder (all steps of a greedy decode in one launch)
+inline const char* kProfNames[PC_COUNT] = {"lstm_gemm", "gemm", "attention", "softmax", "beam", "embed", "lstm_gemm_small", "persist"};
 
 struct Prof {
     bool on = false;
@@ -128,12 +129,12 @@ struct casv_model {
     Prof prof;
 
     void prof_begin(int cls, double fl, double by, hipEvent_t& a) {
-        if (!prof.on || (prof.only_lstm && cls != PC_LSTM)) return;
+        if (!prof.on || (prof.only_lstm && cls != PC_LSTM && cls != PC_PERSIST)) return;
         a = prof.get(); (void)hipEventRecord(a, stream);
         prof.flops[cls] += fl; prof.bytes[cls] += by; prof.launches[cls] += 1;
     }
     void prof_end(int cls, hipEvent_t a) {
-        if (!prof.on || (prof.only_lstm && cls != PC_LSTM)) return;
+        if (!prof.on || (prof.only_lstm && cls != PC_LSTM && cls != PC_PERSIST)) return;
         hipEvent_t b = prof.get(); (void)hipEventRecord(b, stream);
         prof.recs.push_back({a, b, cls});
     }

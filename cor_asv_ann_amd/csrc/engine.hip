@@ -554,8 +554,11 @@ struct StepRunner {
 // All S greedy steps in ONE launch of the persistent decoder (persist.hip): small batches, where the per-step kernels are
 // bound by launch and memory latency.  Same results bit for bit (tested), same state / alignment / window stores.
 static bool persist_applies(const casv_model* m, int B) {
-    if (m->persist_mode == 0 || m->prof.on) return false;          // the profiler times the per-step kernels
+    if (m->persist_mode == 0) return false;
     if (m->ncu < 64 || m->D > 8) return false;
+    int kmax = m->W;
+    for (int n = 1; n <= m->D; ++n) kmax = std::max(kmax, m->dec[n].kin + m->W);
+    if ((size_t)16 * (kmax + 4) * 4 > 150 * 1024) return false;   // the staged rows must fit the LDS
     return m->persist_mode == 1 ? B <= 4096 : B <= 512;
 }
 static int decode_greedy_persistent(casv_model* m, int mode, int S) {
@@ -589,10 +592,42 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S) {
     const int nq4 = (W / 16 + 3) / 4, nl4 = (Vp / 16 + 3) / 4;
     const int ncu = m->ncu;
     pa.g_lstm = std::min(nrb * nug, ncu);
-    pa.g_att = std::min(nrb * 4, std::max(ncu / 8, 8));
-    pa.g_plain = std::min(nrb * (nq4 + nl4), std::max(ncu / 4, 8));
-    launch_persist_decode(pa, m->stream);
+    pa.g_att = std::min(nrb * 4, std::max(ncu / 4, 8));
+    pa.g_plain = std::min(nrb * (nq4 + nl4), std::max(ncu / 2, 8));
+#ifdef CASV_PERSIST_PROF
+    static DevBuf profbuf;
+    if (int rc = profbuf.ensure(32 * 8)) return rc;
+    HIPCHK(hipMemsetAsync(profbuf.p, 0, 32 * 8, m->stream));
+    pa.prof = profbuf.as<unsigned long long>();
+#endif
+    int kmax = W;
+    for (int n = 1; n <= D; ++n) kmax = std::max(kmax, pa.layer[n - 1].Kt);
+    pa.lda = kmax + 4;
+    hipEvent_t pev{};
+    {   // executed FLOPs of the launch: every step's layer, query and logits contractions over all rows; bytes: what a step
+        // must move per row (state in and out, attention window, logits) -- SURVEY.md section 8(d)'s Q_row
+        double fl = 0;
+        for (int n = 1; n <= D; ++n) fl += 2.0 * R * 4.0 * W * pa.layer[n - 1].Kt;
+        fl += 2.0 * R * W * W + 2.0 * R * Vp * W;
+        const double by = 4.0 * R * (4.0 * D * W + 11.0 * (W + C) + 2.0 * m->V + 2.0 * T);
+        m->prof_begin(PC_PERSIST, fl * S, by * S, pev);
+    }
+    if (launch_persist_decode(pa, m->stream)) return fail(CASV_ERR_ARG, "persistent decoder: rows of %d floats do not fit the LDS", kmax);
+    m->prof_end(PC_PERSIST, pev);
     HIPCHK(hipGetLastError());
+#ifdef CASV_PERSIST_PROF
+    {
+        unsigned long long h[32];
+        HIPCHK(hipMemcpyAsync(h, profbuf.p, sizeof h, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        const char* names[4] = {"layer1 (wait stats kloop cell publish)", "upper  (wait - kloop cell publish)", "att    (wait row publish)", "plain  (wait kloop publish)"};
+        for (int r = 0; r < 4; ++r) {
+            fprintf(stderr, "persist prof %s us/step:", names[r]);
+            for (int k = 0; k < 5; ++k) fprintf(stderr, " %.2f", h[r * 8 + k] * 0.01 / S);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     unsigned aborted = 0;
     HIPCHK(hipMemcpyAsync(&aborted, m->p_counters.as<unsigned>() + (size_t)nrb * (D + 3) * 32, 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));

@@ -34,7 +34,16 @@ namespace casv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PDEPTH = 8;                       // K tiles in flight per wave (16 k each)
+// Diagnostic build (-DCASV_PERSIST_PROF): the first workgroup of every role adds the wall-clock ticks (10 ns) it spends
+// in each part of its tasks to pa.prof[role * 8 + part].
+#ifdef CASV_PERSIST_PROF
+#define PROF_T(var) const unsigned long long var = wall_clock64()
+#define PROF_ADD(slot, t1, t0) do { if (threadIdx.x == 0 && prof_on) atomicAdd(pa.prof + (slot), (unsigned long long)((t1) - (t0))); } while (0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, t1, t0)
+#endif
+
 constexpr unsigned PERSIST_SPIN_LIMIT = 40u * 1000u * 1000u;   // polls before a wait gives up (seconds)
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
@@ -78,62 +87,72 @@ __device__ __forceinline__ void publish(unsigned* counter) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// A operand of one wave: up to three K segments of natural-layout rows; segment kind 1 = logits turned into the
-// fed-back distribution on the fly.
-struct ASeg { const float* p; int tiles; };
-
 struct RowStat { float m, sum; int nan0; };   // softmax statistics of one row; nan0: mode 1 wrote NaN over p[0]
 
-// The K loop of one wave: acc += A[16 rows][K] . B[16 cols][K]^T in the k order of the module comment.
-// `lane` supplies row / column (lane & 15) and k group (lane >> 4); `b` points at this lane's packed weight row + 4 * kg.
-template <bool SOFTMAX0>
-__device__ __forceinline__ f32x4 k_loop(const ASeg s0, const ASeg s1, const ASeg s2, const float* __restrict__ b,
-                                        const int kt_begin, const int lane, const RowStat st, const int V, const int mode) {
+constexpr int PDB = 12;                         // weight tiles (16 k each) in flight per wave
+
+// The workgroup's 16 activation rows [x | ctx | h] are staged ONCE in LDS (they were written by other workgroups a moment
+// ago, so every line is a miss in this XCD's L2: fetched one by one along the K loop they would cost a memory round trip per
+// few tiles; together they cost one).  16 threads per row, 16 B per load, all loads of a thread independent.
+// Inside every group of 16 k the rows are stored in MFMA-group order (position 4*kg + q = the k that k group kg contracts in
+// instruction q, as the packed weights are): a lane's operands of one tile are ONE 16-B LDS read, no cross-lane traffic.
+__device__ __forceinline__ int perm16(const int k) {       // natural k -> position inside its 16-group
+    // positions of k = 0..15: 0,8,1,9, 4,12,5,13, 2,10,3,11, 6,14,7,15
+    return ((k & 1) << 3) | (k & 4) | ((k & 8) >> 2) | ((k & 2) >> 1);
+}
+__device__ __forceinline__ void stage_rows(float* s_a, const int lda, const int koff, const float* __restrict__ base,
+                                           const int ld, const int width, const int rb, const int R, const int tid) {
+    const int r = tid >> 4, c0 = tid & 15;
+    int row = rb * 16 + r; row = row < R ? row : R - 1;
+    const f32x4* src = reinterpret_cast<const f32x4*>(base + (long long)row * ld);
+    float* dst = s_a + r * lda + koff;
+    for (int c = c0; c < width / 4; c += 16) {
+        const f32x4 v = src[c];
+        float* d = dst + (c >> 2) * 16;                     // chunk c holds k = 4*(c&3) .. +3 of 16-group c>>2
+        const int k0 = 4 * (c & 3);
+        d[perm16(k0)] = v[0]; d[perm16(k0 + 1)] = v[1]; d[perm16(k0 + 2)] = v[2]; d[perm16(k0 + 3)] = v[3];
+    }
+}
+__device__ __forceinline__ int permv(const int v) { return (v & ~15) | perm16(v & 15); }
+
+// Weight tiles kt_begin .. kt_begin + PDB - 1 of this lane's packed row: issued ahead of the dependency wait (weights
+// depend on nothing), so their latency hides behind it.
+struct BRing { f32x4 t[PDB]; };
+__device__ __forceinline__ void ring_start(BRing& ring, const float* __restrict__ b, const int kt_begin, const int nt) {
+#pragma unroll
+    for (int q = 0; q < PDB; ++q) {
+        const int kt = kt_begin + q < nt ? kt_begin + q : nt - 1;
+        ring.t[q] = *reinterpret_cast<const f32x4*>(b + (long long)kt * 16);
+    }
+}
+
+// The K loop of one wave: acc += A[16 rows][K] . B[16 cols][K]^T in the k order of the module comment.  A from the staged
+// rows (row stride lda), B from global memory through the ring.  Lane: row / column = lane & 15, k group = lane >> 4.
+__device__ __forceinline__ f32x4 k_loop(const float* s_a, const int lda, const float* __restrict__ b, BRing& ring,
+                                        const int kt_begin, const int nt, const int lane) {
     const int kg = lane >> 4;
-    const bool lo = lane < 32;
-    const int c0 = s0.tiles, c1 = s0.tiles + s1.tiles, nt = s0.tiles + s1.tiles + s2.tiles;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (kt_begin >= nt) return acc;
-    f32x4 fa[PDEPTH], fb[PDEPTH];
-    auto load = [&](f32x4& a, f32x4& bq, int kt) {
-        kt = kt < nt ? kt : nt - 1;                               // past the end: a valid, unused re-load
-        const float* pa = kt < c0 ? s0.p + (long long)kt * 16 : (kt < c1 ? s1.p + (long long)(kt - c0) * 16 : s2.p + (long long)(kt - c1) * 16);
-        a = *reinterpret_cast<const f32x4*>(pa);
-        bq = *reinterpret_cast<const f32x4*>(b + (long long)kt * 16);
+    const float* arow = s_a + (lane & 15) * lda + 4 * kg;
+    auto mma = [&](const f32x4 a, const f32x4 bq) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bq[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bq[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bq[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bq[3], acc, 0, 0, 0);
     };
-    auto mma = [&](f32x4 a, const f32x4 bq, const int kt) {
-        if (SOFTMAX0 && kt < c0) {                                // logits -> softmax (decode_kernels.hip: expf(x - m) / sum)
-            const int v0 = kt * 16 + 4 * kg;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float pv = (v0 + j) < V ? expf(a[j] - st.m) / st.sum : 0.0f;
-                if (mode == 1 && st.nan0 && v0 + j == 0) pv = __builtin_nanf("");
-                a[j] = pv;
-            }
-        }
-        // natural chunk (k = 4kg .. 4kg+3) -> the k of this lane's group in the four instructions of the tile
-        const float snd0 = lo ? a[1] : a[0], snd1 = lo ? a[3] : a[2];
-        const float rcv0 = __shfl_xor(snd0, 32, 64), rcv1 = __shfl_xor(snd1, 32, 64);
-        const float a0 = lo ? a[0] : rcv0, a1 = lo ? a[2] : rcv1, a2 = lo ? rcv0 : a[1], a3 = lo ? rcv1 : a[3];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bq[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bq[3], acc, 0, 0, 0);
-    };
-#pragma unroll
-    for (int q = 0; q < PDEPTH; ++q) load(fa[q], fb[q], kt_begin + q);
     int kt = kt_begin;
-    for (; kt + PDEPTH <= nt; kt += PDEPTH) {
+    for (; kt + PDB <= nt; kt += PDB) {
 #pragma unroll
-        for (int q = 0; q < PDEPTH; ++q) {
-            mma(fa[q], fb[q], kt + q);
-            load(fa[q], fb[q], kt + PDEPTH + q);
+        for (int q = 0; q < PDB; ++q) {
+            mma(*reinterpret_cast<const f32x4*>(arow + (kt + q) * 16), ring.t[q]);
+            const int nx = kt + PDB + q < nt ? kt + PDB + q : nt - 1;          // past the end: a valid, unused re-load
+            ring.t[q] = *reinterpret_cast<const f32x4*>(b + (long long)nx * 16);
         }
     }
     const int rest = nt - kt;
 #pragma unroll
-    for (int q = 0; q < PDEPTH - 1; ++q)
-        if (rest > q) mma(fa[q], fb[q], kt + q);
+    for (int q = 0; q < PDB - 1; ++q)
+        if (rest > q) mma(*reinterpret_cast<const f32x4*>(arow + (kt + q) * 16), ring.t[q]);
     return acc;
 }
 
@@ -142,14 +161,14 @@ __device__ __forceinline__ f32x4 k_loop(const ASeg s0, const ASeg s1, const ASeg
 // independent, so their loads, transcendentals and shuffles interleave; every row's numbers are what the one-row kernel
 // computes.  VPL = vocabulary entries per lane held in registers (V <= 64 * VPL).
 template <int VPL>
-__device__ __forceinline__ void row_stats4(const float* const (&x)[4], const int V, const int mode, const int lane,
+__device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, const int Vp, const int mode, const int lane,
                                            const bool (&emit)[4], int* const (&out_idx)[4], float* const (&out_prob)[4],
                                            int* nan_flag, RowStat (&st)[4]) {
     float xv[4][VPL];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; xv[i][k] = v < V ? x[i][v] : 0.0f; }
+        for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; xv[i][k] = v < V ? x[i][permv(v)] : 0.0f; }
     float m[4], nan[4], sum[4], best[4], p0[4];
     int bidx[4];
 #pragma unroll
@@ -184,6 +203,7 @@ __device__ __forceinline__ void row_stats4(const float* const (&x)[4], const int
             const float pv = v < V ? xv[i][k] / sum[i] : 0.0f;
             if (v == 0) p0[i] = pv;
             if (v >= 1 && v < V && pv > best[i]) { best[i] = pv; bidx[i] = v; }
+            xv[i][k] = pv;                                        // xv now holds the distribution
         }
     }
 #pragma unroll
@@ -206,25 +226,31 @@ __device__ __forceinline__ void row_stats4(const float* const (&x)[4], const int
             if (p00 >= best[i] && p00 == p00) st[i].nan0 = 1;    // seq2seq.py:1334: NaN over index 0, stays in the feedback
         }
         if (emit[i] && lane == 0) { *out_idx[i] = idx; *out_prob[i] = pr; }
+        // the row becomes the fed-back distribution in place (zeros in the K padding beyond V)
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int v = lane + 64 * k;
+            if (v < Vp) x[i][permv(v)] = (v == 0 && st[i].nan0) ? __builtin_nanf("") : xv[i][k];
+        }
     }
 }
 
 // the same for one row of any vocabulary size (values re-read from memory in every pass)
-__device__ __forceinline__ RowStat row_stats(const float* __restrict__ x, const int V, const int Vp, const int mode, const int lane,
+__device__ __forceinline__ RowStat row_stats(const float* x, const int V, const int Vp, const int mode, const int lane,
                                              const bool emit, int* out_idx, float* out_prob, int* nan_flag) {
     float m = -INFINITY;
-    for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, x[permv(v)]);
     float anynan = 0.0f;
-    for (int v = lane; v < V; v += 64) anynan += (x[v] != x[v]) ? 1.0f : 0.0f;
+    for (int v = lane; v < V; v += 64) anynan += (x[permv(v)] != x[permv(v)]) ? 1.0f : 0.0f;
     m = wave_max(m);
     if (wave_sum(anynan) > 0.0f) m = __builtin_nanf("");
     float sum = 0.0f;
-    for (int v = lane; v < V; v += 64) sum += expf(x[v] - m);
+    for (int v = lane; v < V; v += 64) sum += expf(x[permv(v)] - m);
     sum = wave_sum(sum);
     float best = -INFINITY; int bidx = 0x7fffffff;
     float p0 = 0.0f;
     for (int v = lane; v < Vp; v += 64) {
-        const float pv = v < V ? expf(x[v] - m) / sum : 0.0f;
+        const float pv = v < V ? expf(x[permv(v)] - m) / sum : 0.0f;
         if (v == 0) p0 = pv;
         if (v >= 1 && v < V && pv > best) { best = pv; bidx = v; }
     }
@@ -247,13 +273,14 @@ __device__ __forceinline__ RowStat row_stats(const float* __restrict__ x, const 
     return st;
 }
 
-__global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArgs pa) {
+__global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) float s_a[];         // 16 staged activation rows, stride pa.lda
     __shared__ float s_gate[4][16 * 16];
     __shared__ float s_m[16], s_sum[16];
     __shared__ int s_nan0[16];
     __shared__ int s_ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int R = pa.R, D = pa.D, W = pa.W, V = pa.V, Vp = pa.Vp, C = pa.C, S = pa.S;
+    const int R = pa.R, D = pa.D, W = pa.W, V = pa.V, Vp = pa.Vp, C = pa.C, S = pa.S, lda = pa.lda;
     const int NRB = (R + 15) / 16, NUG = W / 16;
     const int NQ4 = (W / 16 + 3) / 4, NL4 = (Vp / 16 + 3) / 4;         // query / logits tasks per row block (4 column tiles each)
     const int NCNT = D + 3;
@@ -262,6 +289,10 @@ __global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArg
     auto counter = [&](int rb, int kind) { return cnt + ((long long)rb * NCNT + kind) * 32; };   // kind: 0..D-1 layers, D ctx, D+1 logits, D+2 query
     const long long RW = (long long)R * W;
     const int g = blockIdx.x;
+    const int kg4 = 4 * (lane >> 4);
+#ifdef CASV_PERSIST_PROF
+    const bool prof_on = pa.prof && (g == 0 || g == pa.g_lstm || g == pa.g_lstm + pa.g_att);
+#endif
 
     if (g < pa.g_lstm) {
         // ------------------------------------------------------------------ LSTM tiles
@@ -273,6 +304,12 @@ __global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArg
                     const int rb = t / NUG, ug = t % NUG;
                     if (s == S && ug != 0) continue;               // after the last step: only the outputs of its logits
                     const bool top = n == D, first = n == 1;
+                    const PersistLayer& L = pa.layer[n - 1];
+                    const int wx = first ? Vp : W, nt = L.Kt / 16;
+                    const int kt_begin = (first && s == 0) ? Vp / 16 : 0;        // step 0: the fed-back distribution is all zero
+                    const float* b = L.w + ((long long)((ug * 4 + wave) * 16 + (lane & 15))) * L.Kt + kg4;
+                    BRing ring;
+                    if (s < S) ring_start(ring, b, kt_begin, nt);
                     Dep dx{nullptr, 0}, dc{nullptr, 0}, dh{nullptr, 0};
                     if (first) { if (s > 0) dx = Dep{counter(rb, D + 1), (unsigned)(s * NL4)}; }
                     else dx = Dep{counter(rb, n - 2), (unsigned)((s + 1) * NUG)};
@@ -280,53 +317,60 @@ __global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArg
                         if (top) dc = Dep{counter(rb, D), (unsigned)((s + 1) * 4)};
                         if (s > 0) dh = Dep{counter(rb, n - 1), (unsigned)(s * NUG)};
                     }
+                    PROF_T(t0);
                     if (!wait_deps(dx, dc, dh, abort_w, &s_ok)) return;
-                    RowStat st{0.f, 1.f, 0};
+                    PROF_T(t1);
+                    PROF_ADD((n == 1 ? 0 : 8) + 0, t1, t0);
+                    // previous cell state of this thread's (row, unit)
+                    const int erow = rb * 16 + (tid >> 4), eu = ug * 16 + (tid & 15);
+                    const int erow_c = erow < R ? erow : R - 1;
+                    float cprev = 0.0f;
+                    if (s < S) cprev = pa.c[n - 1][(long long)s * RW + (long long)erow_c * W + eu];
+                    // the 16 rows of [x | ctx | h] -> LDS
+                    if (first) { if (s > 0) stage_rows(s_a, lda, 0, pa.logits + (long long)s * R * Vp, Vp, Vp, rb, R, tid); }
+                    else stage_rows(s_a, lda, 0, pa.h[n - 2] + (long long)(s + 1) * RW, W, W, rb, R, tid);
+                    if (s < S) {
+                        if (top) stage_rows(s_a, lda, wx, pa.ctx + (long long)(s + 1) * R * C, C, C, rb, R, tid);
+                        stage_rows(s_a, lda, wx + (top ? C : 0), pa.h[n - 1] + (long long)s * RW, W, W, rb, R, tid);
+                    }
+                    __syncthreads();
                     if (first && s > 0) {
-                        // softmax statistics of the 16 rows from the logits of step s-1; unit group 0 reports the character
-                        const float* lg = pa.logits + (long long)s * R * Vp;
-                        const float* xr[4]; bool emit[4]; int* oi[4]; float* op[4];
+                        // softmax statistics of the 16 rows from the logits of step s-1 (unit group 0 reports the character),
+                        // then the rows become the fed-back distribution in place (softmax_kernel: expf(x - m) / sum)
+                        float* xr[4]; bool emit[4]; int* oi[4]; float* op[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int rr = rb * 16 + wave * 4 + i;
                             const int r = rr < R ? rr : R - 1;
-                            xr[i] = lg + (long long)r * Vp; emit[i] = ug == 0 && rr < R;
+                            xr[i] = s_a + (wave * 4 + i) * lda; emit[i] = ug == 0 && rr < R;
                             oi[i] = pa.out_idx + (long long)r * S + (s - 1); op[i] = pa.out_prob + (long long)r * S + (s - 1);
                         }
                         RowStat q[4];
-                        if (V <= 256) row_stats4<4>(xr, V, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
-                        else if (V <= 512) row_stats4<8>(xr, V, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
-                        else if (V <= 1024) row_stats4<16>(xr, V, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
+                        if (V <= 256) row_stats4<4>(xr, V, Vp, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
                         else {
-#pragma unroll
+                            // large vocabularies: one row at a time, values re-read in every pass, then the rows are rewritten
                             for (int i = 0; i < 4; ++i) q[i] = row_stats(xr[i], V, Vp, pa.mode, lane, emit[i], oi[i], op[i], pa.nan_flag);
+                            if (lane == 0) {
+                                for (int i = 0; i < 4; ++i) { s_m[wave * 4 + i] = q[i].m; s_sum[wave * 4 + i] = q[i].sum; s_nan0[wave * 4 + i] = q[i].nan0; }
+                            }
+                            __syncthreads();
+                            const int r = tid >> 4;
+                            const float m = s_m[r], sum = s_sum[r];
+                            float* xrow = s_a + r * lda;
+                            for (int v = tid & 15; v < Vp; v += 16) {
+                                float pv = v < V ? expf(xrow[permv(v)] - m) / sum : 0.0f;
+                                if (pa.mode == 1 && v == 0 && s_nan0[r]) pv = __builtin_nanf("");
+                                xrow[permv(v)] = pv;
+                            }
                         }
-                        if (lane == 0) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { s_m[wave * 4 + i] = q[i].m; s_sum[wave * 4 + i] = q[i].sum; s_nan0[wave * 4 + i] = q[i].nan0; }
-                        }
-                        __syncthreads();
-                        st.m = s_m[lane & 15]; st.sum = s_sum[lane & 15]; st.nan0 = s_nan0[lane & 15];
                         __syncthreads();
                     }
+                    PROF_T(t2);
+                    PROF_ADD((n == 1 ? 0 : 8) + 1, t2, t1);
                     if (s == S) continue;
-                    const PersistLayer& L = pa.layer[n - 1];
-                    int row = rb * 16 + (lane & 15); row = row < R ? row : R - 1;
-                    const int kg4 = 4 * (lane >> 4);
-                    ASeg s0, s1{nullptr, 0}, s2;
-                    int kt_begin = 0;
-                    if (first) { s0 = ASeg{pa.logits + (long long)s * R * Vp + (long long)row * Vp + kg4, Vp / 16}; if (s == 0) kt_begin = Vp / 16; }
-                    else s0 = ASeg{pa.h[n - 2] + (long long)(s + 1) * RW + (long long)row * W + kg4, W / 16};
-                    if (top) s1 = ASeg{pa.ctx + ((long long)(s + 1) * R + row) * C + kg4, C / 16};
-                    s2 = ASeg{pa.h[n - 1] + (long long)s * RW + (long long)row * W + kg4, W / 16};
-                    const float* b = L.w + ((long long)((ug * 4 + wave) * 16 + (lane & 15))) * L.Kt + kg4;
-                    // previous cell state of this thread's (row, unit) -- issued ahead of the K loop
-                    const int erow = rb * 16 + (tid >> 4), eu = ug * 16 + (tid & 15);
-                    const int erow_c = erow < R ? erow : R - 1;
-                    const float cprev = pa.c[n - 1][(long long)s * RW + (long long)erow_c * W + eu];
-                    f32x4 acc;
-                    if (first) acc = k_loop<true>(s0, s1, s2, b, kt_begin, lane, st, V, pa.mode);
-                    else acc = k_loop<false>(s0, s1, s2, b, kt_begin, lane, st, V, pa.mode);
+                    const f32x4 acc = k_loop(s_a, lda, b, ring, kt_begin, nt, lane);
+                    PROF_T(t3);
+                    PROF_ADD((n == 1 ? 0 : 8) + 2, t3, t2);
                     // gate g of (row = 4*(lane>>4) + reg, unit = lane & 15) -> LDS; thread (row, unit) runs the cell
 #pragma unroll
                     for (int q = 0; q < 4; ++q) s_gate[wave][((lane >> 4) * 4 + q) * 16 + (lane & 15)] = acc[q];
@@ -339,7 +383,11 @@ __global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArg
                         pa.c[n - 1][(long long)(s + 1) * RW + (long long)erow * W + eu] = cell.c;      // read back by this workgroup only
                         store_sc1(pa.h[n - 1] + (long long)(s + 1) * RW + (long long)erow * W + eu, cell.h);
                     }
+                    PROF_T(t4);
+                    PROF_ADD((n == 1 ? 0 : 8) + 3, t4, t3);
                     publish(counter(rb, n - 1));
+                    PROF_T(t5);
+                    PROF_ADD((n == 1 ? 0 : 8) + 4, t5, t4);
                 }
             }
         }
@@ -351,7 +399,10 @@ __global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArg
         for (int s = 0; s < S; ++s) {
             for (int t = ga; t < NRB * 4; t += pa.g_att) {
                 const int rb = t >> 2, q = t & 3;
+                PROF_T(t0);
                 if (!wait_deps(Dep{counter(rb, D + 2), (unsigned)((s + 1) * NQ4)}, Dep{nullptr, 0}, Dep{nullptr, 0}, abort_w, &s_ok)) return;
+                PROF_T(t1);
+                PROF_ADD(16, t1, t0);
                 const int r = rb * 16 + q * 4 + wave;
                 if (r < R) {
                     AttnArgs a = pa.att;
@@ -359,7 +410,11 @@ __global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArg
                     a.ctx = pa.ctx + (long long)(s + 1) * R * C;
                     attention_row<true>(a, r, s, lane);
                 }
+                PROF_T(t2);
+                PROF_ADD(17, t2, t1);
                 publish(counter(rb, D));
+                PROF_T(t3);
+                PROF_ADD(18, t3, t2);
             }
         }
         return;
@@ -374,15 +429,22 @@ __global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArg
                 const bool query = k < NQ4;
                 if (s < 0 && !query) continue;
                 if (s == S - 1 && query) continue;                 // no step follows the last one
+                // this wave's weight rows do not depend on anything: start them ahead of the wait
+                const int ctb = (query ? k : k - NQ4) * 4 + wave;
+                const int ctc = ctb < (query ? W / 16 : Vp / 16) ? ctb : 0;
+                const float* b = (query ? pa.wa : pa.e) + ((long long)(ctc * 16 + (lane & 15))) * W + kg4;
+                BRing ring;
+                ring_start(ring, b, 0, W / 16);
+                PROF_T(t0);
                 if (s >= 0) { if (!wait_deps(Dep{counter(rb, D - 1), (unsigned)((s + 1) * NUG)}, Dep{nullptr, 0}, Dep{nullptr, 0}, abort_w, &s_ok)) return; }
+                PROF_T(t1);
+                PROF_ADD(24, t1, t0);
                 const int ct = (query ? k : k - NQ4) * 4 + wave;               // this wave's 16-column tile
                 const int nct = query ? W / 16 : Vp / 16;
-                int row = rb * 16 + (lane & 15); row = row < R ? row : R - 1;
-                const int kg4 = 4 * (lane >> 4);
+                stage_rows(s_a, lda, 0, pa.h[D - 1] + (long long)(s + 1) * RW, W, W, rb, R, tid);
+                __syncthreads();
                 if (ct < nct) {
-                    const ASeg s0{pa.h[D - 1] + (long long)(s + 1) * RW + (long long)row * W + kg4, W / 16};
-                    const float* b = (query ? pa.wa : pa.e) + ((long long)(ct * 16 + (lane & 15))) * W + kg4;
-                    const f32x4 acc = k_loop<false>(s0, ASeg{nullptr, 0}, ASeg{nullptr, 0}, b, 0, lane, RowStat{0.f, 1.f, 0}, V, 0);
+                    const f32x4 acc = k_loop(s_a, lda, b, ring, 0, W / 16, lane);
                     const int col = ct * 16 + (lane & 15);
                     const float bias = query ? pa.bUW[col] : 0.0f;
                     float* out = query ? pa.wq + (long long)(s + 1) * RW : pa.logits + (long long)(s + 1) * R * Vp;
@@ -393,7 +455,11 @@ __global__ __launch_bounds__(256, 3) void persist_decode_kernel(const PersistArg
                         if (orow < R) store_sc1(out + (long long)orow * ld + col, acc[q] + bias);
                     }
                 }
+                PROF_T(t2);
+                PROF_ADD(25, t2, t1);
                 publish(counter(rb, query ? D + 2 : D + 1));
+                PROF_T(t3);
+                PROF_ADD(26, t3, t2);
             }
         }
     }
@@ -404,8 +470,17 @@ size_t persist_counter_bytes(int R, int D) {
     return (nrb * (D + 3) * 32 + 32) * sizeof(unsigned);
 }
 
-void launch_persist_decode(const PersistArgs& pa, hipStream_t stream) {
-    hipLaunchKernelGGL(persist_decode_kernel, dim3(pa.g_lstm + pa.g_att + pa.g_plain), dim3(256), 0, stream, pa);
+size_t persist_lds_bytes(const PersistArgs& pa) { return (size_t)16 * pa.lda * sizeof(float); }
+
+int launch_persist_decode(const PersistArgs& pa, hipStream_t stream) {
+    const size_t lds = persist_lds_bytes(pa);
+    if (lds > 150 * 1024) return -1;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -1;
+    }
+    hipLaunchKernelGGL(persist_decode_kernel, dim3(pa.g_lstm + pa.g_att + pa.g_plain), dim3(256), lds, stream, pa);
+    return 0;
 }
 
 }  // namespace casv

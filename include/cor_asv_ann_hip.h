@@ -161,7 +161,7 @@ int casv_train_end(casv_model* m);
 /* Measurement support for bench.py: per-kernel HIP-event timing on the library's stream.
  * casv_profile(m, 1) starts recording for all kernel classes, casv_profile(m, 2) only for "lstm_gemm" (fewer
  * event records inside a timed region), casv_profile(m, 0) stops; casv_profile_read returns, for kernel class `name`
- * ("lstm_gemm", "gemm", "attention", "softmax", "beam", "embed"), the number of launches, their
+ * ("lstm_gemm", "lstm_gemm_small", "gemm", "attention", "softmax", "beam", "embed", "persist"), the number of launches, their
  * summed duration (ms) and their summed algorithmic FLOPs and bytes. */
 int casv_profile(casv_model* m, int32_t enable);
 int casv_profile_read(casv_model* m, const char* name, int64_t* launches, double* total_ms,
@@ -171,6 +171,9 @@ int casv_profile_read(casv_model* m, const char* name, int64_t* launches, double
 int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K, int32_t gather,
                     int32_t iters, double* ms_per_launch);
 /* Options: "graph" = replay the decode step through a captured hipGraph (1) or launch kernels eagerly (0);
+ * "persistent" = greedy decoding through the persistent decoder (all steps in ONE launch, workgroups hand rows to each
+ * other through memory: small batches, where a step is too short for a launch per kernel): -1 by batch size (default:
+ * up to 512 lines), 0 never, 1 always -- the results are the same bit for bit;
  * "eos" = vocabulary index of the end-of-line character '\n' (default 1: '' and '\n' sort first, seq2seq.py:580);
  * "tile" (process-wide; alias "skinny") = tile shape of the GEMM launches: -1 by size (default), 0 always 128x128,
  * 1 always 32x128 -- a measurement/test switch, the values computed are the same bit for bit. */
