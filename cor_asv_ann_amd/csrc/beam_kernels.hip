@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
     __shared__ double pop_key[64];
 
     const int line = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int step = *s.step_ptr;
+    const int step = s.step_ptr ? *s.step_ptr : s.step_imm;
     if (s.line_done[line]) return;
     const int N = p.N, V = s.V, Vp = (V + 31) & ~31, T = s.T, R = s.R;
     const int CMAX = (p.width_in < V ? p.width_in : V) + 1;      // children per expansion: <= min(width_in, V) + the late rejection

@@ -188,7 +188,8 @@ struct BeamState {
     const float* p_base;        // score store
     const double* apos; const int* amax1;
     const int* src_rej;         // [B][T]
-    const int* step_ptr;
+    const int* step_ptr;        // step number in device memory (graph replay), or nullptr: step_imm
+    int step_imm;
 };
 void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t stream);
 void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream);

@@ -523,31 +523,32 @@ extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, 
     return CASV_OK;
 }
 
-// Runs iterations of `body` (which launches one step reading *d_step) eagerly, or as replays of ONE
-// hipGraph captured at the first call (every pointer in a step is static; only *d_step moves).
+// Runs iterations of `body(step_ptr, step_imm)` (which launches one step).  Eagerly the host passes the step number as
+// an immediate -- no kernel has to fetch it from memory first (a dependent load of a line another kernel just wrote, at
+// the head of every launch) and no kernel has to advance it.  Under "graph" the iterations are replays of ONE hipGraph
+// captured at the first call, whose kernels read the step from device memory and whose last node advances it.
 struct StepRunner {
     casv_model* m; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     explicit StepRunner(casv_model* m_) : m(m_) {}
-    template <class F> int run(int n, F body) {
+    template <class F> int run(int first, int n, F body) {
         if (m->use_graph && !m->prof.on) {
             if (!exec) {
                 HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
-                body();
+                body(m->d_step.as<int>(), 0);
                 launch_advance_step(m->d_step.as<int>(), m->stream);
-                HIPCHK(hipStreamEndCapture(m->stream, &graph));
+                hipError_t e = hipStreamEndCapture(m->stream, &graph);        // also on the way out of a failed capture
+                if (e != hipSuccess) { graph = nullptr; return fail(CASV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
                 HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             }
             for (int s = 0; s < n; ++s) HIPCHK(hipGraphLaunch(exec, m->stream));
             return 0;
         }
-        for (int s = 0; s < n; ++s) {
-            body();
-            launch_advance_step(m->d_step.as<int>(), m->stream);
-        }
+        for (int s = 0; s < n; ++s) body(nullptr, first + s);
         return 0;
     }
     ~StepRunner() {
-        if (exec) { (void)hipStreamSynchronize(m->stream); (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); }
+        if (exec) { (void)hipStreamSynchronize(m->stream); (void)hipGraphExecDestroy(exec); }
+        if (graph) (void)hipGraphDestroy(graph);
     }
 };
 
@@ -650,13 +651,12 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (int rc = init_root(m, 1)) return rc;
     HIPCHK(hipMemsetAsync(m->o_idx.p, 0, (size_t)B * S * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->o_prob.p, 0, (size_t)B * S * 4, m->stream));
-    const int* sp = m->d_step.as<int>();
     if (persist_applies(m, B)) {
         if (int rc = decode_greedy_persistent(m, mode, S)) return rc;
     } else {
         StepRunner runner(m);
-        if (int rc = runner.run(S, [&]() {
-                launch_step(m, false, mode, nullptr, 1, m->o_idx.as<int>(), m->o_prob.as<float>(), sp, 0);
+        if (int rc = runner.run(0, S, [&](const int* step_ptr, int step_imm) {
+                launch_step(m, false, mode, nullptr, 1, m->o_idx.as<int>(), m->o_prob.as<float>(), step_ptr, step_imm);
             })) return rc;
     }
     HIPCHK(hipGetLastError());
@@ -749,12 +749,13 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     // steps), otherwise once a line has finished; not under graph replay, whose kernel arguments are fixed at capture.
     m->skip_nact = (N >= 128 && !m->use_graph) ? m->b_nact.as<int>() : nullptr; m->skip_group = N;
     launch_beam_init(s, p, m->stream);
-    const int* sp = m->d_step.as<int>();
-    auto body = [&]() {
-        launch_step(m, true, -1, nullptr, N, nullptr, nullptr, sp, 0);
+    auto body = [&](const int* step_ptr, int step_imm) {
+        launch_step(m, true, -1, nullptr, N, nullptr, nullptr, step_ptr, step_imm);
         hipEvent_t ev{};
         m->prof_begin(PC_BEAM, 0.0, 4.0 * R * (2.0 * m->Vp), ev);
-        launch_beam_step(s, p, m->stream);
+        BeamState sb = s;
+        sb.step_ptr = step_ptr; sb.step_imm = step_imm;
+        launch_beam_step(sb, p, m->stream);
         m->prof_end(PC_BEAM, ev);
     };
     // the host looks at the number of unfinished lines every `chunk` iterations
@@ -763,7 +764,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     StepRunner runner(m);
     while (done_steps < S) {
         const int n = (S - done_steps) < chunk ? (S - done_steps) : chunk;
-        if (int rc = runner.run(n, body)) return rc;
+        if (int rc = runner.run(done_steps, n, body)) return rc;
         done_steps += n;
         int active = 0;
         HIPCHK(hipMemcpyAsync(&active, m->b_active.p, 4, hipMemcpyDeviceToHost, m->stream));

@@ -15,7 +15,7 @@ namespace casv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SBM = 32, SBN = 128, SBK = 16, SDEPTH = 4;      // prefetch depth 4 = 6 > 8 K-tiles (measured)
+constexpr int SBM = 32, SBN = 128, SBK = 16, SDEPTH = 4;      // prefetch depth 4 = 6 = 8 K-tiles (measured; in round 2 again: 8 gains 2 % on the train step, nothing on decode)
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch batch) {

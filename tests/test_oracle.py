@@ -187,3 +187,85 @@ def test_golden_fixtures_match_oracle(golden_dir):
                 assert np.array_equal(got[k], v), (name, k)
             else:
                 assert np.allclose(got[k], v, rtol=2e-5, atol=1e-6, equal_nan=True), (name, k)
+
+
+def test_attention_cell_known_answer():
+    """attention.py:526-575 by hand: W_a = 0 and b_UW = 0 make the query vanish, u[s] = (c_s, 0), v_a = (1, 0), b_v = 0.5
+    give the energy exp(tanh(c_s) + 0.5); the previous alignment sits on position 3, so t' = 4 and positions 0..9 of the
+    12 survive the |t' - s| <= 5 mask; the context is the weighted mean of the attended rows."""
+    import math
+    cfg = ModelConfig(depth=2, width=2, voc_size=4)
+    T = 12
+    c = [0.1 * s - 0.4 for s in range(T)]
+    w = {'att_Wa': np.zeros((2, 2)), 'att_bUW': np.zeros(2), 'att_va': np.array([1.0, 0.0]), 'att_bv': np.array([0.5])}
+    u = np.array([[[cs, 0.0] for cs in c]])
+    enc = np.array([[[float(s), 1.0 - s] for s in range(T)]])
+    a_prev = np.zeros((1, T)); a_prev[0, 3] = 1.0
+    ctx, a = attention(cfg, w, np.array([[7.0, -3.0]]), a_prev, enc, u)
+    e = [math.exp(math.tanh(c[s]) + 0.5) if abs(4.0 - s) <= 5 else 0.0 for s in range(T)]
+    tot = sum(e)
+    assert e[10] == 0.0 and e[9] > 0.0 and e[0] > 0.0
+    assert np.allclose(a[0], [x / tot for x in e], atol=1e-15)
+    assert np.allclose(ctx[0], [sum(e[s] / tot * s for s in range(T)), sum(e[s] / tot * (1.0 - s) for s in range(T))], atol=1e-13)
+    # a query that is not zero shifts every energy's argument by the same h.W_a + b_UW
+    w2 = dict(w, att_Wa=np.array([[0.2, 0.0], [0.0, 0.0]]), att_bUW=np.array([0.05, 0.0]))
+    _, a2 = attention(cfg, w2, np.array([[1.5, 9.0]]), a_prev, enc, u)
+    e2 = [math.exp(math.tanh(c[s] + 0.2 * 1.5 + 0.05) + 0.5) if abs(4.0 - s) <= 5 else 0.0 for s in range(T)]
+    assert np.allclose(a2[0], [x / sum(e2) for x in e2], atol=1e-15)
+
+
+def test_tied_projection_and_softmax_known_answer():
+    """seq2seq.py:379 `softmax(h . E^T)` with the SAME matrix that embeds the input (seq2seq.py:239-243), through a
+    whole decoder step: all kernels zero, so the top cell's output is o * tanh(i * g) with gates set by the bias alone,
+    the attention is uniform over its window, and the probabilities are softmax(E h) by hand."""
+    import math
+    cfg = ModelConfig(depth=1, width=2, voc_size=3)
+    W, C, V, T = 2, 4, 3, 5
+    E = np.array([[1.0, 0.0], [0.0, 2.0], [1.0, 1.0]])
+    sig = lambda v: 1 / (1 + math.exp(-v))
+    bias = np.array([0.3, -0.2, 50.0, 50.0, 0.7, 0.1, 2.0, -1.0])        # i (2), f (2), c~ (2), o (2)
+    w = {'E': E, 'att_U': np.zeros((C, W)), 'att_Wa': np.zeros((W, W)), 'att_bUW': np.zeros(W), 'att_va': np.zeros(W),
+         'att_bv': np.zeros(1), 'dec1_K': np.zeros((W + C, 4 * W)), 'dec1_R': np.zeros((W, 4 * W)), 'dec1_b': bias}
+    enc = np.arange(T * C, dtype=np.float64).reshape(1, T, C)
+    states = [np.zeros((1, W)), np.zeros((1, W)), np.zeros((1, T))]        # h, c = 0: the forget gate does not matter
+    p, new = decoder_step(cfg, w, np.array([[0.2, 0.5, 0.3]]), enc, states)
+    h = [sig(bias[6 + k]) * math.tanh(sig(bias[k]) * math.tanh(bias[4 + k])) for k in range(W)]
+    logits = [E[v, 0] * h[0] + E[v, 1] * h[1] for v in range(V)]
+    z = sum(math.exp(x) for x in logits)
+    assert np.allclose(new[0][0], h, atol=1e-15)
+    assert np.allclose(p[0], [math.exp(x) / z for x in logits], atol=1e-15) and abs(p.sum() - 1) < 1e-15
+    assert np.allclose(new[2][0], [0.2] * 5, atol=1e-15)                   # zero energies: uniform over the window s <= 6
+
+
+def test_oracle_matches_keras_goldens(golden_dir):
+    """Reference-generated fixtures (tests/golden/make_keras_goldens.py, run where Keras 2.3 / TF 1.15 exist) pin the
+    oracle to the reference itself.  None can be produced in this pipeline: until someone drops them into
+    tests/golden/keras/, parity stays "unpinned" and this test says so."""
+    import glob
+    from tests.golden.make_golden import CASES, NTENS
+    files = sorted(glob.glob(os.path.join(os.environ.get('CASV_GOLDEN_DIR', os.path.join(golden_dir, 'keras')), '*.npz')))
+    if not files:
+        pytest.skip('no reference-generated fixtures under tests/golden/keras (parity unpinned: see DESIGN.md section 3)')
+    for path in files:
+        name = os.path.splitext(os.path.basename(path))[0]
+        d, W, V, B, L, seed, es, N = CASES[name]
+        cfg = ModelConfig(depth=d, width=W, voc_size=V)
+        m = OracleModel(cfg, make_weights(cfg, emb_scale=es), batch_size=N)
+        with np.load(path) as f:
+            g = {k: f[k] for k in f.files}
+        lines, _ = make_lines(B, L, seed, voc_size=V)
+        enc_in, _, _, _ = vectorize_lines(m, lines, [[] for _ in lines])
+        enc = m.encode(enc_in)
+        assert np.allclose(enc[0][:NTENS], g['enc_out'], rtol=2e-4, atol=2e-6), name
+        assert np.allclose(np.stack(enc[1:-1])[:, :NTENS], g['enc_states'], rtol=2e-4, atol=2e-6), name
+        p, states = np.zeros((B, V), np.float32), enc[1:]
+        for s in range(3):
+            p, states = m.step(p, enc[0], states)
+            assert np.allclose(p[:NTENS], g['step%d_probs' % s], rtol=2e-4, atol=2e-6), (name, s)
+            assert np.allclose(states[-1][:NTENS], g['step%d_align' % s], rtol=2e-4, atol=2e-6), (name, s)
+        got = decode_batch_greedy(m, enc_in, return_indexes=True)
+        for j in range(B):
+            n = int(g['greedy_len'][j])
+            assert np.array_equal(got[5][j, :n], g['greedy_idx'][j, :n]), (name, j)
+            r = next(decode_sequence_beam(m, source_seq=enc_in[j]), ('', None, 0.0, None))
+            assert r[0] == str(g['beam_text'][j]) and abs(r[2] - g['beam_score'][j]) < 1e-4, (name, j)
