@@ -46,6 +46,7 @@ SIGNATURES = {
     'casv_get_weight': (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     'casv_commit_weights': (c_int, [c_void_p]),
     'casv_encode': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'casv_set_encoder_outputs': (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     'casv_get_encoder_outputs': (c_int, [c_void_p, c_void_p, c_void_p]),
     'casv_decoder_step': (c_int, [c_void_p, c_int32] + [c_void_p] * 7),
     'casv_decode_greedy': (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

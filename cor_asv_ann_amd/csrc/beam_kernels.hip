@@ -372,16 +372,6 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
         if (ftot != s.f_total[line]) { s.f_n[line] = fn; s.f_total[line] = ftot; }
         s.q_n[line] = qn - h; s.q_n[s.B + line] = h;
         sh_nb = nb; sh_done = done;
-        if (!done && N <= 16) {       // statistic: rows of the next step and how many different parent expansions they continue
-            int distinct = 0;
-            for (int a = 0; a < nb; ++a) {
-                const int ea = s.n_exp[nbase + r_count[a]];
-                bool seen = false;
-                for (int b = 0; b < a; ++b) seen |= s.n_exp[nbase + r_count[b]] == ea;
-                distinct += seen ? 0 : 1;
-            }
-            atomicAdd(s.active_lines + 2, nb); atomicAdd(s.active_lines + 3, distinct);
-        }
         if (done) { s.line_done[line] = 1; s.nact[line] = 0; atomicSub(s.active_lines, 1); }
         else s.nact[line] = nb;
     }

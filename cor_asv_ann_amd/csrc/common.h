@@ -225,6 +225,17 @@ struct PersistArgs {
     int g_lstm, g_att, g_plain;            // workgroups per role
     unsigned long long* prof;              // diagnostic build only (CASV_PERSIST_PROF): 32 tick sums, see persist.hip
 };
+// persistent encoder: x0 [B][T][W] embedded input, H1 [B][T][2W] layer-1 outputs (fw | bw), Hn[n-2] [B][T][W] outputs of layer
+// n >= 2, cfin [(D+1)][B][W] final cell states (slot 0: backward direction of layer 1, slot n-1: layer n, slot D: forward)
+struct PersistEncArgs {
+    int B, T, D, W, lda;
+    PersistLayer l1[2];            // forward, backward
+    PersistLayer ln[7];            // layers 2..D
+    const float* x0; float* H1; float* Hn[7]; float* cfin;
+    unsigned* counters;            // persist_enc_counter_bytes(); zeroed ahead of the launch
+};
+size_t persist_enc_counter_bytes(int B, int D);
+int launch_persist_encode(const PersistEncArgs& pa, int grid, hipStream_t stream);
 size_t persist_counter_bytes(int R, int D);
 size_t persist_lds_bytes(const PersistArgs& pa);
 int launch_persist_decode(const PersistArgs& pa, hipStream_t stream);   // -1: the staged rows do not fit the LDS

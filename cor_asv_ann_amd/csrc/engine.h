@@ -31,10 +31,12 @@ inline int fail(int code, const char* fmt, ...) {
     return fail(e_ == hipErrorOutOfMemory ? CASV_ERR_NOMEM : CASV_ERR_HIP, "%s failed: %s (%s:%d)", #x, \
                 hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+inline long g_devbuf_generation = 0;    // bumped by every (re)allocation: captured hipGraphs hold raw pointers
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
+        ++g_devbuf_generation;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         hipError_t e = hipMalloc(&p, bytes);
@@ -46,7 +48,7 @@ struct DevBuf {
         if (poison) (void)hipMemset(p, 0xFF, bytes);
         return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) { (void)hipFree(p); ++g_devbuf_generation; } p = nullptr; cap = 0; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -105,6 +107,7 @@ struct casv_model {
     bool encoded = false;
     DevBuf d_idx, d_val, d_srcrej, x0, H1, Ha, Hb, Hc, cfin, hfin, u;
     float* enc_out = nullptr;
+    DevBuf a0; bool has_a0 = false;                       // initial alignment handed in with casv_set_encoder_outputs
     // decode session
     int R = 0, S = 0;
     std::vector<DevBuf> st_h, st_c;
@@ -124,6 +127,9 @@ struct casv_model {
     bool use_graph = false;
     const int* skip_nact = nullptr;                       // beam decode: live rows per line, handed to the step's kernels when
     int skip_group = 0;                                   // skipping can pay (wide beams, or a line has finished); rows per line
+    // the captured step graph of the last decode configuration (option "graph"): kept across calls, rebuilt when the
+    // configuration or any device buffer changes
+    hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; std::string step_graph_key;
     int stat_beam[3] = {0, 0, 0};                         // last beam decode: most new hypotheses of one line in one step; rows stepped
                                                           // and distinct parent expansions among them (N <= 16 only)
     Prof prof;

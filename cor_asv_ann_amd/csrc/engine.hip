@@ -1,6 +1,7 @@
 // Host side of the C ABI (include/cor_asv_ann_hip.h): weight repacking, the encoder (seq2seq.py:237-314),
 // the decoder step (seq2seq.py:416-480) and the greedy / beam decode loops (seq2seq.py:1215-1544).
 #include "engine.h"
+#include <mutex>
 
 static std::map<std::string, size_t> expected_shapes(const casv_config& c) {
     const size_t W = c.width, V = c.voc_size, D = c.depth, C = (D == 1 ? 2 * W : W);
@@ -64,18 +65,21 @@ extern "C" void casv_model_destroy(casv_model* m) {
     DevBuf* bufs[] = {&m->E, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
         &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->Hc, &m->cfin,
         &m->hfin, &m->u, &m->st_a, &m->st_p, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
-        &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->st_win, &m->sp_lo, &m->sp_w, &m->b_parent, &m->b_chr, &m->b_prob,
+        &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->a0, &m->st_win, &m->sp_lo, &m->sp_w, &m->b_parent, &m->b_chr, &m->b_prob,
         &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos, &m->b_pos, &m->b_is1, &m->b_count, &m->b_created,
         &m->b_gkey, &m->b_gid, &m->b_qkey, &m->b_qid, &m->b_qn, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_beamnode, &m->b_nact,
         &m->b_done, &m->b_steps, &m->b_active, &m->bo_idx, &m->bo_prob, &m->bo_len, &m->bo_score,
         &m->bo_rej, &m->bo_align, &m->bo_found, &m->bo_nsteps};
     for (DevBuf* b : bufs) b->release();
-    for (auto& l : m->enc) { l.wt.release(); l.bias.release(); }
+    for (auto& l : m->enc) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
+    for (LstmW* l : {&m->enc_fw, &m->enc_bw}) { l->pw.release(); l->pbias.release(); }
     for (auto& l : m->dec) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
     for (DevBuf* b : {&m->WaP, &m->EP, &m->p_ctx, &m->p_wq, &m->p_logits, &m->p_counters}) b->release();
     for (auto& b : m->st_h) b.release();
     for (auto& b : m->st_c) b.release();
     (void)casv_train_release(m);
+    if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
+    if (m->step_graph) (void)hipGraphDestroy(m->step_graph);
     for (auto e : m->prof.pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(m->ev_inputs);
     (void)hipStreamDestroy(m->stream);
@@ -183,9 +187,9 @@ extern "C" int casv_commit_weights(casv_model* m) {
     const int W = m->W, C = m->C, D = m->D;
     const auto& E = m->host["E"];
     if (int rc = upload(m->E, E)) return rc;
-    if (int rc = pack_lstm(m, m->enc_fw, "enc1_fw", W)) return rc;
-    if (int rc = pack_lstm(m, m->enc_bw, "enc1_bw", W)) return rc;
-    for (int n = 2; n <= D; ++n) if (int rc = pack_lstm(m, m->enc[n], "enc" + std::to_string(n), n == 2 ? 2 * W : W)) return rc;
+    if (int rc = pack_lstm(m, m->enc_fw, "enc1_fw", W, true)) return rc;
+    if (int rc = pack_lstm(m, m->enc_bw, "enc1_bw", W, true)) return rc;
+    for (int n = 2; n <= D; ++n) if (int rc = pack_lstm(m, m->enc[n], "enc" + std::to_string(n), n == 2 ? 2 * W : W, true)) return rc;
     if (D == 1) {
         if (int rc = pack_dec1(m, m->dec[1], "dec1", C)) return rc;
     } else {
@@ -215,6 +219,19 @@ extern "C" int casv_commit_weights(casv_model* m) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent launches (persist.hip) are serialised inside the process: two of them together can want more workgroup slots
+// than the chip has, and workgroups that spin on peers which are not resident never make room for them.  (Across processes
+// the bounded spins catch that case: the launch aborts and the caller falls back to the per-step kernels.)
+static std::mutex g_persist_mutex;
+static bool persist_enc_applies(const casv_model* m, int B) {
+    if (m->persist_mode == 0 || m->ncu < 64 || m->D > 8) return false;
+    const int W = m->W, D = m->D;
+    if ((size_t)16 * ((D >= 2 ? 3 * W : 2 * W) + 4) * 4 > 150 * 1024) return false;        // staged rows must fit the LDS
+    const int ntile = ((B + 15) / 16) * (W / 16), grid = std::min(std::max(2, D - 1) * ntile, 2 * m->ncu);
+    if ((2 * ntile + grid - 1) / grid > 8 || ((D - 1) * ntile + grid - 1) / grid > 8) return false;   // tiles per workgroup (PENC_MAXT)
+    return m->persist_mode == 1 ? B <= 4096 : B <= 512;
+}
+
 extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const int32_t* idx, const float* val,
                            const int32_t* src_rej) {
     if (!m || !idx || !val) return fail(CASV_ERR_ARG, "null argument");
@@ -243,7 +260,7 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
     HIPCHK(hipEventRecord(m->ev_inputs, m->stream));
     HIPCHK(hipEventSynchronize(m->ev_inputs));
     m->B = B; m->T = T; m->A = A;
-    m->last_decode = 0;
+    m->last_decode = 0; m->has_a0 = false;
 
     hipEvent_t ev{};
     m->prof_begin(PC_EMBED, 2.0 * BT * A * W, 4.0 * BT * W * (A + 1), ev);
@@ -272,16 +289,6 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         g.step_imm = t; g.step_ptr = nullptr;
         return g;
     };
-    for (int t = 0; t < T; ++t) {
-        GemmBatch b{};
-        b.g[0] = layer1_job(0, t); b.g[1] = layer1_job(1, t); b.count = 2;
-        run_gemm_batch(m, EPI_LSTM, b);
-    }
-    // backward final h = output at time 0 (seq2seq.py:280)
-    launch_scatter_rows(H1 + W, T * 2 * W, m->hfin.as<float>(), W, B, W, 1, m->stream);
-    // layers 2..D (seq2seq.py:283): cell (n, t) needs (n-1, t) and (n, t-1); the cells of one
-    // anti-diagonal k = t + (n-2) are independent -> one launch per diagonal (<= GEMM_MAX_JOBS cells,
-    // deeper stacks are cut into groups of GEMM_MAX_JOBS layers)
     std::vector<float*> lout(D + 1, nullptr);
     lout[1] = H1;
     for (int n = 2; n <= D; ++n) lout[n] = (n % 2 == 0) ? m->Ha.as<float>() : m->Hb.as<float>();
@@ -289,6 +296,50 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         if (int rc = m->Hc.ensure((size_t)(D - 1) * BT * W * 4)) return rc;
         for (int n = 2; n <= D; ++n) lout[n] = m->Hc.as<float>() + (size_t)(n - 2) * BT * W;
     }
+    // Small batches: the whole encoder in one launch of the persistent encoder (persist.hip; same values bit for bit)
+    bool persistent = persist_enc_applies(m, B);
+    if (persistent) {
+        std::lock_guard<std::mutex> lock(g_persist_mutex);
+        const size_t cbytes = persist_enc_counter_bytes(B, D);
+        if (int rc = m->p_counters.ensure(cbytes)) return rc;
+        HIPCHK(hipMemsetAsync(m->p_counters.p, 0, cbytes, m->stream));
+        PersistEncArgs pa{};
+        pa.B = B; pa.T = T; pa.D = D; pa.W = W; pa.lda = (D >= 2 ? 3 * W : 2 * W) + 4;
+        pa.l1[0] = PersistLayer{m->enc_fw.pw.as<float>(), m->enc_fw.pbias.as<float>(), 2 * W};
+        pa.l1[1] = PersistLayer{m->enc_bw.pw.as<float>(), m->enc_bw.pbias.as<float>(), 2 * W};
+        for (int n = 2; n <= D; ++n) {
+            pa.ln[n - 2] = PersistLayer{m->enc[n].pw.as<float>(), m->enc[n].pbias.as<float>(), m->enc[n].kin + W};
+            pa.Hn[n - 2] = lout[n];
+        }
+        pa.x0 = x0; pa.H1 = H1; pa.cfin = cfin; pa.counters = m->p_counters.as<unsigned>();
+        const int nrb = (B + 15) / 16, ntile = nrb * (W / 16);
+        const int grid = std::min(std::max(2, D - 1) * ntile, 2 * m->ncu);
+        hipEvent_t pev{};
+        m->prof_begin(PC_PERSIST, 2.0 * BT * 4.0 * W * (2.0 * 2 * W + (D >= 2 ? 3.0 * W : 0.0) + (D >= 3 ? (D - 2) * 2.0 * W : 0.0)), 0.0, pev);
+        if (launch_persist_encode(pa, grid, m->stream)) return fail(CASV_ERR_ARG, "persistent encoder: rows do not fit the LDS");
+        m->prof_end(PC_PERSIST, pev);
+        HIPCHK(hipGetLastError());
+        unsigned aborted = 0;
+        HIPCHK(hipMemcpyAsync(&aborted, m->p_counters.as<unsigned>() + (size_t)nrb * (D + 1) * 32, 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (aborted) {
+            static bool told = false;
+            if (!told) { fprintf(stderr, "cor_asv_ann_hip: persistent encoder gave up waiting (GPU shared with another persistent kernel?); using the per-step kernels\n"); told = true; }
+            persistent = false;
+        }
+    }
+    if (!persistent) {
+    for (int t = 0; t < T; ++t) {
+        GemmBatch b{};
+        b.g[0] = layer1_job(0, t); b.g[1] = layer1_job(1, t); b.count = 2;
+        run_gemm_batch(m, EPI_LSTM, b);
+    }
+    }
+    // backward final h = output at time 0 (seq2seq.py:280)
+    launch_scatter_rows(H1 + W, T * 2 * W, m->hfin.as<float>(), W, B, W, 1, m->stream);
+    // layers 2..D (seq2seq.py:283): cell (n, t) needs (n-1, t) and (n, t-1); the cells of one
+    // anti-diagonal k = t + (n-2) are independent -> one launch per diagonal (<= GEMM_MAX_JOBS cells,
+    // deeper stacks are cut into groups of GEMM_MAX_JOBS layers)
     auto layer_job = [&](int n, int t) {
         GemmArgs g{};
         const int win = n == 2 ? 2 * W : W;
@@ -304,7 +355,7 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         g.step_imm = t;
         return g;
     };
-    for (int n0 = 2; n0 <= D; n0 += GEMM_MAX_JOBS) {
+    for (int n0 = 2; n0 <= D && !persistent; n0 += GEMM_MAX_JOBS) {
         const int n1 = std::min(D, n0 + GEMM_MAX_JOBS - 1);
         for (int k = 0; k < T + (n1 - n0); ++k) {
             GemmBatch b{};
@@ -322,6 +373,49 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
     m->enc_out = D == 1 ? H1 : outb;
     // u = attention_dense(enc_out) once per line (seq2seq.py:313; the reference redoes it every step)
     {
+        GemmArgs g{};
+        g.nseg = 1; g.a[0] = mkseg(m->enc_out, C, C, 0);
+        g.Bt = m->UT.as<float>(); g.bias = nullptr; g.M = (int)BT; g.N = W; g.Ktot = C;
+        g.out = mkslot(m->u.as<float>(), W);
+        run_gemm(m, EPI_PLAIN, g);
+    }
+    HIPCHK(hipGetLastError());
+    m->encoded = true;
+    return CASV_OK;
+}
+
+extern "C" int casv_set_encoder_outputs(casv_model* m, int32_t B, int32_t T, const float* enc_out, const float* states,
+                                        const float* a0, const int32_t* src_rej) {
+    if (!m || !enc_out || !states) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->committed) return fail(CASV_ERR_STATE, "weights not committed");
+    if (B < 1 || T < 1) return fail(CASV_ERR_ARG, "bad shape B=%d T=%d", B, T);
+    if (T > CASV_MAX_T) return fail(CASV_ERR_ARG, "line length %d exceeds the supported maximum of %d", T, CASV_MAX_T);
+    HIPCHK(hipSetDevice(m->device));
+    const int W = m->W, C = m->C, D = m->D;
+    const size_t BT = (size_t)B * T, BW = (size_t)B * W;
+    if (int rc = m->Hc.ensure(std::max((size_t)(D - 1), (size_t)1) * BT * std::max(W, C) * 4)) return rc;
+    if (int rc = m->d_srcrej.ensure(BT * 4)) return rc;
+    if (int rc = m->cfin.ensure((size_t)(D + 1) * BW * 4)) return rc;
+    if (int rc = m->hfin.ensure((size_t)D * BW * 4)) return rc;
+    if (int rc = m->u.ensure(BT * W * 4)) return rc;
+    m->enc_out = m->Hc.as<float>();
+    HIPCHK(hipMemcpyAsync(m->enc_out, enc_out, BT * C * 4, hipMemcpyHostToDevice, m->stream));
+    for (int n = 0; n < D; ++n) {
+        HIPCHK(hipMemcpyAsync(m->hfin.as<float>() + n * BW, states + (size_t)(2 * n) * BW, BW * 4, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(m->cfin.as<float>() + n * BW, states + (size_t)(2 * n + 1) * BW, BW * 4, hipMemcpyHostToDevice, m->stream));
+    }
+    if (src_rej) HIPCHK(hipMemcpyAsync(m->d_srcrej.p, src_rej, BT * 4, hipMemcpyHostToDevice, m->stream));
+    else HIPCHK(hipMemsetAsync(m->d_srcrej.p, 0xff, BT * 4, m->stream));
+    m->has_a0 = a0 != nullptr;
+    if (a0) {
+        if (int rc = m->a0.ensure(BT * 4)) return rc;
+        HIPCHK(hipMemcpyAsync(m->a0.p, a0, BT * 4, hipMemcpyHostToDevice, m->stream));
+    }
+    HIPCHK(hipEventRecord(m->ev_inputs, m->stream));
+    HIPCHK(hipEventSynchronize(m->ev_inputs));
+    m->B = B; m->T = T; m->A = 1;
+    m->last_decode = 0;
+    {   // u = attention_dense(enc_out) (seq2seq.py:313,459-460)
         GemmArgs g{};
         g.nseg = 1; g.a[0] = mkseg(m->enc_out, C, C, 0);
         g.Bt = m->UT.as<float>(); g.bias = nullptr; g.M = (int)BT; g.N = W; g.Ktot = C;
@@ -376,6 +470,7 @@ static int ensure_session(casv_model* m, int R, int S) {
 static int init_root(casv_model* m, int rows_per_line) {
     const int W = m->W, Vp = m->Vp, T = m->T, D = m->D, R = m->R, B = m->B;
     HIPCHK(hipMemsetAsync(m->st_a.p, 0, (size_t)R * T * 4, m->stream));
+    if (m->has_a0) launch_scatter_rows(m->a0.as<float>(), T, m->st_a.as<float>(), T, B, T, rows_per_line, m->stream);
     HIPCHK(hipMemsetAsync(m->st_p.p, 0, (size_t)R * Vp * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->logits.p, 0, (size_t)R * Vp * 4, m->stream));
     for (int n = 1; n <= D; ++n) {
@@ -528,30 +623,35 @@ extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, 
 // the head of every launch) and no kernel has to advance it.  Under "graph" the iterations are replays of ONE hipGraph
 // captured at the first call, whose kernels read the step from device memory and whose last node advances it.
 struct StepRunner {
-    casv_model* m; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-    explicit StepRunner(casv_model* m_) : m(m_) {}
+    casv_model* m; std::string key;
+    StepRunner(casv_model* m_, const std::string& key_) : m(m_), key(key_ + "/" + std::to_string(g_devbuf_generation)) {}
+    static void drop(casv_model* m) {
+        if (m->step_exec) { (void)hipStreamSynchronize(m->stream); (void)hipGraphExecDestroy(m->step_exec); m->step_exec = nullptr; }
+        if (m->step_graph) { (void)hipGraphDestroy(m->step_graph); m->step_graph = nullptr; }
+        m->step_graph_key.clear();
+    }
     template <class F> int run(int first, int n, F body) {
         if (m->use_graph && !m->prof.on) {
-            if (!exec) {
+            if (!m->step_exec || m->step_graph_key != key) {
+                drop(m);
                 HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
                 body(m->d_step.as<int>(), 0);
                 launch_advance_step(m->d_step.as<int>(), m->stream);
-                hipError_t e = hipStreamEndCapture(m->stream, &graph);        // also on the way out of a failed capture
-                if (e != hipSuccess) { graph = nullptr; return fail(CASV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
-                HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                hipError_t e = hipStreamEndCapture(m->stream, &m->step_graph);        // also the way out of a failed capture
+                if (e != hipSuccess) { m->step_graph = nullptr; return fail(CASV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
+                e = hipGraphInstantiate(&m->step_exec, m->step_graph, nullptr, nullptr, 0);
+                if (e != hipSuccess) { m->step_exec = nullptr; drop(m); return fail(CASV_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+                m->step_graph_key = key;
             }
-            for (int s = 0; s < n; ++s) HIPCHK(hipGraphLaunch(exec, m->stream));
+            for (int s = 0; s < n; ++s) HIPCHK(hipGraphLaunch(m->step_exec, m->stream));
             return 0;
         }
         for (int s = 0; s < n; ++s) body(nullptr, first + s);
         return 0;
     }
-    ~StepRunner() {
-        if (exec) { (void)hipStreamSynchronize(m->stream); (void)hipGraphExecDestroy(exec); }
-        if (graph) (void)hipGraphDestroy(graph);
-    }
 };
 
+// (declared ahead of casv_encode, which uses them too)
 // All S greedy steps in ONE launch of the persistent decoder (persist.hip): small batches, where the per-step kernels are
 // bound by launch and memory latency.  Same results bit for bit (tested), same state / alignment / window stores.
 static bool persist_applies(const casv_model* m, int B) {
@@ -562,7 +662,9 @@ static bool persist_applies(const casv_model* m, int B) {
     if ((size_t)16 * (kmax + 4) * 4 > 150 * 1024) return false;   // the staged rows must fit the LDS
     return m->persist_mode == 1 ? B <= 4096 : B <= 512;
 }
-static int decode_greedy_persistent(casv_model* m, int mode, int S) {
+static int decode_greedy_persistent(casv_model* m, int mode, int S, bool* aborted_out) {
+    std::lock_guard<std::mutex> lock(g_persist_mutex);
+    *aborted_out = false;
     const int W = m->W, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
     const size_t slots = (size_t)(S + 1) * R;
     if (int rc = m->p_ctx.ensure(slots * C * 4)) return rc;
@@ -632,8 +734,7 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S) {
     unsigned aborted = 0;
     HIPCHK(hipMemcpyAsync(&aborted, m->p_counters.as<unsigned>() + (size_t)nrb * (D + 3) * 32, 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    if (aborted) return fail(CASV_ERR_HIP, "persistent decoder: a hand-off wait ran out (workgroups not co-resident?); "
-                             "set option 'persistent' to 0 for the per-step kernels");
+    *aborted_out = aborted != 0;
     return 0;
 }
 
@@ -651,10 +752,25 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (int rc = init_root(m, 1)) return rc;
     HIPCHK(hipMemsetAsync(m->o_idx.p, 0, (size_t)B * S * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->o_prob.p, 0, (size_t)B * S * 4, m->stream));
-    if (persist_applies(m, B)) {
-        if (int rc = decode_greedy_persistent(m, mode, S)) return rc;
-    } else {
-        StepRunner runner(m);
+    bool persistent = persist_applies(m, B);
+    if (persistent) {
+        bool aborted = false;
+        if (int rc = decode_greedy_persistent(m, mode, S, &aborted)) return rc;
+        if (aborted) {
+            // a hand-off wait ran out: the workgroups were not all resident (another process running a persistent kernel on
+            // this GPU).  Nothing is lost -- the per-step kernels compute the same values; start over with them.
+            static bool told = false;
+            if (!told) { fprintf(stderr, "cor_asv_ann_hip: persistent decoder gave up waiting (GPU shared with another persistent kernel?); using the per-step kernels\n"); told = true; }
+            if (int rc = init_root(m, 1)) return rc;
+            HIPCHK(hipMemsetAsync(m->o_idx.p, 0, (size_t)B * S * 4, m->stream));
+            HIPCHK(hipMemsetAsync(m->o_prob.p, 0, (size_t)B * S * 4, m->stream));
+            persistent = false;
+        }
+    }
+    if (!persistent) {
+        char key[96];
+        snprintf(key, sizeof key, "greedy/%d/%d/%d/%d/%d", mode, B, T, S, m->eos);
+        StepRunner runner(m, key);
         if (int rc = runner.run(0, S, [&](const int* step_ptr, int step_imm) {
                 launch_step(m, false, mode, nullptr, 1, m->o_idx.as<int>(), m->o_prob.as<float>(), step_ptr, step_imm);
             })) return rc;
@@ -761,7 +877,10 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     // the host looks at the number of unfinished lines every `chunk` iterations
     const int chunk = 16;
     int done_steps = 0;
-    StepRunner runner(m);
+    char key[256];
+    snprintf(key, sizeof key, "beam/%d/%d/%d/%d/%d/%d/%d/%.17g/%.17g/%.17g/%d", B, T, S, N, p.width_in, p.width_out, MR, p.threshold_in,
+             p.rejection, p.cost0, p.eos);
+    StepRunner runner(m, key);
     while (done_steps < S) {
         const int n = (S - done_steps) < chunk ? (S - done_steps) : chunk;
         if (int rc = runner.run(done_steps, n, body)) return rc;
@@ -825,8 +944,6 @@ extern "C" int casv_get_alignments_sparse(casv_model* m, int32_t K, int32_t* out
 extern "C" int casv_get_stat(casv_model* m, const char* key, int64_t* value) {
     if (!m || !key || !value) return fail(CASV_ERR_ARG, "null argument");
     if (!strcmp(key, "beam_max_new_keys")) { *value = m->stat_beam[0]; return CASV_OK; }
-    if (!strcmp(key, "beam_rows")) { *value = m->stat_beam[1]; return CASV_OK; }
-    if (!strcmp(key, "beam_distinct_parents")) { *value = m->stat_beam[2]; return CASV_OK; }
     if (!strcmp(key, "beam_sort_capacity")) { *value = 4096; return CASV_OK; }
     return fail(CASV_ERR_ARG, "unknown statistic '%s'", key);
 }

@@ -313,11 +313,14 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
 
 template <int EPI, int KS>
 static void launch_one(const GemmBatch& bb, int blocks, int ksplit, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the (function, device) pair: a second model on another device needs its own
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   GEMM_LDS_BYTES * KS);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((gemm_kernel<EPI, KS>), dim3(blocks, bb.count, ksplit), dim3(256 * KS), GEMM_LDS_BYTES * KS, stream, bb);
 }
@@ -344,7 +347,7 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
     }
     bool splittable = epi == EPI_PLAIN;         // split-K: every job of the batch must ask for it and share the shape
     for (int j = 0; j < b.count; ++j)
-        if (b.g[j].ksplit == 0 || b.g[j].ksplit == 1 || b.g[j].ksplit != b.g[0].ksplit || b.g[j].Ktot != b.g[0].Ktot ||
+        if (b.g[j].step_ptr || b.g[j].ksplit == 0 || b.g[j].ksplit == 1 || b.g[j].ksplit != b.g[0].ksplit || b.g[j].Ktot != b.g[0].Ktot ||
             b.g[j].M != b.g[0].M || b.g[j].N != b.g[0].N) splittable = false;
     auto choose_ksplit = [&](int grid, int want) {
         if (!splittable) return 1;
@@ -387,6 +390,8 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     for (int j = 0; j < b.count && ksplit > 1; ++j) {
         const GemmArgs& g = b.g[j];
         if (g.accumulate || g.out_zeroed) continue;   // partial sums are added atomically: start from zero
+        // the slot to clear is computed from the immediate step: split-K jobs never take their step from device memory
+        // (plan_gemm keeps ksplit at 1 for them)
         float* cbase = g.out.base + (long long)(g.step_imm * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
         if (g.out.ld == g.N) (void)hipMemsetAsync(cbase, 0, (size_t)g.M * g.N * sizeof(float), stream);
         else (void)hipMemset2DAsync(cbase, (size_t)g.out.ld * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream);

@@ -44,7 +44,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PROF_ADD(slot, t1, t0)
 #endif
 
-constexpr unsigned PERSIST_SPIN_LIMIT = 40u * 1000u * 1000u;   // polls before a wait gives up (seconds)
+constexpr unsigned PERSIST_SPIN_LIMIT = 2u * 1000u * 1000u;    // polls before a wait gives up (a few seconds; a whole decode takes milliseconds)
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -463,6 +463,130 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent encoder (seq2seq.py:237-314) for the same small batches: the BiLSTM layer and the stacked layers as tiles of
+// 16 lines x 16 units that hand rows to each other through memory, one launch instead of one per (layer, time) cell.
+//   phase A  the two directions of layer 1, time step by time step (a tile needs all unit groups of its own direction at the
+//            previous step);
+//   phase B  layers 2..D along anti-diagonals (cell (n, t) needs (n-1, t) and (n, t-1)); layer 2 at time t reads the backward
+//            output of time t, i.e. all of phase A for t = 0 -- hence two phases, each walked in dependency order.
+// The cell state of a tile never leaves its thread's register; outputs go to the same buffers, in the same k order and with
+// the same cell function as the per-step launches: identical bits (tested).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PENC_MAXT = 8;        // tiles of one phase a workgroup may own
+
+__global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEncArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) float s_a[];
+    __shared__ float s_gate[4][16 * 16];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = pa.B, T = pa.T, D = pa.D, W = pa.W, lda = pa.lda;
+    const int NRB = (B + 15) / 16, NUG = W / 16, NT = NRB * NUG;
+    const int NCNT = D + 1;                                        // counters per row block: fw, bw, layers 2..D
+    unsigned* const abort_w = pa.counters + (long long)NRB * NCNT * 32;
+    auto counter = [&](int rb, int kind) { return pa.counters + ((long long)rb * NCNT + kind) * 32; };
+    const int g = blockIdx.x, G = gridDim.x;
+    const int kg4 = 4 * (lane >> 4);
+    const int er = tid >> 4, ec = tid & 15;                        // this thread's (row, unit) of a tile in the cell epilogue
+
+    // One cell: tile (kind, rb, ug) at time t, the `nth` step of its recurrence.  x rows: xbase + row * xld (width kx);
+    // h rows of the previous step: hprev + row * hld.  Output h -> hout + row * hld (+ unit).
+    auto cell = [&](const PersistLayer& L, int kx, const float* xbase, long long xld, const float* hprev, float* hout,
+                    long long hld, int rb, int ug, bool first, float& creg, unsigned* done, Dep dx, Dep dh, Dep d3) -> bool {
+        const int nt = first ? kx / 16 : L.Kt / 16;                 // zero initial state: the recurrent segment is skipped
+        const float* b = L.w + ((long long)((ug * 4 + wave) * 16 + (lane & 15))) * L.Kt + kg4;
+        BRing ring;
+        ring_start(ring, b, 0, nt);
+        if (!wait_deps(dx, dh, d3, abort_w, &s_ok)) return false;
+        stage_rows(s_a, lda, 0, xbase, (int)xld, kx, rb, B, tid);
+        if (!first) stage_rows(s_a, lda, kx, hprev, (int)hld, W, rb, B, tid);
+        __syncthreads();
+        const f32x4 acc = k_loop(s_a, lda, b, ring, 0, nt, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_gate[wave][((lane >> 4) * 4 + q) * 16 + (lane & 15)] = acc[q];
+        __syncthreads();
+        const float* bias = L.bias + (long long)ug * 64 + ec;
+        const float zi = s_gate[0][tid] + bias[0], zf = s_gate[1][tid] + bias[16], zg = s_gate[2][tid] + bias[32], zo = s_gate[3][tid] + bias[48];
+        const LstmCellOut c = lstm_cell(zi, zf, zg, zo, first ? 0.0f : creg);
+        creg = c.c;
+        const int row = rb * 16 + er;
+        if (row < B) store_sc1(hout + (long long)row * hld + ug * 16 + ec, c.h);
+        publish(done);
+        return true;
+    };
+
+    // ---- phase A: layer 1, forward and backward
+    {
+        float creg[PENC_MAXT];
+#pragma unroll
+        for (int i = 0; i < PENC_MAXT; ++i) creg[i] = 0.0f;
+        const long long hld = (long long)T * 2 * W, xld = (long long)T * W;
+        for (int st = 0; st < T; ++st) {
+#pragma unroll
+            for (int i = 0; i < PENC_MAXT; ++i) {
+                const int tile = g + i * G;
+                if (tile >= 2 * NT) break;
+                const int dir = tile / NT, rb = (tile % NT) / NUG, ug = tile % NUG;
+                const int t = dir == 0 ? st : T - 1 - st, tp = dir == 0 ? t - 1 : t + 1;
+                float* H = pa.H1 + dir * W;
+                const Dep dh = st > 0 ? Dep{counter(rb, dir), (unsigned)(st * NUG)} : Dep{nullptr, 0};
+                if (!cell(pa.l1[dir], W, pa.x0 + (long long)t * W, xld, H + (long long)tp * 2 * W, H + (long long)t * 2 * W, hld, rb, ug,
+                          st == 0, creg[i], counter(rb, dir), Dep{nullptr, 0}, dh, Dep{nullptr, 0})) return;
+                if (st == T - 1) {                                  // final cell state of this direction
+                    const int row = rb * 16 + er;
+                    if (row < B) pa.cfin[(long long)(dir == 0 ? D : 0) * B * W + (long long)row * W + ug * 16 + ec] = creg[i];
+                }
+            }
+        }
+    }
+    // ---- phase B: layers 2..D along anti-diagonals
+    if (D >= 2) {
+        float creg[PENC_MAXT];
+#pragma unroll
+        for (int i = 0; i < PENC_MAXT; ++i) creg[i] = 0.0f;
+        for (int k = 0; k < T + D - 2; ++k) {
+#pragma unroll
+            for (int i = 0; i < PENC_MAXT; ++i) {
+                const int tile = g + i * G;
+                if (tile >= (D - 1) * NT) break;
+                const int n = 2 + tile / NT, rb = (tile % NT) / NUG, ug = tile % NUG;
+                const int t = k - (n - 2);
+                if (t < 0 || t >= T) continue;
+                const int win = n == 2 ? 2 * W : W;
+                const float* xin = n == 2 ? pa.H1 : pa.Hn[n - 3];
+                float* H = pa.Hn[n - 2];
+                const long long xld = (long long)T * win, hld = (long long)T * W;
+                Dep dx, dh = t > 0 ? Dep{counter(rb, n), (unsigned)(t * NUG)} : Dep{nullptr, 0};
+                if (n == 2) dx = Dep{counter(rb, 1), (unsigned)((T - t) * NUG)};       // backward output of time t (the forward one came earlier)
+                else dx = Dep{counter(rb, n - 1), (unsigned)((t + 1) * NUG)};
+                const Dep dfw = n == 2 ? Dep{counter(rb, 0), (unsigned)((t + 1) * NUG)} : Dep{nullptr, 0};
+                if (!cell(pa.ln[n - 2], win, xin + (long long)t * win, xld, H + (long long)(t - 1) * W, H + (long long)t * W, hld, rb, ug,
+                          t == 0, creg[i], counter(rb, n), dx, dh, dfw)) return;
+                if (t == T - 1) {
+                    const int row = rb * 16 + er;
+                    if (row < B) pa.cfin[(long long)(n - 1) * B * W + (long long)row * W + ug * 16 + ec] = creg[i];
+                }
+            }
+        }
+    }
+}
+
+size_t persist_enc_counter_bytes(int B, int D) {
+    const size_t nrb = (B + 15) / 16;
+    return (nrb * (D + 1) * 32 + 32) * sizeof(unsigned);
+}
+
+int launch_persist_encode(const PersistEncArgs& pa, int grid, hipStream_t stream) {
+    const size_t lds = (size_t)16 * pa.lda * sizeof(float);
+    if (lds > 150 * 1024) return -1;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -1;
+    }
+    hipLaunchKernelGGL(persist_encode_kernel, dim3(grid), dim3(256), lds, stream, pa);
+    return 0;
 }
 
 size_t persist_counter_bytes(int R, int D) {

@@ -111,6 +111,16 @@ class HipEngine(object):
         nv.check(self.lib.casv_encode(self.handle, B, T, A, nv.ptr(idx), nv.ptr(val), nv.ptr(src_rej)))
         self.B, self.T = B, T
 
+    def set_encoder_outputs(self, enc_out, states, a0=None, src_rej=None):
+        """Install encoder outputs computed elsewhere: enc_out (B,T,C), states [h1,c1,...,hd,cd] each (B,W), a0 (B,T) or None."""
+        enc_out = nv.carray(enc_out, np.float32)
+        B, T = enc_out.shape[:2]
+        st = nv.carray(np.stack([np.asarray(x, np.float32).reshape(B, self.width) for x in states[:2 * self.depth]]), np.float32)
+        a0 = None if a0 is None else nv.carray(np.asarray(a0, np.float32).reshape(B, T), np.float32)
+        src_rej = None if src_rej is None else nv.carray(src_rej, np.int32)
+        nv.check(self.lib.casv_set_encoder_outputs(self.handle, B, T, nv.ptr(enc_out), nv.ptr(st), nv.ptr(a0), nv.ptr(src_rej)))
+        self.B, self.T = B, T
+
     def encoder_outputs(self):
         enc = np.empty((self.B, self.T, self.ctx_width), np.float32)
         st = np.empty((2 * self.depth, self.B, self.width), np.float32)

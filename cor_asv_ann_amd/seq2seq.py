@@ -476,14 +476,38 @@ class Sequence2Sequence(object):
         decoder_output_data = np.zeros((B, 2 * T, self.voc_size), dtype=np.uint32)
         return decoder_output_data, lines, probs, scores, aligns
 
+    def _encode_or_install(self, eng, source_seq, encoder_outputs):
+        """Run the encoder on `source_seq` (T,V), or install `encoder_outputs` = what `encoder_model.predict_on_batch`
+        returns for one line ([enc_out (1,T,C), h1, c1, ..., hd, cd, a0 (1,T)], seq2seq.py:1305-1308,1382-1386)."""
+        if encoder_outputs is None:
+            if source_seq is None:
+                raise ValueError('need source_seq or encoder_outputs')
+            idx, val = self._dense_to_sparse(np.asarray(source_seq)[None])
+            eng.encode(idx, val)
+            return
+        outs = list(encoder_outputs)
+        src_rej = None
+        if source_seq is not None:      # the beam reads the source line back for its rejection candidates (seq2seq.py:1458)
+            src = np.asarray(source_seq)
+            src_rej = np.where(src.any(axis=1), src.argmax(axis=1), -1).astype(np.int32)[None]
+        eng.set_encoder_outputs(outs[0], outs[1:1 + 2 * self.depth], a0=outs[1 + 2 * self.depth] if len(outs) > 1 + 2 * self.depth else None,
+                                src_rej=src_rej)
+
+    @property
+    def encoder_model(self):
+        """Stand-in for the Keras `encoder_model` (seq2seq.py:403-406): `.predict_on_batch(x)` -> [enc_out, h1, c1, ..., a0]."""
+        return _EncoderModel(self)
+
+    @property
+    def decoder_model(self):
+        """Stand-in for the Keras `decoder_model` (seq2seq.py:470-473): `.predict_on_batch([p, enc_out] + states)` ->
+        [scores (R,1,V)] + new states."""
+        return _DecoderModel(self)
+
     def decode_sequence_greedy(self, source_seq=None, encoder_outputs=None):
-        """seq2seq.py:1288-1354 for one line given as a (T,V) array."""
+        """seq2seq.py:1288-1354 for one line given as a (T,V) array (or as the encoder's outputs for it)."""
         eng = self._require_engine()
-        if source_seq is None:
-            raise ValueError('decode_sequence_greedy needs source_seq (device-resident encoder outputs '
-                             'are not exchangeable as arrays)')
-        idx, val = self._dense_to_sparse(np.asarray(source_seq)[None])
-        eng.encode(idx, val)
+        self._encode_or_install(eng, source_seq, encoder_outputs)
         return self._sequence_greedy_results(eng, 1)[0]
 
     def _sequence_greedy_results(self, eng, B, want_align=True):
@@ -520,13 +544,9 @@ class Sequence2Sequence(object):
         """seq2seq.py:1356-1544: generator of (string, probabilities, score, alignments), best first.
         The search itself runs on the device when the first result is requested."""
         eng = self._require_engine()
-        if source_seq is None:
-            raise ValueError('decode_sequence_beam needs source_seq')
-        source_seq = np.asarray(source_seq)
-        idx, val = self._dense_to_sparse(source_seq[None])
-        eng.encode(idx, val)
+        self._encode_or_install(eng, source_seq, encoder_outputs)
         res = eng.decode_beam(max_results=64, want_align=True, **self._beam_kwargs())
-        for item in self._beam_results(res, 0, 64, source_seq.shape[0]):
+        for item in self._beam_results(res, 0, 64, eng.T):
             yield item
 
     def correct_lines(self, lines, conf=None, fast=True, greedy=True, alignments=True):
@@ -798,6 +818,44 @@ class Sequence2Sequence(object):
     def train(self, filenames, val_filenames=None):
         from .training import train_files
         return train_files(self, filenames, val_filenames)
+
+
+class _EncoderModel(object):
+    def __init__(self, s2s):
+        self.s2s = s2s
+
+    def predict_on_batch(self, x):
+        s2s = self.s2s
+        eng = s2s._require_engine()
+        x = np.asarray(x)
+        idx, val = s2s._dense_to_sparse(x)
+        eng.encode(idx, val)
+        enc, states = eng.encoder_outputs()
+        return [enc] + states + [np.zeros(x.shape[:2], np.float32)]
+
+    predict = predict_on_batch
+
+
+class _DecoderModel(object):
+    def __init__(self, s2s):
+        self.s2s = s2s
+
+    def predict_on_batch(self, inputs):
+        s2s = self.s2s
+        eng = s2s._require_engine()
+        p_in, attended = np.asarray(inputs[0], np.float32), np.asarray(inputs[1], np.float32)
+        states = [np.asarray(x, np.float32) for x in inputs[2:]]
+        R = p_in.shape[0]
+        d = s2s.depth
+        # the attended sequence may have batch size 1 against R rows of state (the beam relies on it, seq2seq.py:1428-1429)
+        Ba = attended.shape[0]
+        zero = [np.zeros((Ba, s2s.width), np.float32)] * (2 * d)
+        eng.set_encoder_outputs(attended, zero)
+        line = np.arange(R, dtype=np.int32) if Ba == R else np.zeros(R, np.int32)
+        probs, new = eng.decoder_step(line, p_in.reshape(R, -1), states[:2 * d], states[2 * d])
+        return [probs[:, None, :]] + new
+
+    predict = predict_on_batch
 
 
 class Node(object):

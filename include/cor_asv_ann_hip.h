@@ -93,6 +93,13 @@ int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A,
  * enc_out (B,T,C); states (2*depth, B, W) ordered h1,c1,...,hd,cd.  Either may be NULL. */
 int casv_get_encoder_outputs(casv_model* m, float* enc_out, float* states);
 
+/* The `encoder_outputs=` argument of decode_sequence_greedy / decode_sequence_beam (seq2seq.py:1305-1308,1382-1386) and
+ * the `attention_input` + state inputs of decoder_model (seq2seq.py:470-473): install encoder outputs computed elsewhere
+ * instead of running the encoder.  enc_out (B,T,C); states (2*depth, B, W) ordered h1,c1,...,hd,cd; a0 (B,T) initial
+ * alignment or NULL for zeros (what the encoder returns, seq2seq.py:307-309); src_rej as in casv_encode or NULL. */
+int casv_set_encoder_outputs(casv_model* m, int32_t B, int32_t T, const float* enc_out, const float* states,
+                             const float* a0, const int32_t* src_rej);
+
 /* One decoder_model.predict_on_batch (seq2seq.py:477-480, 1245, 1321, 1428) on explicit
  * inputs, for parity tests: R rows, `line[r]` selects the encoded line each row attends to.
  * p_in (R,V); states_in (2*depth, R, W) + a_in (R,T)  ->  probs (R,V), states_out, a_out. */
@@ -180,8 +187,7 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 /* Statistics of the last call (tests): "beam_max_new_keys" = most child hypotheses one line created in one search
  * iteration of the last casv_decode_beam; "beam_sort_capacity" = how many of them are sorted in LDS at once (more are
- * sorted in runs and merged by rank); "beam_rows" / "beam_distinct_parents" = hypothesis rows stepped after the first
- * iteration and the number of different parent expansions they continue (siblings share a parent; batch_size <= 16). */
+ * sorted in runs and merged by rank). */
 int casv_get_stat(casv_model* m, const char* key, int64_t* value);
 int casv_synchronize(casv_model* m);
 

@@ -161,3 +161,41 @@ def test_sparse_alignments_equal_dense_and_feed_the_realignment():
     got = s2s.correct_lines(lines, fast=True, greedy=True)
     for j in range(len(lines)):
         assert np.allclose(np.asarray(got[3][j]), np.asarray(want[3][j]), atol=1e-4)
+
+
+def test_encoder_outputs_argument_and_model_stand_ins():
+    """`decode_sequence_greedy/beam(encoder_outputs=...)` (seq2seq.py:1305-1308,1382-1386) and the `encoder_model` /
+    `decoder_model` objects scripts poke at: outputs of the encoder stand-in fed back as `encoder_outputs` decode exactly like
+    the line itself, and the stand-ins agree with the oracle's encoder / decoder step."""
+    from oracle.model import encode, decoder_step
+    om, s2s = _pair(2, 64, 96, es=12.0, batch_size=4)
+    lines, _ = make_lines(3, 11, 5, voc_size=96)
+    enc_in, _, _, _ = vectorize_lines(om, lines, [[] for _ in lines])
+    outs = s2s.encoder_model.predict_on_batch(enc_in)
+    want = encode(om.cfg, om.weights, enc_in)
+    assert len(outs) == len(want) == 2 + 2 * 2
+    for a, b in zip(outs, want):
+        assert np.allclose(a, b, rtol=2e-4, atol=2e-6)
+    for j in range(3):
+        single = [o[j:j + 1] for o in outs]
+        try:
+            direct = s2s.decode_sequence_greedy(source_seq=enc_in[j])
+            via = s2s.decode_sequence_greedy(encoder_outputs=single)
+            assert direct[0] == via[0] and np.array_equal(direct[1], via[1])
+        except ValueError:
+            with pytest.raises(ValueError):
+                s2s.decode_sequence_greedy(encoder_outputs=single)
+        d1 = next(s2s.decode_sequence_beam(source_seq=enc_in[j]), None)
+        d2 = next(s2s.decode_sequence_beam(source_seq=enc_in[j], encoder_outputs=single), None)
+        assert (d1 is None) == (d2 is None) and (d1 is None or (d1[0] == d2[0] and d1[2] == d2[2]))
+    # one decoder step through the stand-in, 5 rows attending to ONE line (Keras broadcasts the attended input)
+    rng = np.random.default_rng(2)
+    R, V, W, T = 5, 96, 64, enc_in.shape[1]
+    p = rng.random((R, 1, V)).astype(np.float32); p /= p.sum(axis=2, keepdims=True)
+    states = [rng.normal(0, 0.3, (R, W)).astype(np.float32) for _ in range(4)]
+    a = np.zeros((R, T), np.float32); a[np.arange(R), rng.integers(0, T, R)] = 1.0
+    got = s2s.decoder_model.predict_on_batch([p, outs[0][1:2]] + states + [a])
+    wp, wst = decoder_step(om.cfg, om.weights, p[:, 0], np.repeat(want[0][1:2], R, axis=0), states + [a])
+    assert got[0].shape == (R, 1, V) and np.allclose(got[0][:, 0], wp, rtol=2e-4, atol=2e-6)
+    for x, y in zip(got[1:], wst):
+        assert np.allclose(x, y, rtol=2e-4, atol=2e-6)

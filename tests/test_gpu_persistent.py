@@ -32,6 +32,14 @@ def test_persistent_equals_per_step_kernels_bit_for_bit(d, W, V, B, L, es):
     _, idx = make_lines(B, L, 5, voc_size=V)
     if B > 2:
         idx[1, L // 2:] = -1                       # ragged batch: zero rows behind a shorter line
+    encs = {}
+    for persistent in (0, 1):          # the persistent ENCODER (one launch for all layers and time steps) against the per-step one
+        eng.set_option('persistent', persistent)
+        eng.encode(idx)
+        encs[persistent] = eng.encoder_outputs()
+    assert np.array_equal(encs[0][0], encs[1][0]), 'encoder outputs'
+    for a, b in zip(encs[0][1], encs[1][1]):
+        assert np.array_equal(a, b), 'encoder final states'
     for mode in (0, 1):
         out = {}
         for persistent in (0, 1):
