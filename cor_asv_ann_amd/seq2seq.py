@@ -433,22 +433,45 @@ class Sequence2Sequence(object):
         cps = self._cp_cache[4][np.asarray(indexes, np.int64)]
         return cps[cps != 0].astype('<u4').tobytes().decode('utf-32-le', 'surrogatepass')
 
-    def _greedy_results(self, idx, prob, align, nonpad):
-        """Per-line bookkeeping of seq2seq.py:1254-1263 on the index/probability matrices."""
+    def _texts(self, idx, n):
+        """Strings of all rows at once: row j = the characters of idx[j, :n[j]] (index 0 maps to no character).  ONE table
+        lookup and ONE utf-32 decode for the whole batch, then slices."""
         B, S = idx.shape
+        n = np.asarray(n, np.int64)
+        keep = np.arange(S)[None, :] < n[:, None]
+        self._codepoint_table()
+        cps = self._cp_cache[4][idx[keep]]
+        present = cps != 0
+        text = cps[present].astype('<u4').tobytes().decode('utf-32-le', 'surrogatepass')
+        upto = np.concatenate([[0], np.cumsum(present)])
+        stop = np.cumsum(n)
+        ends = np.cumsum(upto[stop] - upto[stop - n]).tolist()
+        out, start = [], 0
+        for end in ends:
+            out.append(text[start:end])
+            start = end
+        return out, keep
+
+    def _greedy_results(self, idx, prob, align, nonpad):
+        """Per-line bookkeeping of seq2seq.py:1254-1263 on the index/probability matrices, for all lines at once: length up
+        to the first end-of-line, string, mean -log p."""
+        B, S = idx.shape
+        is_eos = idx == self._eos
+        n = np.where(is_eos.any(axis=1), is_eos.argmax(axis=1) + 1, S)
+        n = np.where(nonpad, n, 0)
+        texts, keep = self._texts(idx, n)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            cost = np.where(keep, -np.log(prob), 0).sum(axis=1, dtype=np.float64) / np.maximum(n, 1)
         lines, probs, scores, aligns = [], [], [], []
         for j in range(B):
             if not nonpad[j]:
                 lines.append(''); probs.append([]); scores.append(0.); aligns.append([])
                 continue
-            eos = np.nonzero(idx[j] == self._eos)[0]
-            n = int(eos[0]) + 1 if len(eos) else S
-            p = prob[j, :n]
-            lines.append(self._chars(idx[j, :n]))
-            probs.append(list(p))
-            with np.errstate(divide='ignore'):
-                scores.append(float(np.sum(-np.log(p), dtype=np.float64)) / n)
-            aligns.append(self._alignment_rows(align, j, n))
+            lines.append(texts[j])
+            nj = int(n[j])
+            probs.append(prob[j, :nj].tolist())
+            scores.append(float(cost[j]))
+            aligns.append(self._alignment_rows(align, j, nj))
         return lines, probs, scores, aligns
 
     def _alignment_rows(self, align, j, n):
@@ -593,9 +616,14 @@ class Sequence2Sequence(object):
             rows = live[lo:lo + chunk]
             eng.encode(idx[rows], val[rows])
             res = eng.decode_beam(max_results=1, want_align=want_align, **self._beam_kwargs())
+            texts, _ = self._texts(res['idx'], res['len'])          # best result of every line of the chunk, in one go
             for k, j in enumerate(rows):
                 input_line = lines[j]
-                item = next(self._beam_results(res, k, 1, T), None)
+                n = int(res['len'][k])
+                item = None
+                if n:
+                    item = (texts[k], res['prob'][k, :n].tolist(), float(res['score'][k]),
+                            self._alignment_rows(res.get('align_sparse', res['align']), k, n))
                 if item is None:
                     # the generator of the reference raises StopIteration here (seq2seq.py:826-836)
                     self.logger.error('cannot beam-decode input line %d: "%s"', j, input_line)
