@@ -247,7 +247,11 @@ def decode_bench(args):
     # CASV_BENCH_FORCE_DIST=1: take the multi-rank path (process group, barrier, all-gather, max-reduce) with ONE rank,
     # to exercise the RCCL calls on a one-GPU box
     dist_on = world > 1 or bool(os.environ.get('CASV_BENCH_FORCE_DIST'))
-    if dist_on:
+    # CASV_BENCH_GATHER=native: barrier, all-gather and max-reduce through the C ABI's RCCL leg (casv_comm_*) instead of
+    # torch.distributed -- no torch in the process at all
+    native = dist_on and os.environ.get('CASV_BENCH_GATHER') == 'native' and not os.environ.get('CASV_BENCH_DRY_RUN')
+    comm = None
+    if dist_on and not native:
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -287,6 +291,10 @@ def decode_bench(args):
         if args.graph:
             eng.set_option('graph', 1)
         lut = s2s._codepoint_lut()
+        if native:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            comm = sharding.NativeComm(eng, rank, world)
 
         def decode(chunk):
             out, probs, scores, al = s2s.correct_lines(chunk, fast=wl['fast'], greedy=wl['fast'], alignments=bool(args.alignments))
@@ -303,14 +311,16 @@ def decode_bench(args):
             # fixed-width records (characters, probabilities, length, score) -> RCCL all-gather
             t0 = time.perf_counter()
             rec = sharding.records_from_lines(out_lines, probs, scores, lut, S)
-            got = sharding.all_gather_records(rec, len(all_lines), device=device)
+            got = comm.all_gather_records(rec, len(all_lines)) if comm else sharding.all_gather_records(rec, len(all_lines), device=device)
             t_gather[0] += time.perf_counter() - t0
             return got
         return out_lines
 
     def sync():
         sync_dev()
-        if dist_on:
+        if comm:
+            comm.max(0.0)
+        elif dist_on:
             if backend == 'nccl':
                 torch.cuda.synchronize()
             dist.barrier()
@@ -341,7 +351,10 @@ def decode_bench(args):
         eng.profile(False)
     per_rank = [mine]
     gather_ms = 1e3 * t_gather[0] / max(args.steps, 1)
-    if dist_on:
+    if comm:
+        elapsed = comm.max(elapsed)
+        per_rank = [mine] * world                 # (the per-rank times are not gathered on this path)
+    elif dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device or 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -363,7 +376,7 @@ def decode_bench(args):
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'dry-run (no decoding)' if dry else 'synthetic',
             'config': {'workload': wl['text'] + ', 2T=%d steps max, synthetic weights seed 20250614 emb_scale=%g' % (S, wl['emb']),
                        'lines_per_gpu': per_gpu, 'lines_per_decode_call': batch, 'line_length': LENGTH, 'beam_n': wl['n'],
-                       'parallelism': 'lines sharded x%d' % world, 'graph': bool(args.graph), 'alignments': bool(args.alignments),
+                       'parallelism': 'lines sharded x%d' % world, 'gather': 'casv_comm (RCCL, C ABI)' if comm else ('torch.distributed/' + backend if dist_on else 'none'), 'graph': bool(args.graph), 'alignments': bool(args.alignments),
                        'launcher': 'bench.py' if os.environ.get('CASV_BENCH_CHILD') else
                                    ('torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ else 'direct')},
             'ms_per_step_by_rank': [1e3 * x / args.steps for x in per_rank],
@@ -398,7 +411,9 @@ def decode_bench(args):
             result['kernel_ms_per_step'] = {k: v['ms'] for k, v in others.items()}     # from one extra untimed step
         if world == 1 and not args.no_cpu_baseline and not dry:
             result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64], wl['n'] if not wl['fast'] else 256, wl['fast'])
-    if dist_on:
+    if comm:
+        comm.close()
+    elif dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -62,6 +62,11 @@ SIGNATURES = {
     'casv_debug_gemm': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_double)]),
     'casv_set_option': (c_int, [c_void_p, c_char_p, c_int64]),
     'casv_get_alignments_sparse': (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    'casv_comm_unique_id': (c_int, [c_void_p]),
+    'casv_comm_init': (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    'casv_comm_all_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    'casv_comm_all_reduce_max': (c_int, [c_void_p, POINTER(c_double)]),
+    'casv_comm_destroy': (c_int, [c_void_p]),
     'casv_get_stat': (c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
     'casv_synchronize': (c_int, [c_void_p]),
 }

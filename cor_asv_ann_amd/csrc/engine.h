@@ -130,6 +130,8 @@ struct casv_model {
     // the captured step graph of the last decode configuration (option "graph"): kept across calls, rebuilt when the
     // configuration or any device buffer changes
     hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; std::string step_graph_key;
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1; DevBuf comm_send, comm_recv;     // RCCL communicator (comm.hip)
+    int* pin_active = nullptr; hipEvent_t ev_active[2] = {nullptr, nullptr};   // beam decode: unfinished-line count, read one chunk behind
     int stat_beam[3] = {0, 0, 0};                         // last beam decode: most new hypotheses of one line in one step; rows stepped
                                                           // and distinct parent expansions among them (N <= 16 only)
     Prof prof;
@@ -188,3 +190,4 @@ inline void run_gemm(casv_model* m, int epi, GemmArgs& g) {
 
 
 int casv_train_release(casv_model* m);
+extern "C" int casv_comm_destroy(casv_model* m);

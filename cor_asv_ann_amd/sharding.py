@@ -87,5 +87,80 @@ def all_gather_records(rec, n_total, device=None, group=None):
     return np.concatenate(parts, axis=0)
 
 
+class NativeComm(object):
+    """The all-gather of result records through the C ABI (`casv_comm_*`: RCCL on the model handle's device and stream) --
+    no torch in the product path.  The 128-byte RCCL id travels from rank 0 to the others over a plain TCP socket
+    (`MASTER_ADDR` / `MASTER_PORT` + 1 of the usual launcher environment)."""
+
+    def __init__(self, engine, rank=None, world=None, addr=None, port=None):
+        import ctypes
+        import os
+        from . import _native as nv
+        self.engine, self.nv = engine, nv
+        self.rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
+        self.world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
+        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+        port = int(port or int(os.environ.get('MASTER_PORT', '29500')) + 1)
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            nv.check(engine.lib.casv_comm_unique_id(uid))
+        if self.world > 1:
+            uid.raw = exchange_bytes(uid.raw, self.rank, self.world, addr, port)
+        nv.check(engine.lib.casv_comm_init(engine.handle, self.rank, self.world, uid))
+
+    def all_gather_records(self, rec, n_total):
+        per = -(-n_total // self.world)
+        width = rec.shape[1]
+        mine = np.zeros((per, width), np.int32)
+        mine[:rec.shape[0]] = rec
+        out = np.empty((self.world * per, width), np.int32)
+        self.nv.check(self.engine.lib.casv_comm_all_gather(self.engine.handle, self.nv.ptr(mine), self.nv.ptr(out), mine.nbytes))
+        out = out.reshape(self.world, per, width)
+        return np.concatenate([out[r, :shard_bounds(n_total, self.world, r)[1] - shard_bounds(n_total, self.world, r)[0]]
+                               for r in range(self.world)], axis=0)
+
+    def max(self, value):
+        """Maximum of a float over the ranks (also a barrier)."""
+        from ctypes import byref, c_double
+        v = c_double(float(value))
+        self.nv.check(self.engine.lib.casv_comm_all_reduce_max(self.engine.handle, byref(v)))
+        return v.value
+
+    def close(self):
+        self.nv.check(self.engine.lib.casv_comm_destroy(self.engine.handle))
+
+
+def exchange_bytes(payload, rank, world, addr, port, timeout=120.0):
+    """Rank 0 sends `payload` to every other rank over TCP; returns the payload on every rank."""
+    import socket
+    import time
+    if rank == 0:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(payload)
+        return payload
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as c:
+                buf = b''
+                while len(buf) < len(payload):
+                    chunk = c.recv(len(payload) - len(buf))
+                    if not chunk:
+                        raise ConnectionError('rank 0 closed the connection early')
+                    buf += chunk
+                return buf
+        except (ConnectionRefusedError, socket.timeout, OSError):
+            if time.time() > deadline:
+                raise
+            time.sleep(0.2)
+
+
 def records_to_strings(idx, length, i_c):
     return [''.join(i_c[int(c)] for c in idx[j, :int(length[j])]) for j in range(idx.shape[0])]

@@ -165,6 +165,21 @@ int casv_train_sync_weights(casv_model* m);
  * (_resync_decoder after training, seq2seq.py:645). */
 int casv_train_end(casv_model* m);
 
+/* Multi-GPU: lines are independent (seq2seq.py:113 stateful=False), so one process per GPU decodes a
+ * contiguous shard of the lines with its own handle and NO data-path collective; what crosses the GPUs is one all-gather
+ * of fixed-width result records per batch -- RCCL over xGMI.  The reference has no counterpart (single process,
+ * wrapper/transcode.py:46).  casv_comm_unique_id: rank 0 draws the 128-byte RCCL id and hands it to the other ranks by
+ * whatever channel the host program has (file, socket, MPI, torch store); casv_comm_init: every rank joins with it, on its
+ * handle's device; casv_comm_all_gather: `send` (bytes_per_rank bytes, host) of every rank -> `recv` (world * bytes_per_rank
+ * bytes, host, rank order), staged through device memory and gathered on the handle's stream; casv_comm_all_reduce_max: the
+ * maximum of one double over the ranks (step timing; also a barrier).  RCCL is opened at the first of these calls (dlopen),
+ * it is not a link dependency of the library. */
+int casv_comm_unique_id(void* out128);
+int casv_comm_init(casv_model* m, int32_t rank, int32_t world, const void* unique_id128);
+int casv_comm_all_gather(casv_model* m, const void* send, void* recv, int64_t bytes_per_rank);
+int casv_comm_all_reduce_max(casv_model* m, double* value);
+int casv_comm_destroy(casv_model* m);
+
 /* Measurement support for bench.py: per-kernel HIP-event timing on the library's stream.
  * casv_profile(m, 1) starts recording for all kernel classes, casv_profile(m, 2) only for "lstm_gemm" (fewer
  * event records inside a timed region), casv_profile(m, 0) stops; casv_profile_read returns, for kernel class `name`

@@ -199,3 +199,18 @@ def test_encoder_outputs_argument_and_model_stand_ins():
     assert got[0].shape == (R, 1, V) and np.allclose(got[0][:, 0], wp, rtol=2e-4, atol=2e-6)
     for x, y in zip(got[1:], wst):
         assert np.allclose(x, y, rtol=2e-4, atol=2e-6)
+
+
+def test_rccl_leg_of_the_c_abi_with_one_rank():
+    """casv_comm_*: unique id, communicator on the handle's device, all-gather of records through device memory, max-reduce.
+    One rank here (one GPU per box); the N-rank pattern is `bench.py --gpus N` with CASV_BENCH_GATHER=native."""
+    from cor_asv_ann_amd import sharding
+    from cor_asv_ann_amd.engine import HipEngine
+    eng = HipEngine(1, 32, 16)
+    comm = sharding.NativeComm(eng, rank=0, world=1)
+    rec = np.arange(5 * 9, dtype=np.int32).reshape(5, 9)
+    out = comm.all_gather_records(rec, 5)
+    assert np.array_equal(out, rec)
+    assert comm.max(3.25) == 3.25
+    comm.close()
+    eng.close()
