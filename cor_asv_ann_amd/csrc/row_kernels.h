@@ -36,20 +36,18 @@ __device__ __forceinline__ float wave_max(float v) {
 constexpr int MAXWIN = 11;
 constexpr int ATT_ROWS = 8;      // rows (waves) per workgroup: the N=8 hypotheses of one line share u/enc rows in L1
 
-// One decoder row r at `step` (reads alignment slot `step` or the parent's, writes slot step + 1).  HANDOFF: the context
-// vector goes out with write-through stores (another workgroup of the same launch consumes it).
-template <bool HANDOFF>
-__device__ __forceinline__ void attention_row(const AttnArgs& a, const int r, const int step, const int lane) {
-    const int ln = a.line ? a.line[r] : r / a.rows_per_line;
-    const int T = a.T, W = a.W, C = a.C;
-    const float* ap = a.a_base + (a.prev ? (long long)a.prev[r] : (long long)step * a.R + r) * T;
-    float* aout = const_cast<float*>(a.a_base) + ((long long)(step + 1) * a.R + r) * T;
+// One decoder row r at `step` (reads alignment slot `step` or the parent's, writes slot step + 1), in three parts so that
+// a workgroup can stage the attended rows between them (attention_line_kernel); attention_row chains them on global memory.
+struct AttWin { int s_lo, cnt; };
 
+// (1) t' = sum_s a_prev[s] * s + 1 and the window |t' - s| <= window_width (attention.py:553-567)
+__device__ __forceinline__ AttWin att_window(const AttnArgs& a, const int r, const int step, const int lane) {
+    const int T = a.T;
+    const float* ap = a.a_base + (a.prev ? (long long)a.prev[r] : (long long)step * a.R + r) * T;
     double acc = 0.0;
     for (int s = lane; s < T; s += 64) acc += (double)ap[s] * (double)s;
     const float tp = (float)(wave_sum_d(acc) + 1.0);
     const float win = (float)a.window;
-
     int s_lo = 0, s_hi = -1;                    // empty unless t' is a number
     if (tp == tp && fabsf(tp) < 1.0e9f) {
         int lo = (int)floorf(tp - win) - 1, hi = (int)floorf(tp + win) + 1;
@@ -59,25 +57,29 @@ __device__ __forceinline__ void attention_row(const AttnArgs& a, const int r, co
         for (int s = lo; s <= hi; ++s)
             if (fabsf(tp - (float)s) <= win) { s_lo = s < s_lo ? s : s_lo; s_hi = s; }
     }
-    const int cnt = s_hi - s_lo + 1;            // <= MAXWIN
+    return AttWin{s_lo, s_hi - s_lo + 1};       // cnt <= MAXWIN
+}
 
+// (2) energies exp(tanh(wq + u[s]) . v_a + b_v) over the window, normalised; writes the alignment row and the per-row
+// by-products.  urow(s) -> the row u[line][s] as float4s (global memory, or the workgroup's staged copy).
+template <class URow>
+__device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, const int step, const int lane, const AttWin w,
+                                            URow urow, float (&e)[MAXWIN]) {
+    const int T = a.T, W = a.W;
+    const int s_lo = w.s_lo, cnt = w.cnt;
+    float* aout = const_cast<float*>(a.a_base) + ((long long)(step + 1) * a.R + r) * T;
     const float4* wq4 = reinterpret_cast<const float4*>(a.wq + (long long)r * W);
     const float4* va4 = reinterpret_cast<const float4*>(a.va);
-    const float* ub = a.u + (long long)ln * a.u_line;
     const float bv = a.bv[0];
     const int W4 = W >> 2;
     // The kernel is latency-bound (one decoder row per wave slot), so all window rows are requested
     // together: loads are unconditional on clamped row indices, positions past the window get weight 0.
-    float e[MAXWIN];
 #pragma unroll
     for (int i = 0; i < MAXWIN; ++i) e[i] = 0.0f;
     for (int j = lane; j < W4; j += 64) {
         float4 uu[MAXWIN];
 #pragma unroll
-        for (int i = 0; i < MAXWIN; ++i) {
-            int sidx = s_lo + i; sidx = sidx < T ? sidx : T - 1;
-            uu[i] = reinterpret_cast<const float4*>(ub + (long long)sidx * a.u_time)[j];
-        }
+        for (int i = 0; i < MAXWIN; ++i) uu[i] = urow(s_lo + i)[j];
         const float4 q = wq4[j], v = va4[j];
 #pragma unroll
         for (int i = 0; i < MAXWIN; ++i) {
@@ -113,16 +115,27 @@ __device__ __forceinline__ void attention_row(const AttnArgs& a, const int r, co
             if (i < cnt && s == s_lo + i) v = e[i];
         aout[s] = v;
     }
-    const float* eb = a.enc + (long long)ln * a.enc_line;
+    if (lane == 0) {
+        if (a.apos) a.apos[r] = cnt <= 0 ? (double)nanv : pos;
+        if (a.amax1) a.amax1[r] = (amax == 1.0f) ? 1 : 0;
+        if (a.win_out) a.win_out[r] = cnt > 0 ? (s_lo | (cnt << 16)) : 0;
+        if (a.win_store) a.win_store[(long long)(step + 1) * a.R + r] = cnt > 0 ? (s_lo | (cnt << 16)) : -1;
+    }
+}
+
+// (3) context = sum_s a'[s] * enc[s].  erow(s) -> the row enc[line][s] as float4s.  HANDOFF: the context vector goes out
+// with write-through stores (another workgroup of the same launch consumes it).
+template <bool HANDOFF, class ERow>
+__device__ __forceinline__ void att_context(const AttnArgs& a, const int r, const int lane, const AttWin w, ERow erow,
+                                            const float (&e)[MAXWIN]) {
+    const int C = a.C, s_lo = w.s_lo, cnt = w.cnt;
+    const float nanv = __builtin_nanf("");
     float4* ctx4 = reinterpret_cast<float4*>(a.ctx + (long long)r * C);
     const int C4 = C >> 2;
     for (int c = lane; c < C4; c += 64) {
         float4 x[MAXWIN];
 #pragma unroll
-        for (int i = 0; i < MAXWIN; ++i) {
-            int sidx = s_lo + i; sidx = sidx < T ? sidx : T - 1;
-            x[i] = reinterpret_cast<const float4*>(eb + (long long)sidx * a.enc_time)[c];
-        }
+        for (int i = 0; i < MAXWIN; ++i) x[i] = erow(s_lo + i)[c];
         float4 v = cnt <= 0 ? make_float4(nanv, nanv, nanv, nanv) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < MAXWIN; ++i)
@@ -134,12 +147,18 @@ __device__ __forceinline__ void attention_row(const AttnArgs& a, const int r, co
             ctx4[c] = v;
         }
     }
-    if (lane == 0) {
-        if (a.apos) a.apos[r] = cnt <= 0 ? (double)nanv : pos;
-        if (a.amax1) a.amax1[r] = (amax == 1.0f) ? 1 : 0;
-        if (a.win_out) a.win_out[r] = cnt > 0 ? (s_lo | (cnt << 16)) : 0;
-        if (a.win_store) a.win_store[(long long)(step + 1) * a.R + r] = cnt > 0 ? (s_lo | (cnt << 16)) : -1;
-    }
+}
+
+template <bool HANDOFF>
+__device__ __forceinline__ void attention_row(const AttnArgs& a, const int r, const int step, const int lane) {
+    const int ln = a.line ? a.line[r] : r / a.rows_per_line;
+    const int T = a.T;
+    const AttWin w = att_window(a, r, step, lane);
+    const float* ub = a.u + (long long)ln * a.u_line;
+    const float* eb = a.enc + (long long)ln * a.enc_line;
+    float e[MAXWIN];
+    att_weights(a, r, step, lane, w, [&](int s) { s = s < T ? s : T - 1; return reinterpret_cast<const float4*>(ub + (long long)s * a.u_time); }, e);
+    att_context<HANDOFF>(a, r, lane, w, [&](int s) { s = s < T ? s : T - 1; return reinterpret_cast<const float4*>(eb + (long long)s * a.enc_time); }, e);
 }
 
 }  // namespace casv
