@@ -5,9 +5,15 @@
 // while most of the chip idles.  Here a workgroup owns a 32 x 128 tile (4x as many workgroups) and its four waves
 // own one 32x32 accumulator tile each -- wave w = gate w of the LSTM epilogue -- over the FULL K range, in the same
 // k order and with the same MFMA sequence per element as the big kernel (so a row's value does not depend on which
-// variant ran).  There is no operand reuse between the waves of a workgroup beyond the 32-row A panel (served by the
-// L1), so fragments go straight from global memory into MFMA operand registers, four K-tiles deep; the LDS is used
-// once, to bring the four gates of a (row, unit) into one lane for the cell epilogue.
+// variant ran).
+//
+// Operands are staged through LDS in steps of 32 k (round 2).  The first version let every lane pull its fragments straight
+// from global memory, 16 B out of each of 32 rows per instruction: a 128-B line was visited by four load instructions of two
+// K tiles out of an L1 that the live lines did not fit, and the kernel ran at ~50 TFLOP/s whatever the MFMA chains did
+// (profiles/r02_gemm_tile_trace.txt).  Now 8 threads take one whole line of a row at once (each line leaves the L2 exactly
+// once per workgroup), two stages are double-buffered in LDS (+4-float row pad: ds_read_b128 conflict-free), and the stage
+// after next is in flight in registers while the 16 MFMAs of the current one issue.  The LDS then brings the four gates of
+// a (row, unit) into one lane for the cell epilogue.
 #include "common.h"
 
 namespace casv {
@@ -15,11 +21,14 @@ namespace casv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SBM = 32, SBN = 128, SBK = 16, SDEPTH = 4;      // prefetch depth 4 = 6 = 8 K-tiles (measured; in round 2 again: 8 gains 2 % on the train step, nothing on decode)
+constexpr int SBM = 32, SBN = 128;
+constexpr int SK2 = 32, SLD = SK2 + 4;                       // k per LDS stage, padded row stride (floats)
+constexpr int STAGE_FLOATS = (SBM + SBN) * SLD;              // A rows, then B rows      // prefetch depth 4 = 6 = 8 K-tiles (measured; in round 2 again: 8 gains 2 % on the train step, nothing on decode)
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch batch) {
-    __shared__ float s_gate[4][16][64];
+    __shared__ __attribute__((aligned(16))) float s_stage[2 * STAGE_FLOATS];      // 46 KB; the epilogue's gate exchange reuses it
+    float (*s_gate)[16][64] = reinterpret_cast<float (*)[16][64]>(s_stage);
     const GemmArgs& g = batch.g[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -36,10 +45,11 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         if (!__any(alive)) return;
     }
 
-    // A: this lane's row of every segment (fragment layout: lane (l31, lh) holds k = 4*lh + 8*j + i of row l31)
+    // staging role of this thread: A row tid >> 3 (of 32), B rows (tid >> 3) + 32 i, 16 bytes at k = 4 * (tid & 7) of every stage
+    const int srow = tid >> 3, sk = 4 * (tid & 7);
     const float* ap0; const float* ap1; const float* ap2;
-    int tiles0 = 0, tiles1 = 0, tiles2 = 0;
-    int mrow = m0 + l31; mrow = mrow < g.M ? mrow : g.M - 1;
+    int tiles0 = 0, tiles1 = 0, tiles2 = 0;                      // in stages of 32 k
+    int mrow = m0 + srow; mrow = mrow < g.M ? mrow : g.M - 1;
 #define CASV_SETUP_SEG(S, AP, TILES)                                                             \
     if (g.nseg > S && !(g.a[S].skip_first && step == 0 && !g.a[S].first_base)) {                 \
         const Seg& sg = g.a[S];                                                                  \
@@ -47,8 +57,8 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         const float* base = first ? sg.first_base                                                \
             : sg.base + (long long)(step * sg.step_mul + sg.step_add) * sg.slot_stride;          \
         const int rid = (sg.rows && !first) ? sg.rows[mrow] : mrow;                              \
-        AP = base + (long long)rid * sg.ld + 4 * lh;                                             \
-        TILES = sg.width / SBK;                                                                  \
+        AP = base + (long long)rid * sg.ld + sk;                                                 \
+        TILES = sg.width / SK2;                                                                  \
     } else {                                                                                     \
         AP = nullptr;                                                                            \
     }
@@ -65,29 +75,48 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
     const int koff0 = g.a[0].koff, koff1 = g.a[1].koff, koff2 = g.a[2].koff;
     const long long d1 = (long long)((const char*)ap1 - (const char*)ap0), d2 = (long long)((const char*)ap2 - (const char*)ap0);
 
-    // B: this wave's 32 columns (LSTM: gate `wave` of the 32 units of the tile)
-    int ncol = n0 + wave * 32 + l31; ncol = ncol < g.N ? ncol : g.N - 1;
-    const float* bp = g.Bt + (long long)ncol * g.Ktot + 4 * lh;
+    const float* bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ncol = n0 + srow + 32 * i; ncol = ncol < g.N ? ncol : g.N - 1;
+        bp[i] = g.Bt + (long long)ncol * g.Ktot + sk;
+    }
 
-    struct Frag { f32x4 a[2], b[2]; };
-    auto load = [&](Frag& f, int kt_rel) {
-        int kt = kt_rel < ntiles ? kt_rel : ntiles - 1;         // past the end: a valid, unused re-load
-        kt += kt_begin;
+    struct GStage { f32x4 a, b[4]; };
+    auto load_stage = [&](GStage& gs, int kt_rel) {
+        const int kt = kt_rel + kt_begin;
         const long long m1 = (kt >= c0 && kt < c1) ? -1LL : 0LL, m2 = (kt >= c1) ? -1LL : 0LL;
         const int ko = kt - ((int)m1 & c0) - ((int)m2 & c1);
-        const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * SBK;
-        const char* pa = (const char*)ap0 + (d1 & m1) + (d2 & m2) + (long long)ko * (SBK * 4);
-        f.a[0] = *reinterpret_cast<const f32x4*>(pa); f.a[1] = *reinterpret_cast<const f32x4*>(pa + 32);
-        f.b[0] = *reinterpret_cast<const f32x4*>(bp + kb); f.b[1] = *reinterpret_cast<const f32x4*>(bp + kb + 8);
+        const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * SK2;
+        const char* pa = (const char*)ap0 + (d1 & m1) + (d2 & m2) + (long long)ko * (SK2 * 4);
+        gs.a = *reinterpret_cast<const f32x4*>(pa);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gs.b[i] = *reinterpret_cast<const f32x4*>(bp[i] + kb);
+    };
+    auto store_stage = [&](const GStage& gs, int buf) {
+        float* sa = s_stage + buf * STAGE_FLOATS + srow * SLD + sk;
+        *reinterpret_cast<f32x4*>(sa) = gs.a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(sa + (SBM + 32 * i) * SLD) = gs.b[i];
     };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    auto mma = [&](const Frag& f) {
+    // fragments of one stage: two 16-k halves, in each lane half lh contracts k = 4 lh + 8 j + i in instruction (j, i) --
+    // the k order of gemm.hip
+    const int a_off = l31 * SLD + 4 * lh, b_off = (SBM + wave * 32 + l31) * SLD + 4 * lh;
+    auto compute = [&](int buf) {
+        const float* base = s_stage + buf * STAGE_FLOATS;
+        f32x4 fa[4], fb[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int q = 0; q < 4; ++q) {
+            fa[q] = *reinterpret_cast<const f32x4*>(base + a_off + 8 * q);
+            fb[q] = *reinterpret_cast<const f32x4*>(base + b_off + 8 * q);
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j][i], f.b[j][i], acc, 0, 0, 0);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][i], fb[q][i], acc, 0, 0, 0);
     };
 
     // LSTM: wave w finishes rows (r & 3, r >> 2 == w) of the tile; fetch their previous cell state under the K loop
@@ -111,21 +140,19 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
     }
 
     if (ntiles > 0) {
-        Frag f[SDEPTH];
-#pragma unroll
-        for (int q = 0; q < SDEPTH; ++q) load(f[q], q);
-        int kt = 0;
-        for (; kt + SDEPTH <= ntiles; kt += SDEPTH) {
-#pragma unroll
-            for (int q = 0; q < SDEPTH; ++q) {
-                mma(f[q]);
-                load(f[q], kt + SDEPTH + q);
-            }
+        GStage gs;
+        load_stage(gs, 0);
+        store_stage(gs, 0);
+        if (ntiles > 1) load_stage(gs, 1);
+        __syncthreads();
+        for (int kt = 0; kt < ntiles; ++kt) {
+            // stage kt+1 (in registers since the previous iteration) -> the buffer whose readers passed the last barrier;
+            // stage kt+2 starts its way from global memory; stage kt is contracted
+            if (kt + 1 < ntiles) store_stage(gs, (kt + 1) & 1);
+            if (kt + 2 < ntiles) load_stage(gs, kt + 2);
+            compute(kt & 1);
+            __syncthreads();
         }
-        const int rest = ntiles - kt;
-#pragma unroll
-        for (int q = 0; q < SDEPTH - 1; ++q)
-            if (rest > q) mma(f[q]);
     }
 
     // ---- epilogue ----
@@ -147,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
     } else {
         // gate w of every (row, unit) of the tile -> LDS; then wave w takes accumulator rows r = 4w .. 4w+3 of all four gates
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_gate[wave][r][lane] = acc[r];
+        for (int r = 0; r < 16; ++r) s_gate[wave][r][lane] = acc[r];      // (every wave is past the K loop's last barrier)
         __syncthreads();
         const int u = bn * 32 + l31;
         const float bi = g.bias ? g.bias[n0 + l31] : 0.f, bf_ = g.bias ? g.bias[n0 + 32 + l31] : 0.f;

@@ -230,7 +230,7 @@ static int layer_weight_grads(casv_model* m, TLayer& l, const float* x, long lon
     TrainState* ts = m->train;
     const int W = m->W;
     const long long rows = (long long)l.len * ts->B;
-    const long long ldT = (rows + 15) & ~15LL;
+    const long long ldT = (rows + 31) & ~31LL;
     if (ts->tens[l.iwx].frozen) return 0;
     HIPCHK(hipMemsetAsync(ts->T1.p, 0, (size_t)4 * W * ldT * 4, m->stream));
     launch_transpose(l.Z.as<float>(), (int)rows, 4 * W, 4 * W, ts->T1.as<float>(), ldT, m->stream);
@@ -365,7 +365,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     ENS(ts->dfin, (size_t)2 * D * B * W * 4) ENS(ts->dcbuf, (size_t)B * W * 4) ENS(ts->HP, LB * W * 4)
     ENS(ts->dX0, TB * W * 4) ENS(ts->dXtop, UB * W * 4) ENS(ts->dXl, TB * 2 * W * 4) ENS(ts->dYl, UB * W * 4) ENS(ts->dOin, TB * 2 * W * 4)
     ENS(ts->dcbuf2, (size_t)B * W * 4) ENS(ts->dvaP, (size_t)B * W * 4) ENS(ts->dbvP, (size_t)B * 4)
-    const long long ldTmax = (LB + 15) & ~15LL;
+    const long long ldTmax = (LB + 31) & ~31LL;
     ENS(ts->T1, (size_t)4 * W * ldTmax * 4) ENS(ts->T2, (size_t)std::max(2 * W, Vp) * ldTmax * 4) ENS(ts->T3, (size_t)(C + W) * ldTmax * 4)
     for (auto& l : ts->layers) {
         const bool enc = l.name.compare(0, 3, "enc") == 0;
@@ -487,7 +487,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     float* dlog = ts->logits.as<float>();
     // tied projection: dE += dlogits^T . G ; dG = dlogits . E
     {
-        const long long ldT = (UB + 15) & ~15LL;
+        const long long ldT = (UB + 31) & ~31LL;
         HIPCHK(hipMemsetAsync(ts->T2.p, 0, (size_t)Vp * ldT * 4, st));
         launch_transpose(dlog, (int)UB, Vp, Vp, ts->T2.as<float>(), ldT, st);
         HIPCHK(hipMemsetAsync(ts->T3.p, 0, (size_t)W * ldT * 4, st));
@@ -550,7 +550,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         if (int rc = layer_weight_grads(m, top, ts->Ym.as<float>(), W, ts->RecIn.as<float>(), kr)) return rc;
         // attention parameters: dWaT = DWQ^T . Hprev ; dbUW = colsum(DWQ) ; u path
         if (!ts->tens[ts->iWaT].frozen) {
-            const long long ldT = (UB + 15) & ~15LL;
+            const long long ldT = (UB + 31) & ~31LL;
             HIPCHK(hipMemsetAsync(ts->T1.p, 0, (size_t)W * ldT * 4, st));
             launch_transpose(ts->DWQ.as<float>(), (int)UB, W, W, ts->T1.as<float>(), ldT, st);
             // T3 still holds RecIn^T [kr][ldT]: rows C.. are h_prev^T
@@ -559,7 +559,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             launch_colsum(ts->DWQ.as<float>(), UB, W, W, ts->G_(ts->ibUW), st);
         }
         {
-            const long long ldT = (TB + 15) & ~15LL;
+            const long long ldT = (TB + 31) & ~31LL;
             HIPCHK(hipMemsetAsync(ts->T1.p, 0, (size_t)W * ldT * 4, st));
             launch_transpose(ts->du.as<float>(), (int)TB, W, W, ts->T1.as<float>(), ldT, st);
             HIPCHK(hipMemsetAsync(ts->T2.p, 0, (size_t)C * ldT * 4, st));
