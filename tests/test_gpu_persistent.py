@@ -98,3 +98,53 @@ def test_c2_full_size_on_the_persistent_path():
         res[persistent] = eng.decode_greedy(mode=0)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     eng.close()
+
+
+def test_handoffs_under_uneven_load():
+    """The hand-offs between workgroups must not depend on timing: random shapes decoded on the persistent path while a second
+    model handle keeps other CUs busy with beamed decodes on another stream, every result compared bit for bit with the
+    per-step kernels and with a repetition of itself (a stale or early read would show as a difference).  The long version of
+    this (thousands of cases, idle and loaded: all identical) is scratch-level; here a few seconds of it."""
+    import threading
+    import time
+    from cor_asv_ann_amd.engine import HipEngine
+    stop = []
+
+    def background():
+        cfg = ModelConfig(depth=2, width=256, voc_size=64)
+        e = HipEngine(2, 256, 64)
+        e.set_weights(make_weights(cfg, emb_scale=32.0))
+        _, bidx = make_lines(96, 30, 1, voc_size=64)
+        while not stop:
+            e.encode(bidx)
+            e.decode_beam(batch_size=8)
+        e.close()
+
+    th = threading.Thread(target=background)
+    th.start()
+    try:
+        rng = np.random.default_rng(5)
+        t0, cases = time.time(), 0
+        while time.time() - t0 < 8.0 or cases < 20:
+            d = int(rng.integers(1, 4)); W = int(rng.choice([32, 64, 128, 256])); V = int(rng.choice([24, 64, 100, 256]))
+            B = int(rng.integers(1, 200)); L = int(rng.integers(2, 40))
+            cfg = ModelConfig(depth=d, width=W, voc_size=V)
+            eng = _engine(cfg, make_weights(cfg, seed=int(rng.integers(1, 1 << 30)), emb_scale=float(rng.choice([8., 24., 64.]))))
+            _, idx = make_lines(B, L, int(rng.integers(1, 1 << 30)), voc_size=V)
+            out = {}
+            for rep in range(2):
+                for p in (0, 1):
+                    eng.set_option('persistent', p)
+                    eng.encode(idx)
+                    enc = eng.encoder_outputs()
+                    gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=True)
+                    cur = (enc[0], np.stack(enc[1]), gi, gp, ga)
+                    if p in out:
+                        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out[p], cur)), ('not reproducible', p, d, W, V, B, L)
+                    out[p] = cur
+                assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out[0], out[1])), ('persistent != per-step', d, W, V, B, L)
+            eng.close()
+            cases += 1
+    finally:
+        stop.append(1)
+        th.join()
