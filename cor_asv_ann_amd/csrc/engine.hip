@@ -229,9 +229,12 @@ static bool persist_enc_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0 || m->ncu < 64 || m->D > 8) return false;
     const int W = m->W, D = m->D;
     if ((size_t)16 * ((D >= 2 ? 3 * W : 2 * W) + 4) * 4 > 150 * 1024) return false;        // staged rows must fit the LDS
-    const int ntile = ((B + 15) / 16) * (W / 16), grid = std::min(std::max(2, D - 1) * ntile, 2 * m->ncu);
+    const int per_cu = std::min(2, (int)((160 * 1024) / ((size_t)16 * ((D >= 2 ? 3 * W : 2 * W) + 4) * 4 + 6 * 1024)));
+    if (per_cu < 1) return false;
+    const int ntile = ((B + 15) / 16) * (W / 16), grid = std::min(std::max(2, D - 1) * ntile, per_cu * m->ncu);
     if ((2 * ntile + grid - 1) / grid > 8 || ((D - 1) * ntile + grid - 1) / grid > 8) return false;   // tiles per workgroup (PENC_MAXT)
-    return m->persist_mode == 1 ? B <= 4096 : B <= 512;
+    if (m->persist_mode == 1) return B <= 4096;
+    return B <= 512 && (2 * ntile + grid - 1) / grid <= 2 && ((D - 1) * ntile + grid - 1) / grid <= 2;
 }
 
 extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const int32_t* idx, const float* val,
@@ -315,7 +318,8 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         }
         pa.x0 = x0; pa.H1 = H1; pa.cfin = cfin; pa.counters = m->p_counters.as<unsigned>();
         const int nrb = (B + 15) / 16, ntile = nrb * (W / 16);
-        const int grid = std::min(std::max(2, D - 1) * ntile, 2 * m->ncu);
+        const int per_cu = std::min(2, (int)((160 * 1024) / ((size_t)16 * pa.lda * 4 + 6 * 1024)));      // all workgroups resident at once
+        const int grid = std::min(std::max(2, D - 1) * ntile, std::max(per_cu, 1) * m->ncu);
         hipEvent_t pev{};
         m->prof_begin(PC_PERSIST, 2.0 * BT * 4.0 * W * (2.0 * 2 * W + (D >= 2 ? 3.0 * W : 0.0) + (D >= 3 ? (D - 2) * 2.0 * W : 0.0)), 0.0, pev);
         if (launch_persist_encode(pa, grid, m->stream)) return fail(CASV_ERR_ARG, "persistent encoder: rows do not fit the LDS");
@@ -661,8 +665,14 @@ static bool persist_applies(const casv_model* m, int B) {
     if (m->ncu < 64 || m->D > 8) return false;
     int kmax = m->W;
     for (int n = 1; n <= m->D; ++n) kmax = std::max(kmax, m->dec[n].kin + m->W);
-    if ((size_t)16 * (kmax + 4) * 4 > 150 * 1024) return false;   // the staged rows must fit the LDS
-    return m->persist_mode == 1 ? B <= 4096 : B <= 512;
+    const size_t lds = (size_t)16 * (kmax + 4) * 4;
+    if (lds > 150 * 1024) return false;                            // the staged rows must fit the LDS
+    if (m->persist_mode == 1) return B <= 4096;
+    // by size: the persistent kernel wins while a workgroup owns at most two tiles per layer (measured: depth 2, width 512: 64
+    // lines 9.3 vs 20.9 ms, 256 lines 32.5 vs 21.4 ms; depth 2, width 256: 512 lines 11.4 vs 14.7 ms)
+    const int per_cu = std::min(2, (int)((160 * 1024) / (lds + 6 * 1024)));
+    const int g_lstm = std::max(1, m->ncu * per_cu * 4 / 8), ntile = ((B + 15) / 16) * (m->W / 16);
+    return B <= 512 && (ntile + g_lstm - 1) / g_lstm <= 2;
 }
 static int decode_greedy_persistent(casv_model* m, int mode, int S, bool* aborted_out) {
     std::lock_guard<std::mutex> lock(g_persist_mutex);
@@ -695,19 +705,23 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S, bool* aborte
     pa.counters = m->p_counters.as<unsigned>();
     const int nrb = (R + 15) / 16, nug = W / 16;
     const int nq4 = (W / 16 + 3) / 4, nl4 = (Vp / 16 + 3) / 4;
-    const int ncu = m->ncu;
-    pa.g_lstm = std::min(nrb * nug, ncu);
-    pa.g_att = std::min(nrb * 4, std::max(ncu / 4, 8));
-    pa.g_plain = std::min(nrb * (nq4 + nl4), std::max(ncu / 2, 8));
+    int kmax = W;
+    for (int n = 1; n <= D; ++n) kmax = std::max(kmax, pa.layer[n - 1].Kt);
+    pa.lda = kmax + 4;
+    // Every workgroup must be resident at once (they wait for each other): per CU two by registers (247 VGPRs), and as many
+    // as the staged rows leave room for in the 160 KB of LDS.  The roles share the slots 4 : 1 : 2 (tiles, attention, plain).
+    const int per_cu = std::min(2, (int)((160 * 1024) / (persist_lds_bytes(pa) + 6 * 1024)));
+    if (per_cu < 1) return fail(CASV_ERR_ARG, "persistent decoder: rows of %d floats do not fit the LDS", kmax);
+    const int wgslots = m->ncu * per_cu;
+    pa.g_lstm = std::min(nrb * nug, wgslots * 4 / 8);
+    pa.g_att = std::min(nrb * 4, std::max(wgslots / 8, 4));
+    pa.g_plain = std::min(nrb * (nq4 + nl4), std::max(wgslots * 2 / 8, 4));
 #ifdef CASV_PERSIST_PROF
     static DevBuf profbuf;
     if (int rc = profbuf.ensure(32 * 8)) return rc;
     HIPCHK(hipMemsetAsync(profbuf.p, 0, 32 * 8, m->stream));
     pa.prof = profbuf.as<unsigned long long>();
 #endif
-    int kmax = W;
-    for (int n = 1; n <= D; ++n) kmax = std::max(kmax, pa.layer[n - 1].Kt);
-    pa.lda = kmax + 4;
     hipEvent_t pev{};
     {   // executed FLOPs of the launch: every step's layer, query and logits contractions over all rows; bytes: what a step
         // must move per row (state in and out, attention window, logits) -- SURVEY.md section 8(d)'s Q_row
