@@ -718,8 +718,8 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S, bool* aborte
     pa.g_plain = std::min(nrb * (nq4 + nl4), std::max(wgslots * 2 / 8, 4));
 #ifdef CASV_PERSIST_PROF
     static DevBuf profbuf;
-    if (int rc = profbuf.ensure(32 * 8)) return rc;
-    HIPCHK(hipMemsetAsync(profbuf.p, 0, 32 * 8, m->stream));
+    if (int rc = profbuf.ensure((32 + 2048) * 8)) return rc;
+    HIPCHK(hipMemsetAsync(profbuf.p, 0, (32 + 2048) * 8, m->stream));
     pa.prof = profbuf.as<unsigned long long>();
 #endif
     hipEvent_t pev{};
@@ -740,6 +740,22 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S, bool* aborte
         HIPCHK(hipMemcpyAsync(h, profbuf.p, sizeof h, hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
         const char* names[4] = {"layer1 (wait stats kloop cell publish)", "upper  (wait - kloop cell publish)", "att    (wait row publish)", "plain  (wait kloop publish)"};
+        if (getenv("CASV_PERSIST_PLACEMENT")) {
+            const int grid = pa.g_lstm + pa.g_att + pa.g_plain;
+            std::vector<unsigned long long> hw(grid);
+            HIPCHK(hipMemcpy(hw.data(), profbuf.as<unsigned long long>() + 32, (size_t)grid * 8, hipMemcpyDeviceToHost));
+            std::map<unsigned, std::string> cu;
+            for (int g = 0; g < grid; ++g) {
+                const unsigned h = (unsigned)hw[g], xcc = (unsigned)(hw[g] >> 32) & 15;
+                const unsigned key = (xcc << 16) | (((h >> 13) & 7) << 8) | (((h >> 12) & 1) << 4) | ((h >> 8) & 15);   // xcc, se, sh, cu
+                cu[key] += g < pa.g_lstm ? 'L' : g < pa.g_lstm + pa.g_att ? 'A' : 'P';
+            }
+            std::map<std::string, int> hist;
+            for (auto& kv : cu) hist[kv.second]++;
+            fprintf(stderr, "persist placement (%zu CUs):", cu.size());
+            for (auto& kv : hist) fprintf(stderr, " %s x%d", kv.first.c_str(), kv.second);
+            fprintf(stderr, "\n");
+        }
         for (int r = 0; r < 4; ++r) {
             fprintf(stderr, "persist prof %s us/step:", names[r]);
             for (int k = 0; k < 5; ++k) fprintf(stderr, " %.2f", h[r * 8 + k] * 0.01 / S);

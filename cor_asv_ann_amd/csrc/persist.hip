@@ -52,7 +52,9 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
 
 struct Dep { const unsigned* c; unsigned target; };
 
-// One lane waits until every counter has reached its target, then the workgroup acquires.  false = aborted.
+// One lane waits until every counter has reached its target.  No cache invalidation follows: the payload is read with loads
+// that go past the L2 (load_sc1) -- an agent-scope acquire would empty this XCD's L2 of the weights as well, and the K loops
+// would wait for memory instead of the L2.  false = aborted.
 __device__ __forceinline__ bool wait_deps(const Dep d0, const Dep d1, const Dep d2, unsigned* abort_w, int* s_ok) {
     if (threadIdx.x == 0) {
         int good = 1;
@@ -70,8 +72,6 @@ __device__ __forceinline__ bool wait_deps(const Dep d0, const Dep d1, const Dep 
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         *s_ok = good;
     }
     __syncthreads();
@@ -89,28 +89,49 @@ __device__ __forceinline__ void publish(unsigned* counter) {
 
 struct RowStat { float m, sum; int nan0; };   // softmax statistics of one row; nan0: mode 1 wrote NaN over p[0]
 
-constexpr int PDB = 12;                         // weight tiles (16 k each) in flight per wave
+constexpr int PDB = 12;                         // weight tiles (16 k each) in flight per wave; a multiple of 3 (k_loop)
 
 // The workgroup's 16 activation rows [x | ctx | h] are staged ONCE in LDS (they were written by other workgroups a moment
 // ago, so every line is a miss in this XCD's L2: fetched one by one along the K loop they would cost a memory round trip per
-// few tiles; together they cost one).  16 threads per row, 16 B per load, all loads of a thread independent.
+// few tiles; together they cost one).  16 threads per row, 16 B per load.
 // Inside every group of 16 k the rows are stored in MFMA-group order (position 4*kg + q = the k that k group kg contracts in
 // instruction q, as the packed weights are): a lane's operands of one tile are ONE 16-B LDS read, no cross-lane traffic.
 __device__ __forceinline__ int perm16(const int k) {       // natural k -> position inside its 16-group
     // positions of k = 0..15: 0,8,1,9, 4,12,5,13, 2,10,3,11, 6,14,7,15
     return ((k & 1) << 3) | (k & 4) | ((k & 8) >> 2) | ((k & 2) >> 1);
 }
-__device__ __forceinline__ void stage_rows(float* s_a, const int lda, const int koff, const float* __restrict__ base,
-                                           const int ld, const int width, const int rb, const int R, const int tid) {
+constexpr int STAGE_NB = 12;
+struct RowSeg { const float* base; int ld, width; };      // rows `base + row * ld`, `width` floats wide (a multiple of 16)
+// Up to three K segments of the 16 rows at once: chunk f (16 B) of the concatenated row belongs to thread f % 16 of the row,
+// STAGE_NB chunks of a thread are in flight together, whichever segments they come from.
+__device__ __forceinline__ void stage_rows(float* s_a, const int lda, const int koff, const RowSeg g0, const RowSeg g1,
+                                           const RowSeg g2, const int rb, const int R, const int tid) {
     const int r = tid >> 4, c0 = tid & 15;
     int row = rb * 16 + r; row = row < R ? row : R - 1;
-    const f32x4* src = reinterpret_cast<const f32x4*>(base + (long long)row * ld);
-    float* dst = s_a + r * lda + koff;
-    for (int c = c0; c < width / 4; c += 16) {
-        const f32x4 v = src[c];
-        float* d = dst + (c >> 2) * 16;                     // chunk c holds k = 4*(c&3) .. +3 of 16-group c>>2
-        const int k0 = 4 * (c & 3);
-        d[perm16(k0)] = v[0]; d[perm16(k0 + 1)] = v[1]; d[perm16(k0 + 2)] = v[2]; d[perm16(k0 + 3)] = v[3];
+    const float* p0 = g0.base + (long long)row * g0.ld;
+    const float* p1 = g1.width ? g1.base + (long long)row * g1.ld : p0;
+    const float* p2 = g2.width ? g2.base + (long long)row * g2.ld : p0;
+    const int b0 = g0.width >> 2, b1 = b0 + (g1.width >> 2), n4 = b1 + (g2.width >> 2);
+    const int nmine = n4 > c0 ? (n4 - c0 + 15) >> 4 : 0;          // this thread's chunks f = c0 + 16 i
+    float* dst = s_a + r * lda + koff + (c0 >> 2) * 16;           // chunk f sits in 16-group f >> 2 = (c0 >> 2) + 4 i
+    const int k0 = 4 * (c0 & 3);
+    const int q0 = perm16(k0), q1 = perm16(k0 + 1), q2 = perm16(k0 + 2), q3 = perm16(k0 + 3);
+    for (int i0 = 0; i0 < nmine; i0 += STAGE_NB) {
+        f32x4 v[STAGE_NB];
+#pragma unroll
+        for (int j = 0; j < STAGE_NB; ++j) {
+            const int i = i0 + j < nmine ? i0 + j : nmine - 1;
+            const int f = c0 + 16 * i;
+            const float4 x = load_sc1(f < b0 ? p0 + 4 * f : f < b1 ? p1 + 4 * (f - b0) : p2 + 4 * (f - b1));
+            v[j] = f32x4{x.x, x.y, x.z, x.w};
+        }
+#pragma unroll
+        for (int j = 0; j < STAGE_NB; ++j) {
+            if (i0 + j < nmine) {
+                float* d = dst + (i0 + j) * 64;
+                d[q0] = v[j][0]; d[q1] = v[j][1]; d[q2] = v[j][2]; d[q3] = v[j][3];
+            }
+        }
     }
 }
 __device__ __forceinline__ int permv(const int v) { return (v & ~15) | perm16(v & 15); }
@@ -140,11 +161,16 @@ __device__ __forceinline__ f32x4 k_loop(const float* s_a, const int lda, const f
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bq[2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bq[3], acc, 0, 0, 0);
     };
+    // the A fragments run two tiles ahead of their MFMAs in three rotating registers (one ds_read_b128 per tile: issued right
+    // before its use, its latency would be exposed once per tile)
+    auto afrag = [&](const int t) { return *reinterpret_cast<const f32x4*>(arow + (t < nt ? t : nt - 1) * 16); };
     int kt = kt_begin;
+    f32x4 a[3] = {afrag(kt), afrag(kt + 1), afrag(kt + 2)};
     for (; kt + PDB <= nt; kt += PDB) {
 #pragma unroll
         for (int q = 0; q < PDB; ++q) {
-            mma(*reinterpret_cast<const f32x4*>(arow + (kt + q) * 16), ring.t[q]);
+            mma(a[q % 3], ring.t[q]);
+            a[q % 3] = afrag(kt + q + 3);
             const int nx = kt + PDB + q < nt ? kt + PDB + q : nt - 1;          // past the end: a valid, unused re-load
             ring.t[q] = *reinterpret_cast<const f32x4*>(b + (long long)nx * 16);
         }
@@ -152,7 +178,7 @@ __device__ __forceinline__ f32x4 k_loop(const float* s_a, const int lda, const f
     const int rest = nt - kt;
 #pragma unroll
     for (int q = 0; q < PDB - 1; ++q)
-        if (rest > q) mma(*reinterpret_cast<const f32x4*>(arow + (kt + q) * 16), ring.t[q]);
+        if (rest > q) { mma(a[q % 3], ring.t[q]); a[q % 3] = afrag(kt + q + 3); }
     return acc;
 }
 
@@ -292,6 +318,12 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
     const int kg4 = 4 * (lane >> 4);
 #ifdef CASV_PERSIST_PROF
     const bool prof_on = pa.prof && (g == 0 || g == pa.g_lstm || g == pa.g_lstm + pa.g_att);
+    if (pa.prof && tid == 0) {          // where this workgroup runs: XCC_ID (register 20) and HW_ID (register 4)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        pa.prof[32 + g] = ((unsigned long long)xcc << 32) | hw;
+    }
 #endif
 
     if (g < pa.g_lstm) {
@@ -326,12 +358,17 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
                     const int erow_c = erow < R ? erow : R - 1;
                     float cprev = 0.0f;
                     if (s < S) cprev = pa.c[n - 1][(long long)s * RW + (long long)erow_c * W + eu];
-                    // the 16 rows of [x | ctx | h] -> LDS
-                    if (first) { if (s > 0) stage_rows(s_a, lda, 0, pa.logits + (long long)s * R * Vp, Vp, Vp, rb, R, tid); }
-                    else stage_rows(s_a, lda, 0, pa.h[n - 2] + (long long)(s + 1) * RW, W, W, rb, R, tid);
-                    if (s < S) {
-                        if (top) stage_rows(s_a, lda, wx, pa.ctx + (long long)(s + 1) * R * C, C, C, rb, R, tid);
-                        stage_rows(s_a, lda, wx + (top ? C : 0), pa.h[n - 1] + (long long)s * RW, W, W, rb, R, tid);
+                    // the 16 rows of [x | ctx | h] -> LDS: x = the logits of step s-1 (layer 1; slot s) or the output of the layer
+                    // below at this step (slot s+1), ctx of this step, h of step s-1 (slot s)
+                    {
+                        const RowSeg none{nullptr, 0, 0};
+                        const RowSeg gx = first ? RowSeg{pa.logits + (long long)s * R * Vp, Vp, Vp} : RowSeg{pa.h[n - 2] + (long long)(s + 1) * RW, W, W};
+                        const RowSeg gc = top ? RowSeg{pa.ctx + (long long)(s + 1) * R * C, C, C} : none;
+                        const RowSeg gh{pa.h[n - 1] + (long long)s * RW, W, W};
+                        if (s == S) stage_rows(s_a, lda, 0, gx, none, none, rb, R, tid);
+                        else if (first && s == 0) { if (top) stage_rows(s_a, lda, wx, gc, gh, none, rb, R, tid); else stage_rows(s_a, lda, wx, gh, none, none, rb, R, tid); }
+                        else if (top) stage_rows(s_a, lda, 0, gx, gc, gh, rb, R, tid);
+                        else stage_rows(s_a, lda, 0, gx, gh, none, rb, R, tid);
                     }
                     __syncthreads();
                     if (first && s > 0) {
@@ -441,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
                 PROF_ADD(24, t1, t0);
                 const int ct = (query ? k : k - NQ4) * 4 + wave;               // this wave's 16-column tile
                 const int nct = query ? W / 16 : Vp / 16;
-                stage_rows(s_a, lda, 0, pa.h[D - 1] + (long long)(s + 1) * RW, W, W, rb, R, tid);
+                stage_rows(s_a, lda, 0, RowSeg{pa.h[D - 1] + (long long)(s + 1) * RW, W, W}, RowSeg{nullptr, 0, 0}, RowSeg{nullptr, 0, 0}, rb, R, tid);
                 __syncthreads();
                 if (ct < nct) {
                     const f32x4 acc = k_loop(s_a, lda, b, ring, 0, W / 16, lane);
@@ -500,8 +537,7 @@ __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEnc
         BRing ring;
         ring_start(ring, b, 0, nt);
         if (!wait_deps(dx, dh, d3, abort_w, &s_ok)) return false;
-        stage_rows(s_a, lda, 0, xbase, (int)xld, kx, rb, B, tid);
-        if (!first) stage_rows(s_a, lda, kx, hprev, (int)hld, W, rb, B, tid);
+        stage_rows(s_a, lda, 0, RowSeg{xbase, (int)xld, kx}, RowSeg{hprev, (int)hld, first ? 0 : W}, RowSeg{nullptr, 0, 0}, rb, B, tid);
         __syncthreads();
         const f32x4 acc = k_loop(s_a, lda, b, ring, 0, nt, lane);
 #pragma unroll

@@ -9,6 +9,15 @@ namespace casv {
 
 // write-through store (global_store ... sc1): payload handed to another workgroup inside a launch
 __device__ __forceinline__ void store_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... and its read side: 16 B past this XCD's L2 (global_load ... sc1, as two 8-B loads).  Payload that is only ever read
+// this way needs no cache invalidation on the consumer's side -- an invalidation would also evict the weights from the L2.
+__device__ __forceinline__ float4 load_sc1(const float* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -62,7 +71,8 @@ __device__ __forceinline__ AttWin att_window(const AttnArgs& a, const int r, con
 
 // (2) energies exp(tanh(wq + u[s]) . v_a + b_v) over the window, normalised; writes the alignment row and the per-row
 // by-products.  urow(s) -> the row u[line][s] as float4s (global memory, or the workgroup's staged copy).
-template <class URow>
+// HANDOFF: the query row was written by another workgroup of the same launch (read past the L2).
+template <bool HANDOFF, class URow>
 __device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, const int step, const int lane, const AttWin w,
                                             URow urow, float (&e)[MAXWIN]) {
     const int T = a.T, W = a.W;
@@ -80,7 +90,7 @@ __device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, cons
         float4 uu[MAXWIN];
 #pragma unroll
         for (int i = 0; i < MAXWIN; ++i) uu[i] = urow(s_lo + i)[j];
-        const float4 q = wq4[j], v = va4[j];
+        const float4 q = HANDOFF ? load_sc1(reinterpret_cast<const float*>(wq4 + j)) : wq4[j], v = va4[j];
 #pragma unroll
         for (int i = 0; i < MAXWIN; ++i) {
             e[i] += fast_tanh(q.x + uu[i].x) * v.x;
@@ -157,7 +167,7 @@ __device__ __forceinline__ void attention_row(const AttnArgs& a, const int r, co
     const float* ub = a.u + (long long)ln * a.u_line;
     const float* eb = a.enc + (long long)ln * a.enc_line;
     float e[MAXWIN];
-    att_weights(a, r, step, lane, w, [&](int s) { s = s < T ? s : T - 1; return reinterpret_cast<const float4*>(ub + (long long)s * a.u_time); }, e);
+    att_weights<HANDOFF>(a, r, step, lane, w, [&](int s) { s = s < T ? s : T - 1; return reinterpret_cast<const float4*>(ub + (long long)s * a.u_time); }, e);
     att_context<HANDOFF>(a, r, lane, w, [&](int s) { s = s < T ? s : T - 1; return reinterpret_cast<const float4*>(eb + (long long)s * a.enc_time); }, e);
 }
 
