@@ -120,16 +120,14 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
         float hi = -INFINITY;
 #pragma unroll
         for (int k = 0; k < VPL; ++k) hi = fmaxf(hi, vals[k]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        hi = wave_butterfly(hi, [](float a, float b) { return fmaxf(a, b); });
         const double thr = (double)hi * p.threshold_in;
         float v0 = __shfl(vals[0], 0, 64);                  // score of index 0
         float vr = 0.f;
         if (rej >= 0) {
 #pragma unroll
             for (int k = 0; k < VPL; ++k) if (lane + 64 * k == rej) vr = vals[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) vr = fmaxf(vr, __shfl_xor(vr, o, 64));   // scores are >= 0
+            vr = wave_butterfly(vr, [](float a, float b) { return fmaxf(a, b); });   // scores are >= 0
         }
         int cnt = 0, rank0 = 0, rankr = 0;
 #pragma unroll
@@ -141,9 +139,9 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
                 if (rej >= 0) rankr += better(vals[k], v, vr, rej) ? 1 : 0;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            cnt += __shfl_xor(cnt, o, 64); rank0 += __shfl_xor(rank0, o, 64); rankr += __shfl_xor(rankr, o, 64);
+        {
+            auto add = [](int a, int b) { return a + b; };
+            cnt = wave_butterfly(cnt, add); rank0 = wave_butterfly(rank0, add); rankr = wave_butterfly(rankr, add);
         }
         rank0 += 1; rankr += 1;
         const int beampos = cnt < p.width_in ? cnt : p.width_in;
@@ -201,10 +199,10 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
                     const int v = lane + 64 * k;
                     if (v < V && !((taken >> k) & 1ull) && (bi < 0 || better(vals[k], v, bv, bi))) { bv = vals[k]; bi = v; }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                    if (oi >= 0 && (bi < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+                {
+                    auto step = [&](const float ov, const int oi) { if (oi >= 0 && (bi < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; } };
+                    step(lane_xor<32>(bv), lane_xor<32>(bi)); step(lane_xor<16>(bv), lane_xor<16>(bi)); step(lane_xor<8>(bv), lane_xor<8>(bi));
+                    step(lane_xor<4>(bv), lane_xor<4>(bi)); step(lane_xor<2>(bv), lane_xor<2>(bi)); step(lane_xor<1>(bv), lane_xor<1>(bi));
                 }
 #pragma unroll
                 for (int k = 0; k < VPL; ++k) if (lane + 64 * k == bi) taken |= 1ull << k;
@@ -212,8 +210,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
                 bi = rej; bv = 0.f;
 #pragma unroll
                 for (int k = 0; k < VPL; ++k) if (lane + 64 * k == rej) bv = vals[k];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) bv = fmaxf(bv, __shfl_xor(bv, o, 64));
+                bv = wave_butterfly(bv, [](float a, float b) { return fmaxf(a, b); });
             }
             bool isrej = false;
             if (rej >= 0 && bi == rej) { isrej = true; rej = -1; }

@@ -7,6 +7,40 @@ namespace casv {
 
 // tanh on the transcendental units (v_exp_f32 + v_rcp_f32): |error| <= ~2e-7 absolute.  The energies
 // need 11*W tanh per decoder row; libm's tanhf made this kernel VALU-bound at 5x the time.
+// Value of lane (id ^ MASK) of a fully active 64-lane wave, without the LDS crossbar round trip of ds_bpermute (what
+// __shfl_xor compiles to): DPP for partners inside a row of 16 lanes, the gfx950 row-swap instructions across rows.  Same
+// partner, same value: butterflies built from these reduce in exactly the order of the __shfl_xor loops they replace
+// (profiles/lane_xor_probe.hip checks every mask against __shfl_xor on the device).
+template <int MASK> __device__ __forceinline__ int lane_xor(const int x) {
+    static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8 || MASK == 16 || MASK == 32, "one bit");
+    if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);                 // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);            // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 4)                                                                      // i^7 then i^3
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+    else if constexpr (MASK == 8) return __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);            // row_ror:8
+    else if constexpr (MASK == 16) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        return (int)((__lane_id() & 16) ? r[0] : r[1]);
+    } else {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+        return (int)((__lane_id() & 32) ? r[0] : r[1]);
+    }
+}
+template <int MASK> __device__ __forceinline__ float lane_xor(const float x) { return __int_as_float(lane_xor<MASK>(__float_as_int(x))); }
+template <int MASK> __device__ __forceinline__ double lane_xor(const double x) {
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)lane_xor<MASK>((int)(unsigned)b), hi = (unsigned)lane_xor<MASK>((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// butterfly over the wave, partners 32, 16, 8, 4, 2, 1 in this order: v = op(v, partner's v)
+template <class T, class Op> __device__ __forceinline__ T wave_butterfly(T v, Op op) {
+    v = op(v, lane_xor<32>(v)); v = op(v, lane_xor<16>(v)); v = op(v, lane_xor<8>(v));
+    v = op(v, lane_xor<4>(v)); v = op(v, lane_xor<2>(v)); v = op(v, lane_xor<1>(v));
+    return v;
+}
+
 __device__ __forceinline__ float fast_tanh(float x) {
     const float ax = fabsf(x);
     if (ax < 0.25f) {          // odd Taylor region: avoids the cancellation of 1 - 2/(1+e^2x)

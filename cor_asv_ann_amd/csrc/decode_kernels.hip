@@ -55,12 +55,7 @@ __global__ __launch_bounds__(256) void softmax_kernel(const SoftmaxArgs a) {
         if (v >= 1 && v < V && pv > best) { best = pv; bidx = v; }
     }
     if (a.mode < 0) return;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bidx, o, 64);
-        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-    }
+    wave_argmax(best, bidx);
     p0 = __shfl(p0, 0, 64);
     if (lane == 0) {
         int idx = bidx; float pr = best;

@@ -205,9 +205,7 @@ __device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, co
             if (lane + 64 * k < V) { m[i] = fmaxf(m[i], xv[i][k]); nan[i] += (xv[i][k] != xv[i][k]) ? 1.0f : 0.0f; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { m[i] = fmaxf(m[i], __shfl_xor(m[i], o, 64)); nan[i] += __shfl_xor(nan[i], o, 64); }
+    for (int i = 0; i < 4; ++i) { m[i] = wave_max(m[i]); nan[i] = wave_sum(nan[i]); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (nan[i] > 0.0f) m[i] = __builtin_nanf("");
@@ -217,9 +215,7 @@ __device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, co
             if (lane + 64 * k < V) { xv[i][k] = expf(xv[i][k] - m[i]); sum[i] += xv[i][k]; }     // xv now holds exp(x - m)
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sum[i] += __shfl_xor(sum[i], o, 64);
+    for (int i = 0; i < 4; ++i) sum[i] = wave_sum(sum[i]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         best[i] = -INFINITY; bidx[i] = 0x7fffffff; p0[i] = 0.0f;
@@ -233,13 +229,7 @@ __device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, co
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float ob = __shfl_xor(best[i], o, 64);
-            const int oi = __shfl_xor(bidx[i], o, 64);
-            if (ob > best[i] || (ob == best[i] && oi < bidx[i])) { best[i] = ob; bidx[i] = oi; }
-        }
+    for (int i = 0; i < 4; ++i) wave_argmax(best[i], bidx[i]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float p00 = __shfl(p0[i], 0, 64);
@@ -280,12 +270,7 @@ __device__ __forceinline__ RowStat row_stats(const float* x, const int V, const 
         if (v == 0) p0 = pv;
         if (v >= 1 && v < V && pv > best) { best = pv; bidx = v; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bidx, o, 64);
-        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-    }
+    wave_argmax(best, bidx);
     p0 = __shfl(p0, 0, 64);
     RowStat st; st.m = m; st.sum = sum; st.nan0 = 0;
     int idx = bidx; float pr = best;

@@ -19,20 +19,14 @@ __device__ __forceinline__ float4 load_sc1(const float* p) {
                        __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+__device__ __forceinline__ float wave_sum(float v) { return wave_butterfly(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_butterfly(v, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_butterfly(v, [](float a, float b) { return fmaxf(a, b); }); }
+// argmax butterfly of the softmax kernels: larger value wins, the lower index among equals
+__device__ __forceinline__ void wave_argmax(float& best, int& bidx) {
+    auto step = [&](const float ob, const int oi) { if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; } };
+    step(lane_xor<32>(best), lane_xor<32>(bidx)); step(lane_xor<16>(best), lane_xor<16>(bidx)); step(lane_xor<8>(best), lane_xor<8>(bidx));
+    step(lane_xor<4>(best), lane_xor<4>(bidx)); step(lane_xor<2>(best), lane_xor<2>(bidx)); step(lane_xor<1>(best), lane_xor<1>(bidx));
 }
 
 // ---------------------------------------------------------------------------------------------

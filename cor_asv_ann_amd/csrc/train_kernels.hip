@@ -7,11 +7,7 @@
 
 namespace casv {
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wsum(float v) { return wave_butterfly(v, [](float a, float b) { return a + b; }); }
 
 // ---- transpose: dst[c][r] = src[r][c] (32x32 tiles through LDS) ----
 __global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, long long ld_src,
@@ -130,8 +126,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(float* __restrict__ log
     float* x = logits + r * Vp;
     float m = -INFINITY;
     for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    m = wave_butterfly(m, [](float a, float b) { return fmaxf(a, b); });
     float sum = 0.f;
     for (int v = lane; v < V; v += 64) sum += expf(x[v] - m);
     sum = wsum(sum);
