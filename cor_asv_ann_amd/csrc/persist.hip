@@ -185,8 +185,9 @@ __device__ __forceinline__ f32x4 k_loop(const float* s_a, const int lda, const f
 // Softmax statistics + greedy pick (the arithmetic of softmax_kernel, decode_kernels.hip: per-lane partial results over
 // v = lane, lane + 64, ... in ascending order, then the same butterflies) of FOUR rows by one wave.  The rows are
 // independent, so their loads, transcendentals and shuffles interleave; every row's numbers are what the one-row kernel
-// computes.  VPL = vocabulary entries per lane held in registers (V <= 64 * VPL).
-template <int VPL>
+// computes.  VPL = vocabulary entries per lane held in registers (V <= 64 * VPL); FULL: V = Vp = 64 * VPL, no entry is
+// conditional.
+template <int VPL, bool FULL>
 __device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, const int Vp, const int mode, const int lane,
                                            const bool (&emit)[4], int* const (&out_idx)[4], float* const (&out_prob)[4],
                                            int* nan_flag, RowStat (&st)[4]) {
@@ -194,7 +195,7 @@ __device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, co
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; xv[i][k] = v < V ? x[i][permv(v)] : 0.0f; }
+        for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; xv[i][k] = (FULL || v < V) ? x[i][permv(v)] : 0.0f; }
     float m[4], nan[4], sum[4], best[4], p0[4];
     int bidx[4];
 #pragma unroll
@@ -202,7 +203,7 @@ __device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, co
         m[i] = -INFINITY; nan[i] = 0.0f;
 #pragma unroll
         for (int k = 0; k < VPL; ++k)
-            if (lane + 64 * k < V) { m[i] = fmaxf(m[i], xv[i][k]); nan[i] += (xv[i][k] != xv[i][k]) ? 1.0f : 0.0f; }
+            if (FULL || lane + 64 * k < V) { m[i] = fmaxf(m[i], xv[i][k]); nan[i] += (xv[i][k] != xv[i][k]) ? 1.0f : 0.0f; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { m[i] = wave_max(m[i]); nan[i] = wave_sum(nan[i]); }
@@ -212,7 +213,7 @@ __device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, co
         sum[i] = 0.0f;
 #pragma unroll
         for (int k = 0; k < VPL; ++k)
-            if (lane + 64 * k < V) { xv[i][k] = expf(xv[i][k] - m[i]); sum[i] += xv[i][k]; }     // xv now holds exp(x - m)
+            if (FULL || lane + 64 * k < V) { xv[i][k] = expf(xv[i][k] - m[i]); sum[i] += xv[i][k]; }     // xv now holds exp(x - m)
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) sum[i] = wave_sum(sum[i]);
@@ -222,9 +223,9 @@ __device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, co
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             const int v = lane + 64 * k;
-            const float pv = v < V ? xv[i][k] / sum[i] : 0.0f;
+            const float pv = (FULL || v < V) ? xv[i][k] / sum[i] : 0.0f;
             if (v == 0) p0[i] = pv;
-            if (v >= 1 && v < V && pv > best[i]) { best[i] = pv; bidx[i] = v; }
+            if (v >= 1 && (FULL || v < V) && pv > best[i]) { best[i] = pv; bidx[i] = v; }
             xv[i][k] = pv;                                        // xv now holds the distribution
         }
     }
@@ -246,7 +247,7 @@ __device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, co
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             const int v = lane + 64 * k;
-            if (v < Vp) x[i][permv(v)] = (v == 0 && st[i].nan0) ? __builtin_nanf("") : xv[i][k];
+            if (FULL || v < Vp) x[i][permv(v)] = (v == 0 && st[i].nan0) ? __builtin_nanf("") : xv[i][k];
         }
     }
 }
@@ -368,7 +369,8 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
                             oi[i] = pa.out_idx + (long long)r * S + (s - 1); op[i] = pa.out_prob + (long long)r * S + (s - 1);
                         }
                         RowStat q[4];
-                        if (V <= 256) row_stats4<4>(xr, V, Vp, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
+                        if (V == 256 && Vp == 256) row_stats4<4, true>(xr, V, Vp, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
+                        else if (V <= 256) row_stats4<4, false>(xr, V, Vp, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
                         else {
                             // large vocabularies: one row at a time, values re-read in every pass, then the rows are rewritten
                             for (int i = 0; i < 4; ++i) q[i] = row_stats(xr[i], V, Vp, pa.mode, lane, emit[i], oi[i], op[i], pa.nan_flag);
