@@ -11,6 +11,7 @@
 // among equal pro_cost, the node inserted first.
 #include "common.h"
 #include <math.h>
+#include <stdio.h>
 
 namespace casv {
 
@@ -48,9 +49,40 @@ void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t strea
     hipLaunchKernelGGL(beam_init_kernel, dim3(s.B), dim3(256), 0, stream, s, p);
 }
 
+// Diagnostic build (-DCASV_BEAM_PROF): the workgroup of line 0 adds the wall-clock ticks (10 ns) of each phase of its step
+// to g_beam_prof; beam_prof_dump() prints and clears them.
+#ifdef CASV_BEAM_PROF
+__device__ unsigned long long g_beam_prof[8];
+__device__ unsigned g_beam_wg[3 * 4096];          // per line: start and end tick of its workgroup in the last launch, new keys
+#define BPROF(slot) do { __syncthreads(); if (line == 0 && tid == 0) { const unsigned long long now = wall_clock64(); atomicAdd(g_beam_prof + (slot), now - bt); bt = now; } } while (0)
+void beam_prof_dump(int steps) {
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_beam_prof), sizeof h) != hipSuccess) return;
+    fprintf(stderr, "beam prof us/step: A1 %.2f  offsets %.2f  A2 %.2f  sort %.2f  merge %.2f  pop %.2f  inputs %.2f\n",
+            h[0] * 0.01 / steps, h[1] * 0.01 / steps, h[2] * 0.01 / steps, h[3] * 0.01 / steps, h[4] * 0.01 / steps, h[5] * 0.01 / steps, h[6] * 0.01 / steps);
+    for (auto& v : h) v = 0;
+    {
+        static unsigned w[3 * 4096];
+        if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_beam_wg), sizeof w) == hipSuccess) {
+            unsigned t0 = ~0u, t1 = 0; int n = 0;
+            for (int i = 0; i < 4096; ++i) if (w[3 * i + 1]) { t0 = w[3 * i] < t0 ? w[3 * i] : t0; t1 = w[3 * i + 1] > t1 ? w[3 * i + 1] : t1; ++n; }
+            if (n) {
+                double sum = 0; unsigned dmax = 0, smax = 0; int knew = 0;
+                for (int i = 0; i < 4096; ++i) if (w[3 * i + 1]) { const unsigned d = w[3 * i + 1] - w[3 * i]; sum += d; if (d > dmax) { dmax = d; knew = (int)w[3 * i + 2]; } if (w[3 * i] - t0 > smax) smax = w[3 * i] - t0; }
+                fprintf(stderr, "beam prof last launch: %d workgroups, span %.2f us, mean duration %.2f, max %.2f (new keys %d), latest start +%.2f us\n",
+                        n, (t1 - t0) * 0.01, sum / n * 0.01, dmax * 0.01, knew, smax * 0.01);
+            }
+        }
+    }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_beam_prof), h, sizeof h);
+}
+#else
+#define BPROF(slot)
+#endif
+
 // VPL = vocabulary entries per lane (V <= 64 * VPL); NWV = waves per workgroup (one wave expands one hypothesis row)
 template <int VPL, int NWV>
-__global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, const BeamParams p) {
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))) void beam_step_kernel(const BeamState s, const BeamParams p) {
     constexpr int NT = 64 * NWV;
     // dynamic LDS: [sort_cap new keys (f64)] [q_stage old keys (f64)] [sort_cap new ids] [q_stage old ids] [7 x (N+1) row records]
     extern __shared__ __attribute__((aligned(16))) unsigned char beam_smem[];
@@ -81,6 +113,10 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
     if (tid == 0) s.line_steps[line] = step + 1;
     if (step + 1 >= s.S) return;       // children of the last iteration are never popped (s2s:1398)
 
+#ifdef CASV_BEAM_PROF
+    unsigned long long bt = wall_clock64();
+    if (tid == 0 && line < 4096) { g_beam_wg[3 * line] = (unsigned)bt; g_beam_wg[3 * line + 1] = 0; }
+#endif
     // ---------------- A1: per row, rejection overwrite + child count ----------------
     for (int i = wave; i < nact; i += NWV) {
         const int r = line * N + i;
@@ -155,6 +191,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
         }
     }
     __syncthreads();
+    BPROF(0);
     if (tid == 0) {
         int o = 0;
         for (int i = 0; i < nact; ++i) { r_off[i] = o; o += r_count[i]; }
@@ -172,6 +209,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
     double* g0k = s.g_key + 2 * gbase; int* g0i = s.g_id + 2 * gbase;          // unsorted, then sorted runs
     double* g1k = g0k + s.g_cap; int* g1i = g0i + s.g_cap;                     // the merged order
 
+    BPROF(1);
     // ---------------- A2: iterative selection, node records, keys ----------------
     for (int i = wave; i < nact; i += NWV) {
         if (r_count[i] == 0) continue;
@@ -239,6 +277,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
     __syncthreads();
     if (tid == 0) s.n_count[line] = id0 + nnew;
 
+    BPROF(2);
     // ---------------- B: sort the new nodes, merge with the queue, cap ----------------
     auto bitonic = [&](int npow) {          // s_key/s_id[0..npow) best first
         for (int k = 2; k <= npow; k <<= 1) {
@@ -293,6 +332,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
         }
         __syncthreads();
     }
+    BPROF(3);
     const int par = step & 1;
     const long long qstride = (long long)s.B * s.q_cap;
     const int qn_old = s.q_n[line], qhead = s.q_n[s.B + line];
@@ -331,6 +371,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
     __syncthreads();
     const int qn = (qn_old + nnew) < qcap ? (qn_old + nnew) : qcap;
 
+    BPROF(4);
     // ---------------- C: pop the next beam ----------------
     const int pre = qn < 64 ? qn : 64;
     if (tid < pre) pop_chr[tid] = s.n_chr[nbase + pop_id[tid]];
@@ -374,6 +415,7 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
     }
     __syncthreads();
     if (sh_done) return;
+    BPROF(5);
     const int nb = sh_nb;
     // next step's inputs: fed-back scores with the better siblings reset (s2s:1515-1520); one wave per row
     for (int j = wave; j < N; j += NWV) {
@@ -393,6 +435,10 @@ __global__ __launch_bounds__(64 * NWV) void beam_step_kernel(const BeamState s, 
             if (lane == 0) s.prev[r] = line * N;
         }
     }
+    BPROF(6);
+#ifdef CASV_BEAM_PROF
+    if (tid == 0 && line < 4096) { g_beam_wg[3 * line + 1] = (unsigned)wall_clock64(); g_beam_wg[3 * line + 2] = (unsigned)nnew; }
+#endif
 }
 // LDS plan of one launch: sort capacity (new keys held at once), staged entries of the old queue, bytes.
 size_t beam_lds_bytes(int N, int width_in, int V, int q_cap, int* sort_cap, int* q_stage) {

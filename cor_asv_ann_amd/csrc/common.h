@@ -227,6 +227,9 @@ struct BeamState {
 };
 void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t stream);
 void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream);
+#ifdef CASV_BEAM_PROF
+void beam_prof_dump(int steps);      // diagnostic build: phase times of the beam step kernel (beam_kernels.hip)
+#endif
 struct BeamOut {
     int* idx; float* prob; int* len; double* score; int* rejpos; float* align; int* n_found; int* n_steps;
     const float* a_base;

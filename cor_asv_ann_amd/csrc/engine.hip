@@ -943,6 +943,9 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     HIPCHK(hipMemsetAsync(m->bo_idx.p, 0, OR * S * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->bo_prob.p, 0, OR * S * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->bo_rej.p, 0xff, OR * S * 4, m->stream));
+#ifdef CASV_BEAM_PROF
+    { HIPCHK(hipStreamSynchronize(m->stream)); casv::beam_prof_dump(m->S); }
+#endif
     launch_beam_extract(s, p, o, m->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_idx, o.idx, OR * S * 4, hipMemcpyDeviceToHost, m->stream));
