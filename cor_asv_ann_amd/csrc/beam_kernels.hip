@@ -139,11 +139,38 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))
             rej = s.src_rej[line * T + srcpos];           // -1: input row all zero (np.any false)
         float vals[VPL];
         bool anynan = false;
+        if (s.logits) {
+            // the row's softmax (decode_kernels.hip softmax_kernel: per-lane partial results over v = lane, lane + 64, ... in
+            // ascending order, the same butterflies, expf(x - m) / sum), written to the score store and kept in registers
+            const float* x = s.logits + (long long)r * Vp;
+            float m = -INFINITY, nn = 0.0f;
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) {
-            const int v = lane + 64 * k;
-            vals[k] = v < V ? sc[v] : -INFINITY;
-            if (v < V && vals[k] != vals[k]) anynan = true;
+            for (int k = 0; k < VPL; ++k) {
+                const int v = lane + 64 * k;
+                vals[k] = v < V ? x[v] : 0.0f;
+                if (v < V) { m = fmaxf(m, vals[k]); nn += (vals[k] != vals[k]) ? 1.0f : 0.0f; }
+            }
+            m = wave_butterfly(m, [](float a, float b) { return fmaxf(a, b); });
+            if (wave_butterfly(nn, [](float a, float b) { return a + b; }) > 0.0f) m = __builtin_nanf("");
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) if (lane + 64 * k < V) sum += expf(vals[k] - m);
+            sum = wave_butterfly(sum, [](float a, float b) { return a + b; });
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const int v = lane + 64 * k;
+                const float pv = v < V ? expf(vals[k] - m) / sum : 0.0f;
+                if (v < Vp) sc[v] = pv;                      // columns V..Vp-1: exact zeros (K padding of the next step's GEMM)
+                vals[k] = v < V ? pv : -INFINITY;
+                if (v < V && pv != pv) anynan = true;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const int v = lane + 64 * k;
+                vals[k] = v < V ? sc[v] : -INFINITY;
+                if (v < V && vals[k] != vals[k]) anynan = true;
+            }
         }
         anynan = __any(anynan);
         if (rej >= 0) {

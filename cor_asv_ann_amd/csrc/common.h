@@ -220,6 +220,8 @@ struct BeamState {
     int* prev;                  // [R]
     float* p_in;                // [R][V]
     const float* p_base;        // score store
+    const float* logits;        // [R][Vp] of this step: the kernel turns them into the step's row of the score store itself
+                                // (the arithmetic of softmax_kernel); nullptr: a softmax launch has done that already
     const double* apos; const int* amax1;
     const int* src_rej;         // [B][T]
     const int* step_ptr;        // step number in device memory (graph replay), or nullptr: step_imm

@@ -491,7 +491,7 @@ static int init_root(casv_model* m, int rows_per_line) {
 // One decoder_model step on R rows (seq2seq.py:416-480).  beam=true reads the input rows from `pin`,
 // otherwise from the previous slot of the score store (the fed-back softmax, seq2seq.py:1252).
 static void launch_step(casv_model* m, bool beam, int mode, const int* line, int rows_per_line,
-                        int* o_idx, float* o_prob, const int* step_ptr, int step_imm) {
+                        int* o_idx, float* o_prob, const int* step_ptr, int step_imm, bool softmax = true) {
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
     const long long RW = (long long)R * W;
     // previous-step rows of the state stores: the beam gathers its parents' expansions through `prev`; without a beam
@@ -578,7 +578,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.nact = live; g.nact_group = m->skip_group;
         run_gemm(m, EPI_PLAIN, g);
     }
-    {
+    if (softmax) {       // (the beam step kernel computes the rows it reads itself)
         SoftmaxArgs a{};
         a.logits = m->logits.as<float>(); a.p_base = m->st_p.as<float>(); a.R = R; a.V = V;
         a.step_ptr = step_ptr; a.step_imm = step_imm; a.mode = mode; a.out_idx = o_idx; a.out_prob = o_prob; a.S = m->S;
@@ -898,11 +898,11 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     m->skip_nact = (N >= 128 && !m->use_graph) ? m->b_nact.as<int>() : nullptr; m->skip_group = N;
     launch_beam_init(s, p, m->stream);
     auto body = [&](const int* step_ptr, int step_imm) {
-        launch_step(m, true, -1, nullptr, N, nullptr, nullptr, step_ptr, step_imm);
+        launch_step(m, true, -1, nullptr, N, nullptr, nullptr, step_ptr, step_imm, false);
         hipEvent_t ev{};
         m->prof_begin(PC_BEAM, 0.0, 4.0 * R * (2.0 * m->Vp), ev);
         BeamState sb = s;
-        sb.step_ptr = step_ptr; sb.step_imm = step_imm;
+        sb.step_ptr = step_ptr; sb.step_imm = step_imm; sb.logits = m->logits.as<float>();
         launch_beam_step(sb, p, m->stream);
         m->prof_end(PC_BEAM, ev);
     };
