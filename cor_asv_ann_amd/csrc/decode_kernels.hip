@@ -8,14 +8,18 @@
 
 namespace casv {
 
-__global__ __launch_bounds__(64 * ATT_ROWS) void attention_kernel(const AttnArgs a) {
+// The window rows are requested in two batches of 6: 75 registers instead of 111, six waves per SIMD instead of four -- the
+// kernel is bound by its chain of dependent memory latencies, so rows in flight count for more than the round trip the second
+// batch adds (c3: 8.4 -> 7.9 ms per batch; batches of 4, 3, 2 with up to eight waves: 8.5, 9.4, 8.6 ms).
+constexpr int ATT_WB = 6;
+__global__ __launch_bounds__(64 * ATT_ROWS) __attribute__((amdgpu_waves_per_eu(6, 6))) void attention_kernel(const AttnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * ATT_ROWS + wave;
     const int nrows = a.nrows ? *a.nrows : a.R;
     if (r >= nrows) return;
     if (a.nact && r % a.nact_group >= a.nact[r / a.nact_group]) return;
     const int step = a.step_ptr ? *a.step_ptr : a.step_imm;
-    attention_row<false>(a, r, step, lane);
+    attention_row<false, ATT_WB>(a, r, step, lane);
 }
 
 void launch_attention(const AttnArgs& a, hipStream_t stream) {

@@ -66,7 +66,9 @@ __device__ __forceinline__ AttWin att_window(const AttnArgs& a, const int r, con
 // (2) energies exp(tanh(wq + u[s]) . v_a + b_v) over the window, normalised; writes the alignment row and the per-row
 // by-products.  urow(s) -> the row u[line][s] as float4s (global memory, or the workgroup's staged copy).
 // HANDOFF: the query row was written by another workgroup of the same launch (read past the L2).
-template <bool HANDOFF, class URow>
+// WB = window rows requested together (MAXWIN: all of them, fewest round trips; less: fewer registers, more waves per SIMD).
+// The sums per window position are independent of one another: the same values either way.
+template <bool HANDOFF, int WB, class URow>
 __device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, const int step, const int lane, const AttWin w,
                                             URow urow, float (&e)[MAXWIN]) {
     const int T = a.T, W = a.W;
@@ -80,18 +82,22 @@ __device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, cons
     // together: loads are unconditional on clamped row indices, positions past the window get weight 0.
 #pragma unroll
     for (int i = 0; i < MAXWIN; ++i) e[i] = 0.0f;
-    for (int j = lane; j < W4; j += 64) {
-        float4 uu[MAXWIN];
 #pragma unroll
-        for (int i = 0; i < MAXWIN; ++i) uu[i] = urow(s_lo + i)[j];
-        const float4 q = HANDOFF ? load_sc1(reinterpret_cast<const float*>(wq4 + j)) : wq4[j], v = va4[j];
+    for (int i0 = 0; i0 < MAXWIN; i0 += WB) {
+        for (int j = lane; j < W4; j += 64) {
+            const float4 q = HANDOFF ? load_sc1(reinterpret_cast<const float*>(wq4 + j)) : wq4[j], v = va4[j];
+            float4 uu[WB];
 #pragma unroll
-        for (int i = 0; i < MAXWIN; ++i) {
-            e[i] += fast_tanh(q.x + uu[i].x) * v.x;
-            e[i] += fast_tanh(q.y + uu[i].y) * v.y;
-            e[i] += fast_tanh(q.z + uu[i].z) * v.z;
-            e[i] += fast_tanh(q.w + uu[i].w) * v.w;
+            for (int i = 0; i < WB; ++i) if (i0 + i < MAXWIN) uu[i] = urow(s_lo + i0 + i)[j];
+#pragma unroll
+            for (int i = 0; i < WB; ++i) if (i0 + i < MAXWIN) {
+                e[i0 + i] += fast_tanh(q.x + uu[i].x) * v.x;
+                e[i0 + i] += fast_tanh(q.y + uu[i].y) * v.y;
+                e[i0 + i] += fast_tanh(q.z + uu[i].z) * v.z;
+                e[i0 + i] += fast_tanh(q.w + uu[i].w) * v.w;
+            }
         }
+        if (WB < MAXWIN) __builtin_amdgcn_sched_barrier(0);            // keep the batches apart: that is where the registers go
     }
     float denom = 0.0f;
 #pragma unroll
@@ -129,7 +135,7 @@ __device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, cons
 
 // (3) context = sum_s a'[s] * enc[s].  erow(s) -> the row enc[line][s] as float4s.  HANDOFF: the context vector goes out
 // with write-through stores (another workgroup of the same launch consumes it).
-template <bool HANDOFF, class ERow>
+template <bool HANDOFF, int WB, class ERow>
 __device__ __forceinline__ void att_context(const AttnArgs& a, const int r, const int lane, const AttWin w, ERow erow,
                                             const float (&e)[MAXWIN]) {
     const int C = a.C, s_lo = w.s_lo, cnt = w.cnt;
@@ -137,13 +143,17 @@ __device__ __forceinline__ void att_context(const AttnArgs& a, const int r, cons
     float4* ctx4 = reinterpret_cast<float4*>(a.ctx + (long long)r * C);
     const int C4 = C >> 2;
     for (int c = lane; c < C4; c += 64) {
-        float4 x[MAXWIN];
-#pragma unroll
-        for (int i = 0; i < MAXWIN; ++i) x[i] = erow(s_lo + i)[c];
         float4 v = cnt <= 0 ? make_float4(nanv, nanv, nanv, nanv) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < MAXWIN; ++i)
-            if (i < cnt) { v.x += e[i] * x[i].x; v.y += e[i] * x[i].y; v.z += e[i] * x[i].z; v.w += e[i] * x[i].w; }
+        for (int i0 = 0; i0 < MAXWIN; i0 += WB) {
+            float4 x[WB];
+#pragma unroll
+            for (int i = 0; i < WB; ++i) if (i0 + i < MAXWIN) x[i] = erow(s_lo + i0 + i)[c];
+#pragma unroll
+            for (int i = 0; i < WB; ++i)
+                if (i0 + i < MAXWIN && i0 + i < cnt) { v.x += e[i0 + i] * x[i].x; v.y += e[i0 + i] * x[i].y; v.z += e[i0 + i] * x[i].z; v.w += e[i0 + i] * x[i].w; }
+            if (WB < MAXWIN) __builtin_amdgcn_sched_barrier(0);
+        }
         if (HANDOFF) {
             float* dst = reinterpret_cast<float*>(ctx4 + c);
             store_sc1(dst, v.x); store_sc1(dst + 1, v.y); store_sc1(dst + 2, v.z); store_sc1(dst + 3, v.w);
@@ -153,7 +163,7 @@ __device__ __forceinline__ void att_context(const AttnArgs& a, const int r, cons
     }
 }
 
-template <bool HANDOFF>
+template <bool HANDOFF, int WB = MAXWIN>
 __device__ __forceinline__ void attention_row(const AttnArgs& a, const int r, const int step, const int lane) {
     const int ln = a.line ? a.line[r] : r / a.rows_per_line;
     const int T = a.T;
@@ -161,8 +171,8 @@ __device__ __forceinline__ void attention_row(const AttnArgs& a, const int r, co
     const float* ub = a.u + (long long)ln * a.u_line;
     const float* eb = a.enc + (long long)ln * a.enc_line;
     float e[MAXWIN];
-    att_weights<HANDOFF>(a, r, step, lane, w, [&](int s) { s = s < T ? s : T - 1; return reinterpret_cast<const float4*>(ub + (long long)s * a.u_time); }, e);
-    att_context<HANDOFF>(a, r, lane, w, [&](int s) { s = s < T ? s : T - 1; return reinterpret_cast<const float4*>(eb + (long long)s * a.enc_time); }, e);
+    att_weights<HANDOFF, WB>(a, r, step, lane, w, [&](int s) { s = s < T ? s : T - 1; return reinterpret_cast<const float4*>(ub + (long long)s * a.u_time); }, e);
+    att_context<HANDOFF, WB>(a, r, lane, w, [&](int s) { s = s < T ? s : T - 1; return reinterpret_cast<const float4*>(eb + (long long)s * a.enc_time); }, e);
 }
 
 }  // namespace casv
