@@ -99,6 +99,9 @@ struct casv_model {
     DevBuf WaP, EP;                                       // query / output projection in the persistent decoder's K order
     DevBuf p_ctx, p_wq, p_logits, p_counters;             // persistent decoder: slot-indexed hand-off buffers, counters
     int persist_mode = -1;                                // -1 by size, 0 never, 1 always (greedy decode of small batches)
+    DevBuf chain_counters; int chain_set = 0; bool chain_used = false;   // layers 2..D of a large step in one launch (gemm_chain_kernel)
+    int chain_mode = 0;                                   // 0 one launch per layer (default: measured faster), 1 whenever the shapes fit
+    long long stat_chained = 0;                           // chained launches of the last beamed decode
     int ncu = 0;
     LstmW enc_fw, enc_bw;
     std::vector<LstmW> enc, dec;                         // enc[n] for layer n>=2 at index n; dec[n] n=1..D

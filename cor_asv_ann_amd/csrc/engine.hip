@@ -74,7 +74,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     for (auto& l : m->enc) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
     for (LstmW* l : {&m->enc_fw, &m->enc_bw}) { l->pw.release(); l->pbias.release(); }
     for (auto& l : m->dec) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
-    for (DevBuf* b : {&m->WaP, &m->EP, &m->p_ctx, &m->p_wq, &m->p_logits, &m->p_counters}) b->release();
+    for (DevBuf* b : {&m->WaP, &m->EP, &m->p_ctx, &m->p_wq, &m->p_logits, &m->p_counters, &m->chain_counters}) b->release();
     for (auto& b : m->st_h) b.release();
     for (auto& b : m->st_c) b.release();
     (void)casv_train_release(m);
@@ -491,7 +491,7 @@ static int init_root(casv_model* m, int rows_per_line) {
 // One decoder_model step on R rows (seq2seq.py:416-480).  beam=true reads the input rows from `pin`,
 // otherwise from the previous slot of the score store (the fed-back softmax, seq2seq.py:1252).
 static void launch_step(casv_model* m, bool beam, int mode, const int* line, int rows_per_line,
-                        int* o_idx, float* o_prob, const int* step_ptr, int step_imm, bool softmax = true) {
+                        int* o_idx, float* o_prob, const int* step_ptr, int step_imm, bool softmax = true, bool chain = false) {
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
     const long long RW = (long long)R * W;
     // previous-step rows of the state stores: the beam gathers its parents' expansions through `prev`; without a beam
@@ -518,7 +518,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
     gq.out = mkslot(m->wq.as<float>(), W);
     gq.step_ptr = step_ptr; gq.step_imm = step_imm;
     gq.nact = live; gq.nact_group = m->skip_group;
-    for (int n = 1; n < D; ++n) {
+    auto lower = [&](int n) {               // layer n < D on [x | h]
         GemmArgs g{};
         g.nseg = 2;
         g.a[0] = xseg(n);
@@ -530,16 +530,16 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.c_out = mkslot(m->st_c[n].as<float>(), W, RW, 1, 1);
         g.step_ptr = step_ptr; g.step_imm = step_imm;
         g.nact = live; g.nact_group = m->skip_group;
-        if (n == 1) {
-            GemmBatch b{};
-            b.g[0] = g; b.g[1] = gq; b.g[1].epi_plain = 1; b.count = 2;
-            run_gemm_batch(m, EPI_LSTM, b);
-        } else {
-            run_gemm(m, EPI_LSTM, g);
-        }
+        return g;
+    };
+    if (D >= 2) {
+        GemmBatch b{};
+        b.g[0] = lower(1); b.g[1] = gq; b.g[1].epi_plain = 1; b.count = 2;
+        run_gemm_batch(m, EPI_LSTM, b);
+    } else {
+        run_gemm(m, EPI_PLAIN, gq);
     }
-    if (D == 1) run_gemm(m, EPI_PLAIN, gq);
-    {
+    {   // the attention rows need only the query: ahead of the remaining layers, which can then share one launch
         AttnArgs a{};
         a.wq = m->wq.as<float>(); a.u = m->u.as<float>(); a.enc = m->enc_out; a.va = m->va.as<float>(); a.bv = m->bv.as<float>();
         a.a_base = m->st_a.as<float>(); a.prev = prev; a.line = line; a.rows_per_line = rows_per_line;
@@ -554,8 +554,9 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         launch_attention(a, m->stream);
         m->prof_end(PC_ATTN, ev);
     }
+    GemmArgs gtop{};
     {   // top cell on [x | ctx] (attention.py:341-342, seq2seq.py:343-349)
-        GemmArgs g{};
+        GemmArgs& g = gtop;
         g.nseg = 3;
         g.a[0] = xseg(D);
         g.a[1] = mkseg(m->ctx.as<float>(), C, C, xwidth(D));
@@ -567,7 +568,31 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.c_out = mkslot(m->st_c[D].as<float>(), W, RW, 1, 1);
         g.step_ptr = step_ptr; g.step_imm = step_imm;
         g.nact = live; g.nact_group = m->skip_group;
-        run_gemm(m, EPI_LSTM, g);
+    }
+    // Option "chain": layers 2..D as ONE launch whose tiles wait for the row block of the layer below instead of for the whole
+    // chip (gemm_chain_kernel).  Eager launches only; a launch whose shapes do not fit is made layer by layer.  Off by
+    // default: at c3 it measured 4 ms per batch SLOWER than the three launches it replaces.
+    bool chained = false;
+    if (chain && D >= 3 && D - 1 <= GEMM_MAX_JOBS && !step_ptr && !live && m->chain_mode == 1 && m->chain_counters.p) {
+        GemmBatch b{};
+        for (int n = 2; n < D; ++n) b.g[n - 2] = lower(n);
+        b.g[D - 2] = gtop; b.count = D - 1;
+        if (gemm_chain_fits(b)) {
+            hipEvent_t ev{};
+            double fl = 0, by = 0;
+            for (int j = 0; j < b.count; ++j) {
+                const double k = b.g[j].Ktot;
+                fl += 2.0 * R * 4.0 * W * k; by += 4.0 * ((double)R * k + 4.0 * W * k + (double)R * 4.0 * W);
+            }
+            m->prof_begin(PC_LSTM, fl, by, ev);
+            chained = launch_gemm_chain(b, m->chain_counters.as<unsigned>(), m->chain_set, m->ncu, m->stream);
+            m->prof_end(PC_LSTM, ev);
+            m->chain_set ^= 1; m->chain_used = true; ++m->stat_chained;
+        }
+    }
+    if (!chained) {
+        for (int n = 2; n < D; ++n) { GemmArgs g = lower(n); run_gemm(m, EPI_LSTM, g); }
+        run_gemm(m, EPI_LSTM, gtop);
     }
     {   // tied output projection (seq2seq.py:379)
         GemmArgs g{};
@@ -897,8 +922,13 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     // steps), otherwise once a line has finished; not under graph replay, whose kernel arguments are fixed at capture.
     m->skip_nact = (N >= 128 && !m->use_graph) ? m->b_nact.as<int>() : nullptr; m->skip_group = N;
     launch_beam_init(s, p, m->stream);
+    if (m->chain_mode != 0) {               // counters of the chained-layers launches (launch_step), all zero at the start
+        if (int rc = m->chain_counters.ensure(gemm_chain_counter_bytes())) return rc;
+        HIPCHK(hipMemsetAsync(m->chain_counters.p, 0, gemm_chain_counter_bytes(), m->stream));
+        m->chain_set = 0; m->chain_used = false; m->stat_chained = 0;
+    }
     auto body = [&](const int* step_ptr, int step_imm) {
-        launch_step(m, true, -1, nullptr, N, nullptr, nullptr, step_ptr, step_imm, false);
+        launch_step(m, true, -1, nullptr, N, nullptr, nullptr, step_ptr, step_imm, false, true);
         hipEvent_t ev{};
         m->prof_begin(PC_BEAM, 0.0, 4.0 * R * (2.0 * m->Vp), ev);
         BeamState sb = s;
@@ -936,6 +966,17 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
         pending = slot; slot ^= 1;
     }
     m->skip_nact = nullptr; m->skip_group = 0;
+    if (m->chain_used) {                    // did a chained-layers launch give up waiting?  then nothing above is valid
+        unsigned aborted = 0;
+        HIPCHK(hipMemcpyAsync(&aborted, m->chain_counters.as<unsigned>() + 2 * CHAIN_SET_WORDS, 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        m->chain_used = false;
+        if (aborted) {
+            fprintf(stderr, "cor_asv_ann_hip: a chained-layers launch gave up waiting (GPU partitioned or shared?); decoding again layer by layer\n");
+            m->chain_mode = 0;
+            return casv_decode_beam(m, bp, S, out_idx, out_prob, out_len, out_score, out_rej, out_align, n_found, n_steps);
+        }
+    }
     BeamOut o{};
     o.idx = m->bo_idx.as<int>(); o.prob = m->bo_prob.as<float>(); o.len = m->bo_len.as<int>(); o.score = m->bo_score.as<double>();
     o.rejpos = m->bo_rej.as<int>(); o.align = out_align ? m->bo_align.as<float>() : nullptr; o.n_found = m->bo_found.as<int>();
@@ -992,6 +1033,7 @@ extern "C" int casv_get_stat(casv_model* m, const char* key, int64_t* value) {
     if (!m || !key || !value) return fail(CASV_ERR_ARG, "null argument");
     if (!strcmp(key, "beam_max_new_keys")) { *value = m->stat_beam[0]; return CASV_OK; }
     if (!strcmp(key, "beam_sort_capacity")) { *value = 4096; return CASV_OK; }
+    if (!strcmp(key, "chained_launches")) { *value = m->stat_chained; return CASV_OK; }
     return fail(CASV_ERR_ARG, "unknown statistic '%s'", key);
 }
 
@@ -1070,6 +1112,10 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
     if (!strcmp(key, "persistent")) {
         if (value < -1 || value > 1) return fail(CASV_ERR_ARG, "persistent must be -1 (by batch size), 0 (per-step kernels) or 1 (always)");
         m->persist_mode = (int)value; return CASV_OK;
+    }
+    if (!strcmp(key, "chain")) {
+        if (value < 0 || value > 1) return fail(CASV_ERR_ARG, "chain must be 0 (one launch per layer) or 1 (one launch for layers 2..depth whenever the shapes fit)");
+        m->chain_mode = (int)value; return CASV_OK;
     }
     if (!strcmp(key, "eos")) {
         if (value < 0 || value >= m->V) return fail(CASV_ERR_ARG, "eos index %lld outside the vocabulary", (long long)value);
