@@ -451,7 +451,7 @@ static int count_ktiles(const GemmArgs& g) {
 }
 
 // Tile shape and split-K factor of a launch.  Launches that would occupy at most half the CUs as 128x128 tiles (even
-// after split-K) run as 32x128 tiles: 4x the workgroups, same values.
+// after split-K) run as 32x128 tiles: 4x the workgroups, same values ...
 struct GemmPlan { int blocks, sblocks, ksplit; bool skinny; };
 static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
     GemmPlan p{0, 0, 1, false};
@@ -477,7 +477,12 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
         return ks < 1 ? 1 : ks;
     };
     p.ksplit = choose_ksplit(p.blocks * b.count, 512);
-    p.skinny = g_tile_mode == 1 || (g_tile_mode < 0 && p.blocks * b.count * p.ksplit <= 128);
+    // ... and so do launches of more than one but less than two 128x128 tiles per CU: half the CUs would carry two workgroups
+    // and set the pace while the others idle (the encoder's anti-diagonals of three layers at 1024 lines: 384 tiles, 168 us;
+    // as 1536 tiles of 32x128: 140 us)
+    static const int ncu = [] { hipDeviceProp_t pr{}; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+    const int grid = p.blocks * b.count * p.ksplit;
+    p.skinny = g_tile_mode == 1 || (g_tile_mode < 0 && (grid <= 128 || (grid > ncu && grid < 2 * ncu)));
     if (p.skinny) p.ksplit = choose_ksplit(p.sblocks * b.count, 1024);
     return p;
 }
