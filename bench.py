@@ -391,8 +391,8 @@ def decode_bench(args):
             achieved = prof['flops'] / max(prof['ms'], 1e-9) / 1e9            # TFLOP/s
             traffic = None
             try:
-                with open(os.path.join(ROOT, 'profiles', 'lstm_gemm_traffic.json')) as f:
-                    traffic = json.load(f).get('hbm_bytes_per_launch') if args.workload != 'c2' else None
+                with open(os.path.join(ROOT, 'profiles', 'persist_decode_traffic.json' if dom == 'persist' else 'lstm_gemm_traffic.json')) as f:
+                    traffic = json.load(f).get('hbm_bytes_per_launch')
             except Exception:
                 pass
             result['roofline'] = {
