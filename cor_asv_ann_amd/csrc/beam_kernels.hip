@@ -82,7 +82,7 @@ void beam_prof_dump(int steps) {
 
 // VPL = vocabulary entries per lane (V <= 64 * VPL); NWV = waves per workgroup (one wave expands one hypothesis row)
 template <int VPL, int NWV>
-__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))) void beam_step_kernel(const BeamState s, const BeamParams p) {
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <= 4 ? 8 : 1, 8))) void beam_step_kernel(const BeamState s, const BeamParams p) {
     constexpr int NT = 64 * NWV;
     // dynamic LDS: [sort_cap new keys (f64)] [q_stage old keys (f64)] [sort_cap new ids] [q_stage old ids] [7 x (N+1) row records]
     extern __shared__ __attribute__((aligned(16))) unsigned char beam_smem[];
