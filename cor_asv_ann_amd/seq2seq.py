@@ -462,16 +462,22 @@ class Sequence2Sequence(object):
         texts, keep = self._texts(idx, n)
         with np.errstate(divide='ignore', invalid='ignore'):
             cost = np.where(keep, -np.log(prob), 0).sum(axis=1, dtype=np.float64) / np.maximum(n, 1)
+        # probability lists: ONE conversion for the whole batch, then list slices
+        flat = prob[keep].tolist()
+        ends = np.cumsum(n).tolist()
+        costs = cost.tolist()
         lines, probs, scores, aligns = [], [], [], []
+        start = 0
         for j in range(B):
+            end = ends[j]
             if not nonpad[j]:
                 lines.append(''); probs.append([]); scores.append(0.); aligns.append([])
-                continue
-            lines.append(texts[j])
-            nj = int(n[j])
-            probs.append(prob[j, :nj].tolist())
-            scores.append(float(cost[j]))
-            aligns.append(self._alignment_rows(align, j, nj))
+            else:
+                lines.append(texts[j])
+                probs.append(flat[start:end])
+                scores.append(costs[j])
+                aligns.append(self._alignment_rows(align, j, end - start))
+            start = end
         return lines, probs, scores, aligns
 
     def _alignment_rows(self, align, j, n):
@@ -616,13 +622,16 @@ class Sequence2Sequence(object):
             rows = live[lo:lo + chunk]
             eng.encode(idx[rows], val[rows])
             res = eng.decode_beam(max_results=1, want_align=want_align, **self._beam_kwargs())
-            texts, _ = self._texts(res['idx'], res['len'])          # best result of every line of the chunk, in one go
+            texts, keep = self._texts(res['idx'], res['len'])       # best result of every line of the chunk, in one go
+            flat = res['prob'][keep].tolist()                       # likewise the probability lists: one conversion, then slices
+            ends = np.cumsum(res['len']).tolist()
+            lens, scores_ = res['len'].tolist(), res['score'].tolist()
             for k, j in enumerate(rows):
                 input_line = lines[j]
-                n = int(res['len'][k])
+                n = lens[k]
                 item = None
                 if n:
-                    item = (texts[k], res['prob'][k, :n].tolist(), float(res['score'][k]),
+                    item = (texts[k], flat[ends[k] - n:ends[k]], scores_[k],
                             self._alignment_rows(res.get('align_sparse', res['align']), k, n))
                 if item is None:
                     # the generator of the reference raises StopIteration here (seq2seq.py:826-836)
