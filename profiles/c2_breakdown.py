@@ -1,3 +1,6 @@
+"""Where a c2 batch (BASELINE configs[1]: 256 lines, depth 2, width 256, greedy) spends its wall time: host stages of
+correct_lines(fast=True) timed around the engine calls.  With a library built with EXTRA=-DCASV_PERSIST_PROF the persistent
+decoder also prints its per-step phase times (and, with CASV_PERSIST_PLACEMENT=1, which roles share a CU)."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 from bench import make_model
