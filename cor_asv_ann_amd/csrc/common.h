@@ -281,6 +281,7 @@ struct PersistEncArgs {
     PersistLayer ln[7];            // layers 2..D
     const float* x0; float* H1; float* Hn[7]; float* cfin;
     unsigned* counters;            // persist_enc_counter_bytes(); zeroed ahead of the launch
+    unsigned long long* prof;      // diagnostic build only (CASV_PERSIST_PROF): tick sums of workgroup 0, see persist.hip
 };
 size_t persist_enc_counter_bytes(int B, int D);
 int launch_persist_encode(const PersistEncArgs& pa, int grid, hipStream_t stream);

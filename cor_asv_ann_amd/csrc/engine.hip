@@ -320,6 +320,12 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         const int nrb = (B + 15) / 16, ntile = nrb * (W / 16);
         const int per_cu = std::min(2, (int)((160 * 1024) / ((size_t)16 * pa.lda * 4 + 6 * 1024)));      // all workgroups resident at once
         const int grid = std::min(std::max(2, D - 1) * ntile, std::max(per_cu, 1) * m->ncu);
+#ifdef CASV_PERSIST_PROF
+        static DevBuf eprof;
+        if (int rc = eprof.ensure(32 * 8)) return rc;
+        HIPCHK(hipMemsetAsync(eprof.p, 0, 32 * 8, m->stream));
+        pa.prof = eprof.as<unsigned long long>();
+#endif
         hipEvent_t pev{};
         m->prof_begin(PC_PERSIST, 2.0 * BT * 4.0 * W * (2.0 * 2 * W + (D >= 2 ? 3.0 * W : 0.0) + (D >= 3 ? (D - 2) * 2.0 * W : 0.0)), 0.0, pev);
         if (launch_persist_encode(pa, grid, m->stream)) return fail(CASV_ERR_ARG, "persistent encoder: rows do not fit the LDS");
@@ -328,6 +334,15 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         unsigned aborted = 0;
         HIPCHK(hipMemcpyAsync(&aborted, m->p_counters.as<unsigned>() + (size_t)nrb * (D + 1) * 32, 4, hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
+#ifdef CASV_PERSIST_PROF
+        {
+            unsigned long long h[32];
+            HIPCHK(hipMemcpy(h, eprof.p, sizeof h, hipMemcpyDeviceToHost));
+            fprintf(stderr, "persist enc prof (workgroup 0) us/step: phase A wait %.2f stage %.2f kloop %.2f cell %.2f publish %.2f | phase B %.2f %.2f %.2f %.2f %.2f | totals A %.1f us, B %.1f us\n",
+                    h[0] * 0.01 / T, h[1] * 0.01 / T, h[2] * 0.01 / T, h[3] * 0.01 / T, h[4] * 0.01 / T,
+                    h[8] * 0.01 / T, h[9] * 0.01 / T, h[10] * 0.01 / T, h[11] * 0.01 / T, h[12] * 0.01 / T, h[16] * 0.01, h[17] * 0.01);
+        }
+#endif
         if (aborted) {
             static bool told = false;
             if (!told) { fprintf(stderr, "cor_asv_ann_hip: persistent encoder gave up waiting (GPU shared with another persistent kernel?); using the per-step kernels\n"); told = true; }

@@ -38,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // in each part of its tasks to pa.prof[role * 8 + part].
 #ifdef CASV_PERSIST_PROF
 #define PROF_T(var) const unsigned long long var = wall_clock64()
-#define PROF_ADD(slot, t1, t0) do { if (threadIdx.x == 0 && prof_on) atomicAdd(pa.prof + (slot), (unsigned long long)((t1) - (t0))); } while (0)
+#define PROF_ADD(slot, t1, t0) do { if (threadIdx.x == 0 && prof_on) atomicAdd(const_cast<unsigned long long*>(pa.prof) + (slot), (unsigned long long)((t1) - (t0))); } while (0)
 #else
 #define PROF_T(var)
 #define PROF_ADD(slot, t1, t0)
@@ -514,6 +514,11 @@ __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEnc
     const int g = blockIdx.x, G = gridDim.x;
     const int kg4 = 4 * (lane >> 4);
     const int er = tid >> 4, ec = tid & 15;                        // this thread's (row, unit) of a tile in the cell epilogue
+#ifdef CASV_PERSIST_PROF
+    const bool prof_on = pa.prof && g == 0;
+    int pslot = 0;                                                 // 0..4 phase A, 8..12 phase B (wait, stage, K loop, cell, publish)
+    const unsigned long long tk0 = wall_clock64();
+#endif
 
     // One cell: tile (kind, rb, ug) at time t, the `nth` step of its recurrence.  x rows: xbase + row * xld (width kx);
     // h rows of the previous step: hprev + row * hld.  Output h -> hout + row * hld (+ unit).
@@ -523,10 +528,15 @@ __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEnc
         const float* b = L.w + ((long long)((ug * 4 + wave) * 16 + (lane & 15))) * L.Kt + kg4;
         BRing ring;
         ring_start(ring, b, 0, nt);
+        PROF_T(t0);
         if (!wait_deps(dx, dh, d3, abort_w, &s_ok)) return false;
+        PROF_T(t1);
         stage_rows(s_a, lda, 0, RowSeg{xbase, (int)xld, kx}, RowSeg{hprev, (int)hld, first ? 0 : W}, RowSeg{nullptr, 0, 0}, rb, B, tid);
         __syncthreads();
+        PROF_T(t2);
         const f32x4 acc = k_loop(s_a, lda, b, ring, 0, nt, lane);
+        PROF_T(t3);
+        PROF_ADD(pslot + 0, t1, t0); PROF_ADD(pslot + 1, t2, t1); PROF_ADD(pslot + 2, t3, t2);
 #pragma unroll
         for (int q = 0; q < 4; ++q) s_gate[wave][((lane >> 4) * 4 + q) * 16 + (lane & 15)] = acc[q];
         __syncthreads();
@@ -536,7 +546,10 @@ __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEnc
         creg = c.c;
         const int row = rb * 16 + er;
         if (row < B) store_sc1(hout + (long long)row * hld + ug * 16 + ec, c.h);
+        PROF_T(t4);
         publish(done);
+        PROF_T(t5);
+        PROF_ADD(pslot + 3, t4, t3); PROF_ADD(pslot + 4, t5, t4);
         return true;
     };
 
@@ -564,6 +577,11 @@ __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEnc
             }
         }
     }
+#ifdef CASV_PERSIST_PROF
+    pslot = 8;
+    if (prof_on && tid == 0) atomicAdd(const_cast<unsigned long long*>(pa.prof) + 16, wall_clock64() - tk0);     // phase A in all
+    const unsigned long long tk1 = wall_clock64();
+#endif
     // ---- phase B: layers 2..D along anti-diagonals
     if (D >= 2) {
         float creg[PENC_MAXT];
@@ -594,6 +612,9 @@ __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEnc
             }
         }
     }
+#ifdef CASV_PERSIST_PROF
+    if (prof_on && tid == 0) atomicAdd(const_cast<unsigned long long*>(pa.prof) + 17, wall_clock64() - tk1);
+#endif
 }
 
 size_t persist_enc_counter_bytes(int B, int D) {
