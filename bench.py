@@ -290,7 +290,7 @@ def decode_bench(args):
         eng = s2s._require_engine()
         if args.graph:
             eng.set_option('graph', 1)
-        for opt in ('persistent', 'tile', 'chain'):      # A/B switches for experiments: CASV_OPT_<NAME>=value
+        for opt in ('persistent', 'tile', 'attn_ahead'):      # A/B switches for experiments: CASV_OPT_<NAME>=value
             if os.environ.get('CASV_OPT_' + opt.upper()):
                 eng.set_option(opt, int(os.environ['CASV_OPT_' + opt.upper()]))
         lut = s2s._codepoint_lut()

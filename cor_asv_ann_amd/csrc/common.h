@@ -130,15 +130,6 @@ struct GemmBatch {
     int count;
 };
 
-// gemm_chain_kernel (gemm.hip): counters of one launch = CHAIN_SET_WORDS unsigneds, every counter on its own 128-B line:
-// 8 tile queues, GEMM_MAX_JOBS x CHAIN_MAX_NBM dependency counters.
-constexpr int CHAIN_MAX_NBM = 128;
-constexpr int CHAIN_QUEUE = 0, CHAIN_DEPS = 8 * 32;
-constexpr int CHAIN_SET_WORDS = CHAIN_DEPS + GEMM_MAX_JOBS * CHAIN_MAX_NBM * 32;
-struct ChainArgs { unsigned* counters; int set, nbm, nbn, xcd_rows; };
-size_t gemm_chain_counter_bytes();                       // two sets + the abort word (at 2 * CHAIN_SET_WORDS)
-bool gemm_chain_fits(const GemmBatch& b);
-bool launch_gemm_chain(const GemmBatch& b, unsigned* counters, int set, int ncu, hipStream_t stream);
 void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream);
 void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream);
 void launch_gemm_skinny(int epi, const GemmBatch& b, int ksplit, hipStream_t stream);
@@ -284,6 +275,9 @@ struct PersistEncArgs {
     unsigned long long* prof;      // diagnostic build only (CASV_PERSIST_PROF): tick sums of workgroup 0, see persist.hip
 };
 size_t persist_enc_counter_bytes(int B, int D);
+// workgroups per CU the runtime admits for the persistent kernels at a given dynamic-LDS size (capped at 2; 0: none)
+int persist_encode_blocks_per_cu(size_t lds_bytes);
+int persist_decode_blocks_per_cu(size_t lds_bytes);
 int launch_persist_encode(const PersistEncArgs& pa, int grid, hipStream_t stream);
 size_t persist_counter_bytes(int R, int D);
 size_t persist_lds_bytes(const PersistArgs& pa);

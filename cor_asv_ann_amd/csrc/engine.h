@@ -99,9 +99,7 @@ struct casv_model {
     DevBuf WaP, EP;                                       // query / output projection in the persistent decoder's K order
     DevBuf p_ctx, p_wq, p_logits, p_counters;             // persistent decoder: slot-indexed hand-off buffers, counters
     int persist_mode = -1;                                // -1 by size, 0 never, 1 always (greedy decode of small batches)
-    DevBuf chain_counters; int chain_set = 0; bool chain_used = false;   // layers 2..D of a large step in one launch (gemm_chain_kernel)
-    int chain_mode = 0;                                   // 0 one launch per layer (default: measured faster), 1 whenever the shapes fit
-    long long stat_chained = 0;                           // chained launches of the last beamed decode
+    int persist_skip = 0, persist_penalty = 0; bool persist_told = false;   // back-off after a persistent launch gave up waiting
     int ncu = 0;
     LstmW enc_fw, enc_bw;
     std::vector<LstmW> enc, dec;                         // enc[n] for layer n>=2 at index n; dec[n] n=1..D
@@ -117,7 +115,7 @@ struct casv_model {
     DevBuf st_a, st_p, ctx, wq, logits, prev, pin, apos, amax1, d_step, d_line, d_nan;
     DevBuf o_idx, o_prob, o_align, st_win, sp_lo, sp_w;
     // what the last decode call left on the device (casv_get_alignments_sparse): 0 nothing, 1 greedy, 2 beam
-    int last_decode = 0, last_S = 0, last_rows = 0;
+    int last_decode = 0, last_S = 0, last_rows = 0; unsigned long long last_signature = 0;
     BeamState last_beam{}; BeamParams last_beam_params{};
     // beam
     DevBuf b_parent, b_chr, b_prob, b_cum, b_len, b_exp, b_k, b_rejpos, b_pos, b_is1, b_count, b_created;

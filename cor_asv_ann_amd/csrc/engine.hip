@@ -74,7 +74,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     for (auto& l : m->enc) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
     for (LstmW* l : {&m->enc_fw, &m->enc_bw}) { l->pw.release(); l->pbias.release(); }
     for (auto& l : m->dec) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
-    for (DevBuf* b : {&m->WaP, &m->EP, &m->p_ctx, &m->p_wq, &m->p_logits, &m->p_counters, &m->chain_counters}) b->release();
+    for (DevBuf* b : {&m->WaP, &m->EP, &m->p_ctx, &m->p_wq, &m->p_logits, &m->p_counters}) b->release();
     for (auto& b : m->st_h) b.release();
     for (auto& b : m->st_c) b.release();
     (void)casv_train_release(m);
@@ -225,11 +225,27 @@ extern "C" int casv_commit_weights(casv_model* m) {
 // than the chip has, and workgroups that spin on peers which are not resident never make room for them.  (Across processes
 // the bounded spins catch that case: the launch aborts and the caller falls back to the per-step kernels.)
 static std::mutex g_persist_mutex;
+// A persistent launch that gave up waiting (its workgroups were not all resident: the GPU is shared with another process's
+// persistent kernel, or partitioned) costs one bounded wait.  The handle then leaves the persistent path alone for a number
+// of calls that doubles with every further abort, instead of paying that wait on every call.
+static bool persist_backed_off(casv_model* m) {
+    if (m->persist_skip > 0) { --m->persist_skip; return true; }
+    return false;
+}
+static void persist_note_abort(casv_model* m, const char* what) {
+    m->persist_penalty = std::min(m->persist_penalty ? 2 * m->persist_penalty : 16, 1 << 16);
+    m->persist_skip = m->persist_penalty;
+    if (!m->persist_told) {
+        fprintf(stderr, "cor_asv_ann_hip: persistent %s gave up waiting (GPU shared with another persistent kernel?); using the per-step kernels for the next %d calls\n", what, m->persist_skip);
+        m->persist_told = true;
+    }
+}
+// workgroups per CU for the staged rows of `lda` floats, as the runtime admits them for the loaded kernel
+static int persist_enc_lds(const casv_model* m) { return 16 * ((m->D >= 2 ? 3 * m->W : 2 * m->W) + 4) * 4; }
 static bool persist_enc_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0 || m->ncu < 64 || m->D > 8) return false;
     const int W = m->W, D = m->D;
-    if ((size_t)16 * ((D >= 2 ? 3 * W : 2 * W) + 4) * 4 > 150 * 1024) return false;        // staged rows must fit the LDS
-    const int per_cu = std::min(2, (int)((160 * 1024) / ((size_t)16 * ((D >= 2 ? 3 * W : 2 * W) + 4) * 4 + 6 * 1024)));
+    const int per_cu = persist_encode_blocks_per_cu((size_t)persist_enc_lds(m));            // 0: the staged rows do not fit the LDS
     if (per_cu < 1) return false;
     const int ntile = ((B + 15) / 16) * (W / 16), grid = std::min(std::max(2, D - 1) * ntile, per_cu * m->ncu);
     if ((2 * ntile + grid - 1) / grid > 8 || ((D - 1) * ntile + grid - 1) / grid > 8) return false;   // tiles per workgroup (PENC_MAXT)
@@ -302,7 +318,7 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         for (int n = 2; n <= D; ++n) lout[n] = m->Hc.as<float>() + (size_t)(n - 2) * BT * W;
     }
     // Small batches: the whole encoder in one launch of the persistent encoder (persist.hip; same values bit for bit)
-    bool persistent = persist_enc_applies(m, B);
+    bool persistent = persist_enc_applies(m, B) && !persist_backed_off(m);
     if (persistent) {
         std::lock_guard<std::mutex> lock(g_persist_mutex);
         const size_t cbytes = persist_enc_counter_bytes(B, D);
@@ -318,7 +334,7 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         }
         pa.x0 = x0; pa.H1 = H1; pa.cfin = cfin; pa.counters = m->p_counters.as<unsigned>();
         const int nrb = (B + 15) / 16, ntile = nrb * (W / 16);
-        const int per_cu = std::min(2, (int)((160 * 1024) / ((size_t)16 * pa.lda * 4 + 6 * 1024)));      // all workgroups resident at once
+        const int per_cu = persist_encode_blocks_per_cu((size_t)16 * pa.lda * 4);                      // all workgroups resident at once
         const int grid = std::min(std::max(2, D - 1) * ntile, std::max(per_cu, 1) * m->ncu);
 #ifdef CASV_PERSIST_PROF
         static DevBuf eprof;
@@ -343,11 +359,8 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
                     h[8] * 0.01 / T, h[9] * 0.01 / T, h[10] * 0.01 / T, h[11] * 0.01 / T, h[12] * 0.01 / T, h[16] * 0.01, h[17] * 0.01);
         }
 #endif
-        if (aborted) {
-            static bool told = false;
-            if (!told) { fprintf(stderr, "cor_asv_ann_hip: persistent encoder gave up waiting (GPU shared with another persistent kernel?); using the per-step kernels\n"); told = true; }
-            persistent = false;
-        }
+        if (aborted) { persist_note_abort(m, "encoder"); persistent = false; }
+        else m->persist_penalty = 0;
     }
     if (!persistent) {
     for (int t = 0; t < T; ++t) {
@@ -464,6 +477,15 @@ extern "C" int casv_get_encoder_outputs(casv_model* m, float* enc_out, float* st
 }
 
 // ---- decode session ----
+// Identity of the device buffers a finished decode leaves its results in (casv_get_alignments_sparse reads them later through
+// raw pointers kept in last_beam): changes whenever one of them has been reallocated.
+static unsigned long long decode_buffers_signature(const casv_model* m) {
+    unsigned long long h = 1469598103934665603ull;
+    for (const DevBuf* b : {&m->st_a, &m->st_win, &m->b_parent, &m->b_chr, &m->b_prob, &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos,
+                            &m->b_count, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_created})
+        h = (h ^ (unsigned long long)(uintptr_t)b->p) * 1099511628211ull;
+    return h;
+}
 static int ensure_session(casv_model* m, int R, int S) {
     const int W = m->W, Vp = m->Vp, C = m->C, T = m->T, D = m->D;
     const size_t slots = (size_t)(S + 1) * R;
@@ -506,7 +528,7 @@ static int init_root(casv_model* m, int rows_per_line) {
 // One decoder_model step on R rows (seq2seq.py:416-480).  beam=true reads the input rows from `pin`,
 // otherwise from the previous slot of the score store (the fed-back softmax, seq2seq.py:1252).
 static void launch_step(casv_model* m, bool beam, int mode, const int* line, int rows_per_line,
-                        int* o_idx, float* o_prob, const int* step_ptr, int step_imm, bool softmax = true, bool chain = false) {
+                        int* o_idx, float* o_prob, const int* step_ptr, int step_imm, bool softmax = true) {
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
     const long long RW = (long long)R * W;
     // previous-step rows of the state stores: the beam gathers its parents' expansions through `prev`; without a beam
@@ -584,31 +606,8 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.step_ptr = step_ptr; g.step_imm = step_imm;
         g.nact = live; g.nact_group = m->skip_group;
     }
-    // Option "chain": layers 2..D as ONE launch whose tiles wait for the row block of the layer below instead of for the whole
-    // chip (gemm_chain_kernel).  Eager launches only; a launch whose shapes do not fit is made layer by layer.  Off by
-    // default: at c3 it measured 4 ms per batch SLOWER than the three launches it replaces.
-    bool chained = false;
-    if (chain && D >= 3 && D - 1 <= GEMM_MAX_JOBS && !step_ptr && !live && m->chain_mode == 1 && m->chain_counters.p) {
-        GemmBatch b{};
-        for (int n = 2; n < D; ++n) b.g[n - 2] = lower(n);
-        b.g[D - 2] = gtop; b.count = D - 1;
-        if (gemm_chain_fits(b)) {
-            hipEvent_t ev{};
-            double fl = 0, by = 0;
-            for (int j = 0; j < b.count; ++j) {
-                const double k = b.g[j].Ktot;
-                fl += 2.0 * R * 4.0 * W * k; by += 4.0 * ((double)R * k + 4.0 * W * k + (double)R * 4.0 * W);
-            }
-            m->prof_begin(PC_LSTM, fl, by, ev);
-            chained = launch_gemm_chain(b, m->chain_counters.as<unsigned>(), m->chain_set, m->ncu, m->stream);
-            m->prof_end(PC_LSTM, ev);
-            m->chain_set ^= 1; m->chain_used = true; ++m->stat_chained;
-        }
-    }
-    if (!chained) {
-        for (int n = 2; n < D; ++n) { GemmArgs g = lower(n); run_gemm(m, EPI_LSTM, g); }
-        run_gemm(m, EPI_LSTM, gtop);
-    }
+    for (int n = 2; n < D; ++n) { GemmArgs g = lower(n); run_gemm(m, EPI_LSTM, g); }
+    run_gemm(m, EPI_LSTM, gtop);
     {   // tied output projection (seq2seq.py:379)
         GemmArgs g{};
         g.nseg = 1; g.a[0] = mkseg(m->st_h[D].as<float>(), W, W, 0, nullptr, RW, 1, 1);
@@ -640,6 +639,7 @@ extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, 
     for (int r = 0; r < R; ++r) if (line[r] < 0 || line[r] >= m->B) return fail(CASV_ERR_ARG, "line[%d]=%d out of range", r, line[r]);
     HIPCHK(hipSetDevice(m->device));
     const int W = m->W, V = m->V, Vp = m->Vp, T = m->T, D = m->D;
+    m->last_decode = 0;         // the step overwrites slots 0 and 1 of the stores casv_get_alignments_sparse would read
     if (int rc = ensure_session(m, R, 1)) return rc;
     if (int rc = m->d_line.ensure((size_t)R * 4)) return rc;
     HIPCHK(hipMemcpyAsync(m->d_line.p, line, (size_t)R * 4, hipMemcpyHostToDevice, m->stream));
@@ -670,7 +670,12 @@ extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, 
 // captured at the first call, whose kernels read the step from device memory and whose last node advances it.
 struct StepRunner {
     casv_model* m; std::string key;
-    StepRunner(casv_model* m_, const std::string& key_) : m(m_), key(key_ + "/" + std::to_string(g_devbuf_generation)) {}
+    // The captured kernels hold raw pointers.  Reallocations are covered by the buffer generation; the encoder outputs switch
+    // between buffers WITHOUT one (casv_encode: H1 / Ha / Hb / Hc, casv_set_encoder_outputs: Hc; an initial alignment or not),
+    // so their identity is part of the key too.
+    StepRunner(casv_model* m_, const std::string& key_)
+        : m(m_), key(key_ + "/" + std::to_string(g_devbuf_generation) + "/" + std::to_string((unsigned long long)(uintptr_t)m_->enc_out) +
+                     "/" + std::to_string((unsigned long long)(uintptr_t)m_->u.p) + "/" + std::to_string((int)m_->has_a0)) {}
     static void drop(casv_model* m) {
         if (m->step_exec) { (void)hipStreamSynchronize(m->stream); (void)hipGraphExecDestroy(m->step_exec); m->step_exec = nullptr; }
         if (m->step_graph) { (void)hipGraphDestroy(m->step_graph); m->step_graph = nullptr; }
@@ -706,11 +711,11 @@ static bool persist_applies(const casv_model* m, int B) {
     int kmax = m->W;
     for (int n = 1; n <= m->D; ++n) kmax = std::max(kmax, m->dec[n].kin + m->W);
     const size_t lds = (size_t)16 * (kmax + 4) * 4;
-    if (lds > 150 * 1024) return false;                            // the staged rows must fit the LDS
+    const int per_cu = persist_decode_blocks_per_cu(lds);
+    if (per_cu < 1) return false;                                  // the staged rows must fit the LDS
     if (m->persist_mode == 1) return B <= 4096;
     // by size: the persistent kernel wins while a workgroup owns at most two tiles per layer (measured: depth 2, width 512: 64
     // lines 9.3 vs 20.9 ms, 256 lines 32.5 vs 21.4 ms; depth 2, width 256: 512 lines 11.4 vs 14.7 ms)
-    const int per_cu = std::min(2, (int)((160 * 1024) / (lds + 6 * 1024)));
     const int g_lstm = std::max(1, m->ncu * per_cu * 4 / 8), ntile = ((B + 15) / 16) * (m->W / 16);
     return B <= 512 && (ntile + g_lstm - 1) / g_lstm <= 2;
 }
@@ -748,9 +753,9 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S, bool* aborte
     int kmax = W;
     for (int n = 1; n <= D; ++n) kmax = std::max(kmax, pa.layer[n - 1].Kt);
     pa.lda = kmax + 4;
-    // Every workgroup must be resident at once (they wait for each other): per CU two by registers (247 VGPRs), and as many
-    // as the staged rows leave room for in the 160 KB of LDS.  The roles share the slots 4 : 1 : 2 (tiles, attention, plain).
-    const int per_cu = std::min(2, (int)((160 * 1024) / (persist_lds_bytes(pa) + 6 * 1024)));
+    // Every workgroup must be resident at once (they wait for each other): as many per CU as the runtime's occupancy query
+    // admits for this kernel with these staged rows (at most two).  The roles share the slots 4 : 1 : 2 (tiles, attention, plain).
+    const int per_cu = persist_decode_blocks_per_cu(persist_lds_bytes(pa));
     if (per_cu < 1) return fail(CASV_ERR_ARG, "persistent decoder: rows of %d floats do not fit the LDS", kmax);
     const int wgslots = m->ncu * per_cu;
     pa.g_lstm = std::min(nrb * nug, wgslots * 4 / 8);
@@ -818,21 +823,22 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (S < 1 || S > 2 * CASV_MAX_T) return fail(CASV_ERR_ARG, "S=%d out of range 1..%d", S, 2 * CASV_MAX_T);
     HIPCHK(hipSetDevice(m->device));
     const int B = m->B, T = m->T;
+    m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, B, S)) return rc;
     if (int rc = m->o_idx.ensure((size_t)B * S * 4)) return rc;
     if (int rc = m->o_prob.ensure((size_t)B * S * 4)) return rc;
     if (int rc = init_root(m, 1)) return rc;
     HIPCHK(hipMemsetAsync(m->o_idx.p, 0, (size_t)B * S * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->o_prob.p, 0, (size_t)B * S * 4, m->stream));
-    bool persistent = persist_applies(m, B);
+    bool persistent = persist_applies(m, B) && !persist_backed_off(m);
     if (persistent) {
         bool aborted = false;
         if (int rc = decode_greedy_persistent(m, mode, S, &aborted)) return rc;
+        if (!aborted) m->persist_penalty = 0;
         if (aborted) {
             // a hand-off wait ran out: the workgroups were not all resident (another process running a persistent kernel on
             // this GPU).  Nothing is lost -- the per-step kernels compute the same values; start over with them.
-            static bool told = false;
-            if (!told) { fprintf(stderr, "cor_asv_ann_hip: persistent decoder gave up waiting (GPU shared with another persistent kernel?); using the per-step kernels\n"); told = true; }
+            persist_note_abort(m, "decoder");
             if (int rc = init_root(m, 1)) return rc;
             HIPCHK(hipMemsetAsync(m->o_idx.p, 0, (size_t)B * S * 4, m->stream));
             HIPCHK(hipMemsetAsync(m->o_prob.p, 0, (size_t)B * S * 4, m->stream));
@@ -874,7 +880,7 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
         HIPCHK(hipStreamSynchronize(m->stream));
     }
     if (m->prof.on) m->prof.collect();
-    m->last_decode = 1; m->last_S = S; m->last_rows = B;
+    m->last_decode = 1; m->last_S = S; m->last_rows = B; m->last_signature = decode_buffers_signature(m);
     (void)nanflag;
     if (nan_before_end && mode == 1) return fail(CASV_ERR_NAN, "All-NaN slice encountered");
     return CASV_OK;
@@ -896,6 +902,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
         return fail(CASV_ERR_ARG, "search too large: S * batch_size * (beam_width_in + 1) nodes per line overflow int32 (decode fewer lines or steps per call)");
     HIPCHK(hipSetDevice(m->device));
     const int B = m->B, T = m->T, R = B * N, MR = bp->max_results;
+    m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, R, S)) return rc;
     if (int rc = init_root(m, N)) return rc;
     BeamState s{};
@@ -937,13 +944,8 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     // steps), otherwise once a line has finished; not under graph replay, whose kernel arguments are fixed at capture.
     m->skip_nact = (N >= 128 && !m->use_graph) ? m->b_nact.as<int>() : nullptr; m->skip_group = N;
     launch_beam_init(s, p, m->stream);
-    if (m->chain_mode != 0) {               // counters of the chained-layers launches (launch_step), all zero at the start
-        if (int rc = m->chain_counters.ensure(gemm_chain_counter_bytes())) return rc;
-        HIPCHK(hipMemsetAsync(m->chain_counters.p, 0, gemm_chain_counter_bytes(), m->stream));
-        m->chain_set = 0; m->chain_used = false; m->stat_chained = 0;
-    }
     auto body = [&](const int* step_ptr, int step_imm) {
-        launch_step(m, true, -1, nullptr, N, nullptr, nullptr, step_ptr, step_imm, false, true);
+        launch_step(m, true, -1, nullptr, N, nullptr, nullptr, step_ptr, step_imm, false);
         hipEvent_t ev{};
         m->prof_begin(PC_BEAM, 0.0, 4.0 * R * (2.0 * m->Vp), ev);
         BeamState sb = s;
@@ -981,17 +983,6 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
         pending = slot; slot ^= 1;
     }
     m->skip_nact = nullptr; m->skip_group = 0;
-    if (m->chain_used) {                    // did a chained-layers launch give up waiting?  then nothing above is valid
-        unsigned aborted = 0;
-        HIPCHK(hipMemcpyAsync(&aborted, m->chain_counters.as<unsigned>() + 2 * CHAIN_SET_WORDS, 4, hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(hipStreamSynchronize(m->stream));
-        m->chain_used = false;
-        if (aborted) {
-            fprintf(stderr, "cor_asv_ann_hip: a chained-layers launch gave up waiting (GPU partitioned or shared?); decoding again layer by layer\n");
-            m->chain_mode = 0;
-            return casv_decode_beam(m, bp, S, out_idx, out_prob, out_len, out_score, out_rej, out_align, n_found, n_steps);
-        }
-    }
     BeamOut o{};
     o.idx = m->bo_idx.as<int>(); o.prob = m->bo_prob.as<float>(); o.len = m->bo_len.as<int>(); o.score = m->bo_score.as<double>();
     o.rejpos = m->bo_rej.as<int>(); o.align = out_align ? m->bo_align.as<float>() : nullptr; o.n_found = m->bo_found.as<int>();
@@ -1016,12 +1007,15 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->prof.on) m->prof.collect();
     m->last_decode = 2; m->last_S = S; m->last_rows = (int)OR; m->last_beam = s; m->last_beam_params = p;
+    m->last_signature = decode_buffers_signature(m);
     return CASV_OK;
 }
 
 extern "C" int casv_get_alignments_sparse(casv_model* m, int32_t K, int32_t* out_lo, float* out_w) {
     if (!m || !out_lo || !out_w) return fail(CASV_ERR_ARG, "null argument");
     if (!m->last_decode) return fail(CASV_ERR_STATE, "no decode call to take alignments from");
+    // last_beam holds raw pointers into the handle's buffers: refuse once any of them may have moved
+    if (m->last_signature != decode_buffers_signature(m)) { m->last_decode = 0; return fail(CASV_ERR_STATE, "the decode results have been released (a later call reallocated device buffers)"); }
     if (K < 2 * m->cfg.window_width + 1 || K > 64) return fail(CASV_ERR_ARG, "K=%d: need at least 2*window_width+1 = %d weights per step (at most 64)", K, 2 * m->cfg.window_width + 1);
     HIPCHK(hipSetDevice(m->device));
     const size_t n = (size_t)m->last_rows * m->last_S;
@@ -1048,7 +1042,6 @@ extern "C" int casv_get_stat(casv_model* m, const char* key, int64_t* value) {
     if (!m || !key || !value) return fail(CASV_ERR_ARG, "null argument");
     if (!strcmp(key, "beam_max_new_keys")) { *value = m->stat_beam[0]; return CASV_OK; }
     if (!strcmp(key, "beam_sort_capacity")) { *value = 4096; return CASV_OK; }
-    if (!strcmp(key, "chained_launches")) { *value = m->stat_chained; return CASV_OK; }
     return fail(CASV_ERR_ARG, "unknown statistic '%s'", key);
 }
 
@@ -1127,10 +1120,6 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
     if (!strcmp(key, "persistent")) {
         if (value < -1 || value > 1) return fail(CASV_ERR_ARG, "persistent must be -1 (by batch size), 0 (per-step kernels) or 1 (always)");
         m->persist_mode = (int)value; return CASV_OK;
-    }
-    if (!strcmp(key, "chain")) {
-        if (value < 0 || value > 1) return fail(CASV_ERR_ARG, "chain must be 0 (one launch per layer) or 1 (one launch for layers 2..depth whenever the shapes fit)");
-        m->chain_mode = (int)value; return CASV_OK;
     }
     if (!strcmp(key, "eos")) {
         if (value < 0 || value >= m->V) return fail(CASV_ERR_ARG, "eos index %lld outside the vocabulary", (long long)value);

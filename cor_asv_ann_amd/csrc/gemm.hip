@@ -39,9 +39,8 @@ constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;
 // their accumulators through LDS before the epilogue -- a deterministic split-K that halves the critical path of the
 // small-M recurrent GEMMs (M = 512 gives only 64 workgroups).  Inference keeps KS = 1 so that a row's sum order never
 // depends on the batch it sits in.
-// Tile (bm, bn) of job g by the calling workgroup; split-K part zidx of nsplit.  CHAIN: the tile belongs to a launch whose
-// later tiles read this one's h' (gemm_chain_kernel): h' goes out write-through.
-template <int EPI, int KS, bool CHAIN>
+// Tile (bm, bn) of job g by the calling workgroup; split-K part zidx of nsplit.
+template <int EPI, int KS>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const int bn, const int zidx, const int nsplit, float* smem_all) {
     const int grp = KS > 1 ? (threadIdx.x >> 8) : 0;
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -288,8 +287,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
                 float zi = acc[0][r] + bi, zf = acc[1][r] + bf_, zg = acc[2][r] + bg, zo = acc[3][r] + bo;
                 const LstmCellOut cell = lstm_cell(zi, zf, zg, zo, cprev);
                 cout[(long long)m * g.c_out.ld + u] = cell.c;
-                if (CHAIN) __hip_atomic_store(hout + (long long)m * g.out.ld + u, cell.h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else hout[(long long)m * g.out.ld + u] = cell.h;
+                hout[(long long)m * g.out.ld + u] = cell.h;
                 if (gout) {
                     float* gr = gout + (long long)m * g.gates_out.ld + n0 + l31;
                     gr[0] = cell.i; gr[32] = cell.f; gr[64] = cell.g; gr[96] = cell.o;
@@ -316,115 +314,7 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
         bm = (xcd / xc) * pr + local / pc;
         bn = (xcd % xc) * pc + local % pc;
     }
-    gemm_tile<EPI, KS, false>(g, bm, bn, blockIdx.z, gridDim.z, smem_all);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The stacked LSTM layers of ONE decoder step in one launch.  Job n (layer n + 1) reads the h' of job n - 1 at the same rows:
-// tile (n, bm, bn) may start once all column tiles of (n - 1, bm) have finished.  Separate launches put a chip-wide barrier
-// there -- the slowest tile of a layer, the cache write-back and the next launch's idle prologue, ~25 us per layer out of
-// ~275 (profiles/r02_gemm_tile_trace.txt) -- this kernel puts a counter per (layer, row block) there instead, and the head
-// of a layer runs under the tail of the one before.
-//   * Workgroups pull tiles from eight queues, one per XCD (its compact block of every layer's tile grid, layer after
-//     layer), their own XCD's first, then the others' (an XCD short of workgroups is helped out).  A tile waits only for
-//     tiles of a lower layer, and those come earlier in every queue: whoever holds the lowest unfinished tile is never
-//     waiting, so the launch cannot lock up as long as every XCD runs at least one workgroup; should one not (or a wait
-//     run out for any other reason), the abort word is set, every wait gives up and the host repeats the step layer by layer.
-//   * h' is stored write-through and the storing waves drain before one lane counts the tile in (agent scope).  The slots
-//     of the state stores are written once per launch and read by nobody before, so a consumer cannot hold a stale copy:
-//     no cache invalidation on its side.
-//   * Counters: two sets, used alternately by successive launches; a launch clears the set of the next one.
-// Same tiles, same code, same values as the launches it replaces.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gemm_chain_kernel(const GemmBatch batch, const ChainArgs ca) {
-    extern __shared__ __attribute__((aligned(16))) float smem_all[];
-    __shared__ int s_tile;
-    const int tid = threadIdx.x;
-    unsigned* const mine = ca.counters + (ca.set & 1) * CHAIN_SET_WORDS;
-    unsigned* const next = ca.counters + ((ca.set & 1) ^ 1) * CHAIN_SET_WORDS;
-    unsigned* const abort_w = ca.counters + 2 * CHAIN_SET_WORDS;     // sticky: cleared by the host only
-    if (blockIdx.x == 0)
-        for (int i = tid; i < CHAIN_SET_WORDS; i += 256) next[i] = 0;
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const int home = xcc & 7;
-    const int nbm = ca.nbm, nbn = ca.nbn, xr = ca.xcd_rows, xc = 8 / xr;
-    const int pr = nbm / xr, pc = nbn / xc, per_layer = pr * pc, per_queue = per_layer * batch.count;
-    for (int v = 0; v < 8; ++v) {
-        const int q = (home + v) & 7;
-        for (;;) {
-            if (tid == 0) s_tile = (int)__hip_atomic_fetch_add(mine + CHAIN_QUEUE + q * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const int t = s_tile;
-            __syncthreads();
-            if (t >= per_queue) break;
-            const int layer = t / per_layer, local = t - layer * per_layer;
-            const int bm = (q / xc) * pr + local / pc, bn = (q % xc) * pc + local % pc;
-            if (layer > 0) {
-                if (tid == 0) {
-                    const unsigned* dep = mine + CHAIN_DEPS + ((layer - 1) * nbm + bm) * 32;
-                    unsigned spins = 0;
-                    int good = 1;
-                    while (__hip_atomic_load(dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nbn) {
-                        ++spins;
-                        if ((spins & 255u) == 0 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { good = 0; break; }
-                        if (spins > (1u << 22)) { __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); good = 0; break; }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    s_tile = good;
-                }
-                __syncthreads();
-                const int good = s_tile;
-                __syncthreads();
-                if (!good) return;
-            }
-            gemm_tile<EPI_LSTM, 1, true>(batch.g[layer], bm, bn, 0, 1, smem_all);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(mine + CHAIN_DEPS + (layer * nbm + bm) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-size_t gemm_chain_counter_bytes() { return (size_t)(2 * CHAIN_SET_WORDS + 32) * sizeof(unsigned); }
-
-// the XCD split of the tile grid (rows of the 8 = xr * xc blocks), 0: the shapes do not fit the chain kernel
-static int chain_xcd_rows(const GemmBatch& b) {
-    if (b.count < 2 || b.count > GEMM_MAX_JOBS) return 0;
-    const int nbm = (b.g[0].M + BM - 1) / BM, nbn = (b.g[0].N + BN - 1) / BN;
-    for (int j = 0; j < b.count; ++j) {
-        const GemmArgs& g = b.g[j];
-        if (g.M != b.g[0].M || g.N != b.g[0].N || g.nact || g.step_ptr || g.epi_plain || g.zinit.base || g.gates_out.base) return 0;
-    }
-    if ((nbm * nbn) % 8 != 0 || nbm > CHAIN_MAX_NBM) return 0;
-    int best_xr = 0; double best = 0;
-    for (int xr = 1; xr <= 8; xr *= 2) {
-        const int xc = 8 / xr;
-        if (nbm % xr || nbn % xc) continue;
-        const double cost = (double)b.g[0].M * xc + (double)b.g[0].N * xr;
-        if (!best_xr || cost < best) { best = cost; best_xr = xr; }
-    }
-    return best_xr;
-}
-bool gemm_chain_fits(const GemmBatch& b) { return chain_xcd_rows(b) != 0; }
-
-// Counters: gemm_chain_counter_bytes() = two sets + the abort word, all zero before the first launch; `set` alternates.
-bool launch_gemm_chain(const GemmBatch& b, unsigned* counters, int set, int ncu, hipStream_t stream) {
-    const int best_xr = chain_xcd_rows(b);
-    if (!best_xr) return false;
-    const int nbm = (b.g[0].M + BM - 1) / BM, nbn = (b.g[0].N + BN - 1) / BN;
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
-    ChainArgs ca{};
-    ca.counters = counters; ca.set = set; ca.nbm = nbm; ca.nbn = nbn; ca.xcd_rows = best_xr;
-    const int total = nbm * nbn * b.count, resident = 2 * ncu;
-    hipLaunchKernelGGL(gemm_chain_kernel, dim3(total < resident ? total : resident), dim3(256), GEMM_LDS_BYTES, stream, b, ca);
-    return true;
+    gemm_tile<EPI, KS>(g, bm, bn, blockIdx.z, gridDim.z, smem_all);
 }
 
 template <int EPI, int KS>

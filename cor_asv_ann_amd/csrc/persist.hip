@@ -23,12 +23,19 @@
 // (slot s + 1 holds the outputs of step s), so no address is rewritten and none is read before it was written.
 // Producers store the payload write-through (sc1), drain (s_waitcnt vmcnt(0) in every storing wave), meet at the
 // workgroup barrier, and ONE lane adds to the row block's monotonic counter (agent scope).  Consumers: one lane polls the
-// counters it needs (relaxed, agent scope, s_sleep between polls, bounded), then ONE agent-scope acquire, a barrier, and
-// plain loads.  Counters only grow (target = tiles per step x steps done) and are zeroed by a memset ahead of the launch.
-// A spin that runs out sets the abort word; every other wait sees it and the launch drains.
+// counters it needs (relaxed, agent scope, s_sleep between polls, bounded in TIME), a barrier, and then EVERY load of the
+// handed-off rows is a load that goes past the L2 (load_sc1) -- no agent-scope acquire, which would also empty this XCD's L2
+// of the weights (MI355X_MICROARCH.md, "Valid forms": sc1 stores + drain + counter, sc1 loads behind the poll + barrier).
+// Counters only grow (target = tiles per step x steps done) and are zeroed by a memset ahead of the launch.
+// A wait that lasts longer than PERSIST_WAIT_TICKS sets the abort word; every other wait sees it and the launch drains.
+// The grids are sized from the occupancy the runtime reports for these kernels (persist_*_blocks_per_cu), not from assumed
+// register counts: every workgroup must be resident at once.
 #include "common.h"
 #include "row_kernels.h"
 #include <math.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace casv {
 
@@ -44,7 +51,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PROF_ADD(slot, t1, t0)
 #endif
 
-constexpr unsigned PERSIST_SPIN_LIMIT = 2u * 1000u * 1000u;    // polls before a wait gives up (a few seconds; a whole decode takes milliseconds)
+// A wait gives up after this many ticks of the 100 MHz wall clock (50 ms: a whole decode takes milliseconds; a hand-off
+// microseconds).  Lost residency -- a compiler that changed the register count, a partitioned or shared GPU -- then costs
+// one such wait per call, after which the host stops choosing the persistent path for a while (engine.hip).
+constexpr unsigned long long PERSIST_WAIT_TICKS = 5ull * 1000ull * 1000ull;
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -59,16 +69,21 @@ __device__ __forceinline__ bool wait_deps(const Dep d0, const Dep d1, const Dep 
     if (threadIdx.x == 0) {
         int good = 1;
         unsigned spins = 0;
+        unsigned long long t_begin = 0;
         for (;;) {
             const bool ready = (!d0.c || ld_agent(d0.c) >= d0.target) && (!d1.c || ld_agent(d1.c) >= d1.target) &&
                                (!d2.c || ld_agent(d2.c) >= d2.target);
             if (ready) break;
             ++spins;
-            if ((spins & 255u) == 0 && ld_agent(abort_w)) { good = 0; break; }
-            if (spins > PERSIST_SPIN_LIMIT) {
-                __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                good = 0;
-                break;
+            if ((spins & 255u) == 0) {
+                if (ld_agent(abort_w)) { good = 0; break; }
+                const unsigned long long now = wall_clock64();
+                if (!t_begin) t_begin = now;
+                else if (now - t_begin > PERSIST_WAIT_TICKS) {
+                    __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = 0;
+                    break;
+                }
             }
             __builtin_amdgcn_s_sleep(1);
         }
@@ -616,6 +631,30 @@ __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEnc
     if (prof_on && tid == 0) atomicAdd(const_cast<unsigned long long*>(pa.prof) + 17, wall_clock64() - tk1);
 #endif
 }
+
+// Workgroups of `kernel` (256 threads, `lds` bytes of dynamic LDS) that one CU holds at once, as the runtime reports it for
+// the code object that is actually loaded -- asked once per (device, LDS size).  0 = the query failed: no persistent launch.
+template <class K>
+static int blocks_per_cu(K kernel, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<int, size_t>, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({dev, lds});
+    if (it != cache.end()) return it->second;
+    int n = 0;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) n = 0;
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), 256, lds) != hipSuccess) n = 0;
+    // The query counts registers and LDS; the workgroup's static LDS (gate exchange, flags: ~4.3 KB) is part of the kernel's
+    // own figure.  Never plan for more than the two workgroups per CU the launch bounds promise.
+    n = n > 2 ? 2 : (n < 0 ? 0 : n);
+    cache[{dev, lds}] = n;
+    return n;
+}
+int persist_encode_blocks_per_cu(size_t lds) { return lds > 150 * 1024 ? 0 : blocks_per_cu(persist_encode_kernel, lds); }
+int persist_decode_blocks_per_cu(size_t lds) { return lds > 150 * 1024 ? 0 : blocks_per_cu(persist_decode_kernel, lds); }
 
 size_t persist_enc_counter_bytes(int B, int D) {
     const size_t nrb = (B + 15) / 16;

@@ -2,19 +2,26 @@
 
 The attention of the decoder (attention.py:553-571) is zero outside a window of at most 2*window+1 input positions,
 so one output step's alignment row is fully described by (first position, <= 11 weights).  `correct_lines` returns
-one `SparseAlignment` per line: it behaves like the reference's list of T-wide rows (`alignment[j][i]`, `len`,
-iteration, `numpy.asarray`) -- rows are materialised only when somebody asks -- and `alignment2path` below runs the
+one `SparseAlignment` per line: it IS a list of T-wide rows (`alignment[j][i]`, `len`, iteration, `numpy.asarray`)
+whose rows are built, all at once, only when somebody first looks at one -- and `alignment2path` below runs the
 Viterbi re-alignment of the OCR-D wrapper (wrapper/transcode.py:279-349) directly on the windows.
 """
 import numpy as np
 
 
-class SparseAlignment(object):
-    """Alignment rows of one decoded line: row j is zero outside [lo[j], lo[j] + K) (lo[j] < 0: an all-NaN row)."""
+class SparseAlignment(list):
+    """Alignment rows of one decoded line: row j is zero outside [lo[j], lo[j] + K) (lo[j] < 0: an all-NaN row).
+
+    A `list` (the reference hands out a list of T-wide rows, transcode.py:308,316,325 index it cell by cell) that stays
+    EMPTY until somebody looks at a row: the first indexing / iteration / comparison builds all rows with one scatter and
+    turns the object into a plain list of numpy rows (`_DenseAlignment`: the list type's own C slots, so the wrapper's
+    unchanged `_alignment2path` pays nothing per cell).  `len()`, `numpy.asarray`, `cells_above` / `value` and
+    `alignment2path` below work on the windows and never build the rows."""
 
     __slots__ = ('lo', 'w', 'width')
 
     def __init__(self, lo, w, width):
+        list.__init__(self)
         self.lo = np.asarray(lo, np.int32)
         self.w = np.asarray(w, np.float32)
         self.width = int(width)
@@ -25,6 +32,26 @@ class SparseAlignment(object):
         w = np.zeros((n, 1), np.float32)
         w[:, 0] = 1.0
         return cls(np.arange(n, dtype=np.int32), w, n)
+
+    def dense(self):
+        """All rows as one (n, width) float32 array (one scatter over the windows)."""
+        n, K = self.lo.shape[0], self.w.shape[1] if self.w.ndim == 2 else 0
+        out = np.zeros((n, self.width), np.float32)
+        if n and K and self.width:
+            lo = self.lo.astype(np.int64)
+            cols = lo[:, None] + np.arange(K)[None, :]
+            ok = (lo[:, None] >= 0) & (cols < self.width)
+            rows = np.broadcast_to(np.arange(n)[:, None], cols.shape)
+            out[rows[ok], cols[ok]] = self.w[ok]
+        if n:
+            out[self.lo < 0] = np.nan
+        return out
+
+    def _materialise(self):
+        """Build the rows once and become a plain list of them."""
+        list.extend(self, self.dense())
+        self.__class__ = _DenseAlignment
+        return self
 
     def __len__(self):
         return self.lo.shape[0]
@@ -40,24 +67,45 @@ class SparseAlignment(object):
             out[lo:lo + k] = self.w[j, :k]
         return out
 
+    # anything that looks at rows builds them first (then the list type answers by itself)
     def __getitem__(self, j):
-        if isinstance(j, slice):
-            return [self.row(k) for k in range(*j.indices(len(self)))]
-        if j < 0:
-            j += len(self)
-        if not 0 <= j < len(self):
-            raise IndexError(j)
-        return self.row(j)
+        return list.__getitem__(self._materialise(), j)
 
     def __iter__(self):
-        return (self.row(j) for j in range(len(self)))
+        return list.__iter__(self._materialise())
+
+    def __reversed__(self):
+        return list.__reversed__(self._materialise())
+
+    def __contains__(self, x):
+        return list.__contains__(self._materialise(), x)
+
+    def __eq__(self, other):
+        return list.__eq__(self._materialise(), other)
+
+    def __ne__(self, other):
+        return list.__ne__(self._materialise(), other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return list.__repr__(self._materialise())
+
+    def __add__(self, other):
+        return list.__add__(self._materialise(), other)
+
+    def __reduce__(self):
+        return (SparseAlignment, (self.lo, self.w, self.width))
+
+    def copy(self):
+        return list(self._materialise())
 
     def __array__(self, dtype=None, copy=None):
-        a = np.stack([self.row(j) for j in range(len(self))]) if len(self) else np.zeros((0, self.width), np.float32)
+        a = self.dense()
         return a.astype(dtype) if dtype is not None else a
 
     def tolist(self):
-        return [self.row(j).tolist() for j in range(len(self))]
+        return self.dense().tolist()
 
     def cells_above(self, j, min_score, i_max):
         """Positions i < i_max of row j whose weight exceeds min_score, ascending, with their weights."""
@@ -75,6 +123,29 @@ class SparseAlignment(object):
             return float('nan')
         k = i - lo
         return float(self.w[j, k]) if 0 <= k < self.w.shape[1] and i < self.width else 0.0
+
+
+class _DenseAlignment(SparseAlignment):
+    """A SparseAlignment whose rows have been built: every list operation is the list type's own again."""
+
+    __slots__ = ()
+    __len__ = list.__len__
+    __getitem__ = list.__getitem__
+    __iter__ = list.__iter__
+    __reversed__ = list.__reversed__
+    __contains__ = list.__contains__
+    __eq__ = list.__eq__
+    __ne__ = list.__ne__
+    __repr__ = list.__repr__
+    __add__ = list.__add__
+    copy = list.copy
+
+    def _materialise(self):
+        return self
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.stack(list(self)) if list.__len__(self) else np.zeros((0, self.width), np.float32)
+        return a.astype(dtype) if dtype is not None else a
 
 
 def alignment2path(alignment, i_max, j_max, min_score):

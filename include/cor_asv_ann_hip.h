@@ -196,16 +196,13 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
  * "persistent" = greedy decoding through the persistent decoder (all steps in ONE launch, workgroups hand rows to each
  * other through memory: small batches, where a step is too short for a launch per kernel): -1 by batch size (default:
  * up to 512 lines), 0 never, 1 always -- the results are the same bit for bit;
- * "chain" = 1: layers 2..depth of a beamed decoder step in ONE launch whose tiles wait for the row block of the layer below
- * instead of for the whole chip, whenever the tile grid allows (default 0: one launch per layer, which measured faster) --
- * the results are the same bit for bit;
  * "eos" = vocabulary index of the end-of-line character '\n' (default 1: '' and '\n' sort first, seq2seq.py:580);
  * "tile" (process-wide; alias "skinny") = tile shape of the GEMM launches: -1 by size (default), 0 always 128x128,
  * 1 always 32x128 -- a measurement/test switch, the values computed are the same bit for bit. */
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 /* Statistics of the last call (tests): "beam_max_new_keys" = most child hypotheses one line created in one search
  * iteration of the last casv_decode_beam; "beam_sort_capacity" = how many of them are sorted in LDS at once (more are
- * sorted in runs and merged by rank); "chained_launches" = launches of the last casv_decode_beam that carried several layers. */
+ * sorted in runs and merged by rank). */
 int casv_get_stat(casv_model* m, const char* key, int64_t* value);
 int casv_synchronize(casv_model* m);
 

@@ -85,8 +85,10 @@ def test_persistent_path_is_the_default_for_small_batches_and_matches_the_oracle
 
 
 def test_c2_full_size_on_the_persistent_path():
-    """BASELINE configs[1] (depth 2, width 256, 256 lines of 100 characters): both paths agree bit for bit over all 202
-    steps of all lines; the first lines are compared with the oracle."""
+    """BASELINE configs[1] (depth 2, width 256, 256 lines of 100 characters): the persistent and the per-step path are
+    compared with each other over all 202 steps of all lines.  (The comparison of this configuration with the ORACLE is
+    tests/test_gpu_parity.py::test_c2_full_size_properties, which runs on the path the library picks by itself -- the
+    persistent one.)"""
     cfg = ModelConfig(depth=2, width=256, voc_size=256)
     weights = make_weights(cfg, emb_scale=64.0)
     lines, idx = make_lines(256, 100, 102)

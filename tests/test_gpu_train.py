@@ -65,21 +65,36 @@ def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks):
     eng.close()
 
 
-def test_facade_train_copy_task(tmp_path, monkeypatch):
+@pytest.fixture(scope='module')
+def copy_model(tmp_path_factory):
+    """A small model trained on a copy task through the facade's train() (cor-asv-ann-train's path), shared by the tests
+    below: the functional, well-conditioned fixture for beam search and evaluation."""
+    import os
+    from cor_asv_ann_amd.seq2seq import Sequence2Sequence
+    tmp_path = tmp_path_factory.mktemp('copytask')
+    cwd = os.getcwd()
+    os.chdir(tmp_path)                                       # checkpoints go to the CWD like the reference's
+    try:
+        rng = np.random.default_rng(0)
+        alphabet = 'abcdefghij '
+        lines = [''.join(rng.choice(list(alphabet), size=rng.integers(5, 12))) for _ in range(1600)]
+        (tmp_path / 'train.tsv').write_text(''.join('%s\t%s\n' % (l, l) for l in lines))
+        s2s = Sequence2Sequence()
+        s2s.depth, s2s.width, s2s.batch_size, s2s.epochs, s2s.dropout = 2, 64, 32, 50, 0.0
+        s2s._rng = np.random.default_rng(1)
+        s2s.configure()
+        s2s.train([str(tmp_path / 'train.tsv')])
+    finally:
+        os.chdir(cwd)
+    return s2s, lines, tmp_path
+
+
+def test_facade_train_copy_task(copy_model):
     """cor-asv-ann-train's path: map_files -> epochs of train_on_batch -> validation -> early stopping ->
     trained weights usable by correct_lines; afterwards the trained model is the functional fixture for the
     beam search (non-degenerate, well-conditioned distributions): GPU == oracle on it."""
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
-    monkeypatch.chdir(tmp_path)                              # checkpoints go to the CWD like the reference's
-    rng = np.random.default_rng(0)
-    alphabet = 'abcdefghij '
-    lines = [''.join(rng.choice(list(alphabet), size=rng.integers(5, 12))) for _ in range(1600)]
-    (tmp_path / 'train.tsv').write_text(''.join('%s\t%s\n' % (l, l) for l in lines))
-    s2s = Sequence2Sequence()
-    s2s.depth, s2s.width, s2s.batch_size, s2s.epochs, s2s.dropout = 2, 64, 32, 50, 0.0
-    s2s._rng = np.random.default_rng(1)
-    s2s.configure()
-    s2s.train([str(tmp_path / 'train.tsv')])
+    s2s, lines, tmp_path = copy_model
     assert s2s.status == 2
     hist = s2s.history
     assert min(h['val_loss'] for h in hist) < 0.85 * hist[0]['val_loss'], hist
@@ -109,6 +124,55 @@ def test_facade_train_copy_task(tmp_path, monkeypatch):
     third.load_config(ckpts[best]); third.configure(); third.load_weights(ckpts[best])
     for k, v in s2s.get_weights().items():
         assert np.array_equal(third.get_weights()[k], v), k
+
+
+def test_evaluate_runs_through_the_device(copy_model, caplog):
+    """f4: `evaluate()` (seq2seq.py:651-754) un-stubbed -- greedy and beamed decoding on the HIP path, this package's metrics
+    on top.  Expected figures: the same metrics over the ORACLE's decoded strings and scores for the same lines (OCR
+    column: the source lines themselves)."""
+    import logging
+    import math
+    from cor_asv_ann_amd.metrics import Alignment, Edits, splitwords
+    s2s, lines, tmp_path = copy_model
+    rng = np.random.default_rng(7)
+    pairs = []
+    for text in lines[100:111]:                              # 11 lines: the last batch of 4 is partly padding
+        chars = list(text)
+        for k in rng.choice(len(chars), size=max(1, len(chars) // 6), replace=False):
+            chars[k] = str(rng.choice(list('abcdefghij')))   # OCR errors the model may or may not repair
+        pairs.append((''.join(chars), text))
+    tsv = tmp_path / 'eval.tsv'
+    tsv.write_text(''.join('%s\t%s\n' % p for p in pairs))
+    s2s.batch_size = 4
+    s2s.logger = logging.getLogger('evalgpu')
+    with caplog.at_level(logging.INFO, logger='evalgpu'):
+        s2s.evaluate([str(tsv)], fast=False)
+    text = '\n'.join(r.getMessage() for r in caplog.records)
+
+    cfg = ModelConfig(depth=2, width=64, voc_size=s2s.voc_size)
+    om = OracleModel(cfg, s2s.get_weights(), mapping=s2s.mapping, batch_size=4)
+    src = [a + '\n' for a, _ in pairs]
+    tgt = [b + '\n' for _, b in pairs]
+    greedy, beamed = ([], []), ([], [])
+    for b0 in range(0, len(src), 4):                         # the batches gen_lines forms (the last one padded with '')
+        batch = src[b0:b0 + 4] + [''] * (4 - len(src[b0:b0 + 4]))
+        for res, kw in ((greedy, dict(fast=False, greedy=True)), (beamed, dict(fast=False, greedy=False))):
+            out = correct_lines(om, batch, **kw)
+            res[0].extend(out[0][:len(src[b0:b0 + 4])]); res[1].extend(out[2][:len(src[b0:b0 + 4])])
+    cols = {'OCR:   ': (src, None), 'greedy:': greedy, 'beamed:': beamed}
+    for label, (outs, scores) in cols.items():
+        c, w = Edits(s2s.logger), Edits(s2s.logger)
+        ca, wa = Alignment(0, logger=s2s.logger), Alignment(0, logger=s2s.logger)
+        for o, t in zip(outs, tgt):
+            c.add(*ca.get_adjusted_distance(o, t, normalization='historic_latin', gtlevel=1), o, t)
+            w.add(*wa.get_adjusted_distance(splitwords(o), splitwords(t), normalization='historic_latin', gtlevel=1), o, t)
+        assert 'CER %s %.3f±%.3f' % (label, c.mean, math.sqrt(c.varia)) in text, (label, text)
+        assert 'WER %s %.3f±%.3f' % (label, w.mean, math.sqrt(w.varia)) in text, (label, text)
+        if scores is not None:
+            ppl = math.exp(sum(scores) / max(c.length, 1))
+            got = float(text.split('ppl %s ' % label.strip())[1].split()[0])
+            assert abs(got - ppl) < 2e-3 * ppl, (label, got, ppl)
+    assert 'finished ' in text
 
 
 def test_frozen_layers_do_not_train():

@@ -269,3 +269,50 @@ def test_oracle_matches_keras_goldens(golden_dir):
             assert np.array_equal(got[5][j, :n], g['greedy_idx'][j, :n]), (name, j)
             r = next(decode_sequence_beam(m, source_seq=enc_in[j]), ('', None, 0.0, None))
             assert r[0] == str(g['beam_text'][j]) and abs(r[2] - g['beam_score'][j]) < 1e-4, (name, j)
+
+
+def test_keras_golden_hook_reads_the_schema_its_generator_writes(golden_dir, tmp_path, monkeypatch):
+    """`test_oracle_matches_keras_goldens` has never seen a file (none can be produced here).  Feed it one in the schema
+    of tests/golden/make_keras_goldens.py::run_case -- produced by the ORACLE standing in for the reference, with the
+    generator's conventions (greedy characters only up to the end of the line + `greedy_len`, the decoder's
+    (B,1,V)-shaped outputs squeezed the way the generator squeezes them) -- so that the hook works the first time a
+    reference-generated file appears under tests/golden/keras/ or $CASV_GOLDEN_DIR.  Pins nothing about Keras."""
+    from tests.golden.make_golden import CASES, NTENS
+    name = 'd2_w64_v96'
+    d, W, V, B, L, seed, es, N = CASES[name]
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    m = OracleModel(cfg, make_weights(cfg, emb_scale=es), batch_size=N)
+    lines, idx = make_lines(B, L, seed, voc_size=V)
+    enc_in, _, _, _ = vectorize_lines(m, lines, [[] for _ in lines])
+    out = {'idx': idx.astype(np.int32)}
+    enc = m.encode(enc_in)
+    out['enc_out'] = enc[0][:NTENS]
+    out['enc_states'] = np.stack(enc[1:-1])[:, :NTENS]
+    p, states = np.zeros((B, V), np.float32), enc[1:]
+    for s in range(3):
+        p, states = m.step(p, enc[0], states)
+        out['step%d_probs' % s] = p[:, None, :][:NTENS, -1]                 # generator: res[0] is (B,1,V)
+        out['step%d_states' % s] = np.stack(states[:-1])[:, :NTENS]
+        out['step%d_align' % s] = states[-1][:NTENS]
+    g = decode_batch_greedy(m, enc_in, return_indexes=True)
+    c_i = m.mapping[0]
+    gi = np.zeros((B, 2 * (L + 1)), np.int16)
+    for j, text in enumerate(g[1]):
+        gi[j, :len(text)] = [c_i[c] for c in text]
+    out['greedy_idx'] = gi
+    out['greedy_len'] = np.array([len(t) for t in g[1]], np.int32)
+    out['greedy_scores'] = np.asarray(g[3], np.float64)
+    texts, scores = [], []
+    for j in range(B):
+        r = next(decode_sequence_beam(m, source_seq=enc_in[j]), ('', None, 0.0, None))
+        texts.append(r[0]); scores.append(r[2])
+    out['beam_text'] = np.array(texts)
+    out['beam_score'] = np.asarray(scores, np.float64)
+    np.savez_compressed(str(tmp_path / (name + '.npz')), **out)
+    monkeypatch.setenv('CASV_GOLDEN_DIR', str(tmp_path))
+    test_oracle_matches_keras_goldens(golden_dir)                           # must not skip and must not fail
+    # ... and a file that disagrees is reported, not skipped over
+    out['step1_probs'] = out['step1_probs'] * 1.01
+    np.savez_compressed(str(tmp_path / (name + '.npz')), **out)
+    with pytest.raises(AssertionError):
+        test_oracle_matches_keras_goldens(golden_dir)

@@ -72,3 +72,68 @@ def test_identity_alignment_gives_the_diagonal():
     n = 12
     path, dist = alignment2path(SparseAlignment.identity(n), n, n, 1 / 50.)
     assert path == dict([(i, i) for i in range(n)] + [(n, n)]) and dist == 0
+
+
+def _reference_style_forward(alignment, i_max, j_max, min_score):
+    """The cell-by-cell access pattern of the wrapper's unchanged `_alignment2path` forward pass (transcode.py:293-318):
+    `alignment[j][i]` for every cell it looks at."""
+    fw = np.zeros((i_max, j_max), dtype=np.float32)
+    i, j = 0, 0
+    while i < i_max and j < j_max:
+        im1 = fw[i - 1, j] if i > 0 else 0
+        jm1 = fw[i, j - 1] if j > 0 else 0
+        ijm1 = fw[i - 1, j - 1] if i > 0 and j > 0 else 0
+        fw[i, j] = alignment[j][i] + max(im1, jm1, ijm1)
+        while True:
+            i += 1
+            if i == i_max:
+                j += 1
+                if j == j_max:
+                    break
+                i = 0
+            if alignment[j][i] > min_score:
+                break
+    return fw
+
+
+def test_cell_by_cell_access_costs_what_a_list_of_rows_costs():
+    """The OCR-D wrapper indexes `alignment[j][i]` cell by cell (transcode.py:308,316,325).  A SparseAlignment builds its
+    rows once, at the first such access, and is a plain list from then on: the reference's loop over a 101 x 101 line
+    must not take more than 1.5x what it takes on a list of rows (round 2: 8x, a fresh row per access)."""
+    import time
+    rng = np.random.default_rng(5)
+    n = T = 101
+    sp = _random_alignment(rng, n, T)
+    rows = list(np.asarray(sp))
+
+    def best_of(make, repeats=7):
+        best = float('inf')
+        for _ in range(repeats):
+            a = make()
+            t0 = time.perf_counter()
+            fw = _reference_style_forward(a, T, n, 1 / 256.)
+            best = min(best, time.perf_counter() - t0)
+        return best, fw
+
+    t_list, fw_list = best_of(lambda: list(rows))
+    t_sparse, fw_sparse = best_of(lambda: SparseAlignment(sp.lo, sp.w, T))
+    assert np.array_equal(fw_list, fw_sparse)
+    assert t_sparse <= 1.5 * t_list + 2e-4, (t_sparse, t_list)
+
+
+def test_sparse_alignment_stays_lazy_until_rows_are_looked_at():
+    rng = np.random.default_rng(6)
+    sp = _random_alignment(rng, 7, 9)
+    assert isinstance(sp, list) and len(sp) == 7 and bool(sp) and list.__len__(sp) == 0       # nothing built yet
+    dense = np.asarray(sp)                                                                      # ... nor by asarray,
+    alignment2path(sp, 9, 7, 1 / 50.)                                                           # the windows' own Viterbi,
+    assert sp.value(2, int(sp.lo[2])) == dense[2, sp.lo[2]] and list.__len__(sp) == 0           # or single values
+    first = sp[0]                                                                               # the first row access builds all
+    assert list.__len__(sp) == 7 and isinstance(sp, SparseAlignment) and np.array_equal(first, dense[0])
+    assert np.array_equal(np.asarray(sp), dense) and len(sp) == 7 and sp.tolist() == dense.tolist()
+    assert [r.tolist() for r in sp] == dense.tolist() and len(sp[1:3]) == 2
+    fresh = _random_alignment(np.random.default_rng(6), 7, 9)
+    assert fresh != [] and not fresh == []                 # comparing looks at the rows too (an empty list otherwise)
+    assert all(np.array_equal(a, b) for a, b in zip(fresh, dense))
+    empty = SparseAlignment(np.zeros(0, np.int32), np.zeros((0, 11), np.float32), 9)
+    assert len(empty) == 0 and not empty and list(empty) == [] and np.asarray(empty).shape == (0, 9)
