@@ -12,8 +12,12 @@ result records makes all decoded lines available on all ranks (BASELINE.json con
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks already
 (RANK / LOCAL_RANK / WORLD_SIZE from the environment).
 
-Other workloads (`--workload`): c2 = greedy decode of BASELINE configs[1], c4 = train step of configs[3],
-c5 = configs[4]'s shape (8192 lines per GPU per step, decoded in 1024-line batches).
+Workloads (`--workload`; default c3 on one GPU, c5 on several): c2 = greedy decode of BASELINE configs[1], c3 = the metric's
+beamed decode (configs[2]), c4 = train step of configs[3], c5 = configs[4]'s shape (8192 lines per GPU per step, decoded in
+1024-line batches, one all-gather per step), page = the OCR-D processor's call (wrapper/transcode.py:110-115 with the
+defaults of wrapper/ocrd-tool.json: depth 2, width 512, V 640, one page of 40 confusion-network lines, 256 hypotheses per
+step, alignments requested).  The default one-GPU run also times c2, c4 and page after the headline's timed region (child
+processes, bounded) and reports them under "other_workloads".
 
 Prints ONE JSON line on rank 0.
 """
@@ -90,39 +94,39 @@ def launch_ranks(n, argv):
 
 
 # ------------------------------------------------------------------------------------------------------
-def make_model(device, depth=DEPTH, width=WIDTH, batch_size=BEAM_N, emb_scale=EMB_SCALE):
+def make_model(device, depth=DEPTH, width=WIDTH, batch_size=BEAM_N, emb_scale=EMB_SCALE, voc=VOC):
     from cor_asv_ann_amd.synthetic import ModelConfig, make_weights, make_vocabulary
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
-    cfg = ModelConfig(depth=depth, width=width, voc_size=VOC)
+    cfg = ModelConfig(depth=depth, width=width, voc_size=voc)
     weights = make_weights(cfg, emb_scale=emb_scale)
     import logging
     logger = logging.getLogger('bench')
     logger.setLevel(logging.CRITICAL)     # lines without a finished hypothesis fall back to the input (seq2seq.py:826-836)
     s2s = Sequence2Sequence(logger=logger, device=device)   # and are logged as errors: hundreds per step with random weights
     s2s.depth, s2s.width, s2s.batch_size = depth, width, batch_size
-    s2s.mapping, s2s.voc_size = make_vocabulary(VOC), VOC
+    s2s.mapping, s2s.voc_size = make_vocabulary(voc), voc
     s2s.configure()
     s2s.set_weights(weights)
     s2s.status = 2
     return s2s, cfg, weights
 
 
-def survey_flop_per_char(d=DEPTH, W=WIDTH, N=BEAM_N):
+def survey_flop_per_char(d=DEPTH, W=WIDTH, N=BEAM_N, V=VOC, L=LENGTH):
     """F = F_enc + N*S*F_row per line, divided by the L corrected characters."""
-    V, K, T = VOC, 11, LENGTH + 1
+    K, T = 11, L + 1
     C = 2 * W if d == 1 else W
     f_row = 2 * V * W + (d - 1) * 16 * W * W + 2 * W * W + K * (4 * W + 2 * C) + 8 * W * (2 * W + C) + 2 * W * V
     f_enc = T * (32 * W * W + (24 * W * W if d >= 2 else 0) + 16 * W * W * max(d - 2, 0) + 2 * C * W)
-    return (f_enc + N * 2 * T * f_row) / float(LENGTH)
+    return (f_enc + N * 2 * T * f_row) / float(L)
 
 
-def survey_hbm_bytes_per_char(d=DEPTH, W=WIDTH, N=BEAM_N):
+def survey_hbm_bytes_per_char(d=DEPTH, W=WIDTH, N=BEAM_N, V=VOC, L=LENGTH):
     """Q = Q_enc + N*S*Q_row per line (per-beam state in HBM, weights on chip), per corrected character."""
-    V, K, T = VOC, 11, LENGTH + 1
+    K, T = 11, L + 1
     C = 2 * W if d == 1 else W
     q_row = 4 * (4 * d * W + K * (W + C) + 2 * V + 2 * T)
     q_enc = 4 * T * (1 + 2 * 2 * W + 2 * W * max(d - 2, 0) + C + W)
-    return (q_enc + N * 2 * T * q_row) / float(LENGTH)
+    return (q_enc + N * 2 * T * q_row) / float(L)
 
 
 def host_threads():
@@ -133,7 +137,7 @@ def host_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(cfg, weights, lines, batch_size, fast, budget_s=22.0, repeats=5):
+def cpu_baseline(cfg, weights, lines, batch_size, fast, length=LENGTH, budget_s=22.0, repeats=5):
     """The oracle in the reference's dataflow (per-character decoder call, dense-T attention, u recomputed
     every step, per-line best-first search / batched greedy loop) on the host cores: best of `repeats`
     samples of the same workload, each sized to a share of the time budget."""
@@ -151,7 +155,7 @@ def cpu_baseline(cfg, weights, lines, batch_size, fast, budget_s=22.0, repeats=5
         correct_lines(om, lines[:n], **kw)
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
-    return {'value': n * LENGTH / best, 'unit': 'chars/s', 'cores': host_threads(), 'kind': 'port',
+    return {'value': n * length / best, 'unit': 'chars/s', 'cores': host_threads(), 'kind': 'port',
             'sample': 'best of %d runs over %d lines of the same workload (numpy fp32 oracle, reference dataflow: '
                       'per-character decoder call, dense-T attention, u recomputed per step), %.1f s per run' % (repeats, n, best)}
 
@@ -213,22 +217,31 @@ def train_bench(args):
 
 # ------------------------------------------------------------------------------------------------------
 WORKLOADS = {
-    # name: (depth, width, lines per GPU per step, lines per decode call, hypotheses N, greedy?, emb_scale, dominant kernel class)
-    'c2': dict(depth=2, width=256, lines=256, batch=256, n=1, fast=True, emb=EMB_SCALE, seed=102,
+    # lines = lines per GPU per step, batch = lines per decode call, n = hypotheses per line and step (batch_size)
+    'c2': dict(depth=2, width=256, voc=VOC, length=LENGTH, lines=256, batch=256, n=1, fast=True, emb=EMB_SCALE, seed=102,
                text='BASELINE configs[1]: depth=2 width=256 V=256 greedy decode (decode_batch_greedy, 2T steps), '
                     '256 lines x 100 chars per GPU per step'),
-    'c3': dict(depth=DEPTH, width=WIDTH, lines=LINES, batch=LINES, n=BEAM_N, fast=False, emb=EMB_SCALE, seed=LINE_SEED,
+    'c3': dict(depth=DEPTH, width=WIDTH, voc=VOC, length=LENGTH, lines=LINES, batch=LINES, n=BEAM_N, fast=False, emb=EMB_SCALE, seed=LINE_SEED,
                text='BASELINE configs[2]: depth=4 width=512 V=256 beamed decode (N=8 hypotheses/step, defaults otherwise), '
                     '1024 lines x 100 chars per GPU per step'),
-    'c5': dict(depth=DEPTH, width=WIDTH, lines=8192, batch=LINES, n=BEAM_N, fast=False, emb=EMB_SCALE, seed=105,
+    'c5': dict(depth=DEPTH, width=WIDTH, voc=VOC, length=LENGTH, lines=8192, batch=LINES, n=BEAM_N, fast=False, emb=EMB_SCALE, seed=105,
                text='BASELINE configs[4]: depth=4 width=512 V=256 beamed decode (N=8), 8192 lines x 100 chars per GPU per step '
                     'in 1024-line batches, one all-gather of result records per step'),
+    # the OCR-D processor's call (wrapper/transcode.py:110-115; parameter defaults of wrapper/ocrd-tool.json:38-56; the
+    # published models are depth 2, width 512, ocrd-tool.json:61-74; `batch_size` keeps its default 256 = hypotheses per step,
+    # seq2seq.py:111,1414): one page = one correct_lines call on confusion-network lines, alignments requested
+    'page': dict(depth=2, width=512, voc=640, length=60, lines=40, batch=40, n=256, fast=False, emb=EMB_SCALE, seed=106, confmat=True,
+                 alignments=True, rejection=0.5, beam_width_in=15, beam_threshold_in=0.2,
+                 text='OCR-D processor call (wrapper/transcode.py:110-115, ocrd-tool.json defaults): depth=2 width=512 V=640, one page = '
+                      '40 confusion-network lines x 60 positions, beamed decode with batch_size=256 hypotheses/step, fixed_beam_width 15, '
+                      'relative_beam_width 0.2, rejection_threshold 0.5, soft alignments returned'),
 }
 
 
 def decode_bench(args):
     import numpy as np
     wl = WORKLOADS[args.workload]
+    L, V = wl['length'], wl['voc']
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -249,7 +262,13 @@ def decode_bench(args):
     dist_on = world > 1 or bool(os.environ.get('CASV_BENCH_FORCE_DIST'))
     # CASV_BENCH_GATHER=native: barrier, all-gather and max-reduce through the C ABI's RCCL leg (casv_comm_*) instead of
     # torch.distributed -- no torch in the process at all
-    native = dist_on and os.environ.get('CASV_BENCH_GATHER') == 'native' and not os.environ.get('CASV_BENCH_DRY_RUN')
+    native = dist_on and os.environ.get('CASV_BENCH_GATHER') == 'native' and not dry
+    # Where the result records are packed: 'device' (default on the GPU paths) = by a kernel where the decode results
+    # already lie, the collective reads them there (casv_records_*); 'host' = from the returned strings, copied to the
+    # device for the collective (the only way for the gloo rehearsal and the dry run)
+    records = os.environ.get('CASV_BENCH_RECORDS', 'device')
+    if dry or (dist_on and not native and backend != 'nccl') or wl.get('confmat'):
+        records = 'host'
     comm = None
     if dist_on and not native:
         import torch
@@ -264,18 +283,24 @@ def decode_bench(args):
         else:
             dist.init_process_group(backend)
 
-    from cor_asv_ann_amd.synthetic import make_lines, make_vocabulary
+    from cor_asv_ann_amd.synthetic import make_lines, make_confmat_lines, make_vocabulary
     from cor_asv_ann_amd import sharding
     per_gpu, batch = (args.lines_per_gpu or wl['lines']), wl['batch']
     # weak scaling: the global job is world x per_gpu lines, rank r decodes lines [r*per_gpu, (r+1)*per_gpu)
-    all_lines, _ = make_lines(per_gpu * world, LENGTH, wl['seed'], voc_size=VOC)
+    if wl.get('confmat'):
+        all_lines = make_confmat_lines(per_gpu * world, L, wl['seed'], voc_size=V)
+    else:
+        all_lines, _ = make_lines(per_gpu * world, L, wl['seed'], voc_size=V)
     lo, hi = sharding.shard_bounds(len(all_lines), world, rank)
     lines = all_lines[lo:hi]
-    S = 2 * (LENGTH + 1)
+    per_rank = -(-len(all_lines) // world)
+    S = 2 * (L + 1)
     device = ('cuda:%d' % local_rank) if (dist_on and backend == 'nccl') else None
+    want_align = bool(args.alignments) or bool(wl.get('alignments'))
     eng = None
+    t_realign = [0.0]
     if dry:
-        mapping = make_vocabulary(VOC)
+        mapping = make_vocabulary(V)
         lut = np.full(max(ord(c) for c in mapping[0] if c) + 2, -1, np.int32)
         for c, i in mapping[0].items():
             if c:
@@ -286,7 +311,10 @@ def decode_bench(args):
             return chunk, [[1.0] * len(t) for t in chunk], [0.0] * len(chunk)
         sync_dev = lambda: None
     else:
-        s2s, cfg, weights = make_model(local_rank, wl['depth'], wl['width'], wl['n'], wl['emb'])
+        s2s, cfg, weights = make_model(local_rank, wl['depth'], wl['width'], wl['n'], wl['emb'], V)
+        for key in ('rejection', 'beam_width_in', 'beam_threshold_in'):
+            if key in wl:
+                setattr(s2s, 'rejection_threshold' if key == 'rejection' else key, wl[key])
         eng = s2s._require_engine()
         if args.graph:
             eng.set_option('graph', 1)
@@ -300,21 +328,43 @@ def decode_bench(args):
             comm = sharding.NativeComm(eng, rank, world)
 
         def decode(chunk):
-            out, probs, scores, al = s2s.correct_lines(chunk, fast=wl['fast'], greedy=wl['fast'], alignments=bool(args.alignments))
+            if wl.get('confmat'):
+                out, probs, scores, al = s2s.correct_lines(chunk, conf=chunk, fast=False, greedy=False, alignments=want_align)
+                if want_align:
+                    # the wrapper's next step on every line: hard path from the soft alignment (transcode.py:126), here on
+                    # the windows the device returned
+                    from cor_asv_ann_amd.realign import alignment2path
+                    t0 = time.perf_counter()
+                    for line, text, a in zip(chunk, out, al):
+                        if len(a):
+                            alignment2path(a, sum(max((len(x[0]) for x in c), default=0) for c in line), len(text), 1. / V)
+                    t_realign[0] += time.perf_counter() - t0
+                return out, probs, scores
+            out, probs, scores, al = s2s.correct_lines(chunk, fast=wl['fast'], greedy=wl['fast'], alignments=want_align)
             return out, probs, scores
         sync_dev = eng.synchronize
     t_gather = [0.0]
 
     def step():
         out_lines, probs, scores = [], [], []
+        if dist_on and records == 'device':
+            eng.records_reset(per_rank, S)
         for b0 in range(0, len(lines), batch):
             o, p, s = decode(lines[b0:b0 + batch])
+            if dist_on and records == 'device':
+                if eng.B != len(o):             # (correct_lines decodes in several chunks only under a memory budget)
+                    raise RuntimeError('the last decode call covered %d of %d lines: records must be appended per decode call' % (eng.B, len(o)))
+                eng.records_append(b0)          # a small kernel behind the decode, on the same stream
             out_lines += o; probs += p; scores += s
         if dist_on:
             # fixed-width records (characters, probabilities, length, score) -> RCCL all-gather
             t0 = time.perf_counter()
-            rec = sharding.records_from_lines(out_lines, probs, scores, lut, S)
-            got = comm.all_gather_records(rec, len(all_lines)) if comm else sharding.all_gather_records(rec, len(all_lines), device=device)
+            if records == 'device':
+                got = comm.all_gather_device_records(len(all_lines)) if comm else \
+                    sharding.all_gather_device_records(eng, len(all_lines), device)
+            else:
+                rec = sharding.records_from_lines(out_lines, probs, scores, lut, S)
+                got = comm.all_gather_records(rec, len(all_lines)) if comm else sharding.all_gather_records(rec, len(all_lines), device=device)
             t_gather[0] += time.perf_counter() - t0
             return got
         return out_lines
@@ -336,6 +386,7 @@ def decode_bench(args):
     if eng:
         eng.profile(2)      # HIP events around the launches of the dominant kernel, on the library's stream
     t_gather[0] = 0.0
+    t_realign[0] = 0.0
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -344,6 +395,7 @@ def decode_bench(args):
     mine = time.perf_counter() - t0                       # this rank's own time, before it waits for the others
     sync()
     elapsed = time.perf_counter() - t0
+    realign_ms = 1e3 * t_realign[0] / max(args.steps, 1)
     prof, others = None, {}
     if eng:
         prof = eng.profile_read(dom)
@@ -352,11 +404,11 @@ def decode_bench(args):
         sync()
         others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'lstm_gemm_small', 'gemm', 'attention', 'softmax', 'beam', 'embed', 'persist')}
         eng.profile(False)
-    per_rank = [mine]
+    per_rank_s = [mine]
     gather_ms = 1e3 * t_gather[0] / max(args.steps, 1)
     if comm:
         elapsed = comm.max(elapsed)
-        per_rank = [mine] * world                 # (the per-rank times are not gathered on this path)
+        per_rank_s = [mine] * world               # (the per-rank times are not gathered on this path)
     elif dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device or 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -364,30 +416,38 @@ def decode_bench(args):
         tt = torch.zeros(world, dtype=torch.float64, device=device or 'cpu')
         tt[rank] = mine
         dist.all_reduce(tt)
-        per_rank = [float(x) for x in tt.cpu()]
+        per_rank_s = [float(x) for x in tt.cpu()]
 
     result = None
     if rank == 0:
-        chars = len(all_lines) * LENGTH * args.steps
-        fpc = survey_flop_per_char(wl['depth'], wl['width'], wl['n'])
-        qpc = survey_hbm_bytes_per_char(wl['depth'], wl['width'], wl['n'])
+        chars = len(all_lines) * L * args.steps
+        fpc = survey_flop_per_char(wl['depth'], wl['width'], wl['n'], V, L)
+        qpc = survey_hbm_bytes_per_char(wl['depth'], wl['width'], wl['n'], V, L)
         result = {
             'metric': METRIC if args.workload in ('c3', 'c5') else
-                      'corrected chars/sec (1 GPU) greedy, depth-2 width-256, 100-char lines',
+                      ('corrected chars/sec (1 GPU) greedy, depth-2 width-256, 100-char lines' if args.workload == 'c2' else
+                       'corrected chars/sec (1 GPU), OCR-D processor call: depth-2 width-512 V=640, beamed N=256, 40-line pages'),
             'value': chars / elapsed, 'unit': 'chars/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'dry-run (no decoding)' if dry else 'synthetic',
             'config': {'workload': wl['text'] + ', 2T=%d steps max, synthetic weights seed 20250614 emb_scale=%g' % (S, wl['emb']),
-                       'lines_per_gpu': per_gpu, 'lines_per_decode_call': batch, 'line_length': LENGTH, 'beam_n': wl['n'],
-                       'parallelism': 'lines sharded x%d' % world, 'gather': 'casv_comm (RCCL, C ABI)' if comm else ('torch.distributed/' + backend if dist_on else 'none'), 'graph': bool(args.graph), 'alignments': bool(args.alignments),
+                       'lines_per_gpu': per_gpu, 'lines_per_decode_call': batch, 'line_length': L, 'beam_n': wl['n'],
+                       'parallelism': 'lines sharded x%d' % world,
+                       'gather': 'casv_comm (RCCL, C ABI)' if comm else ('torch.distributed/' + backend if dist_on else 'none'),
+                       'records': (records + '-packed') if dist_on else 'none',
+                       'graph': bool(args.graph), 'alignments': want_align,
                        'launcher': 'bench.py' if os.environ.get('CASV_BENCH_CHILD') else
                                    ('torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ else 'direct')},
-            'ms_per_step_by_rank': [1e3 * x / args.steps for x in per_rank],
+            'ms_per_step_by_rank': [1e3 * x / args.steps for x in per_rank_s],
             'gather_ms_per_step': gather_ms if dist_on else 0.0,
         }
+        if wl.get('confmat') and want_align:
+            result['realign_ms_per_step'] = realign_ms       # inside ms_per_step: host time of the Viterbi re-alignment
         if dist_on:
             result['gathered_records'] = int(last.shape[0])
-        if prof is not None:
+            if args.dump_records:
+                np.save(args.dump_records, np.asarray(last, np.int32))
+        if prof is not None and prof['launches']:
             achieved = prof['flops'] / max(prof['ms'], 1e-9) / 1e9            # TFLOP/s
             traffic = None
             try:
@@ -395,6 +455,8 @@ def decode_bench(args):
                     traffic = json.load(f).get('hbm_bytes_per_launch')
             except Exception:
                 pass
+            if args.workload == 'page':
+                traffic = None          # the committed PMC passes were taken on the c3 shapes
             result['roofline'] = {
                 'bound': 'mfma',
                 'kernel': 'gemm_kernel<EPI_LSTM, 1> (fused LSTM-cell GEMM, 128x128 tiles, fp32 MFMA)' if dom == 'lstm_gemm'
@@ -412,16 +474,55 @@ def decode_bench(args):
                                'hbm_bytes_per_char': qpc,
                                'hbm_frac': chars / elapsed * qpc / world / PEAK_HBM_BYTES_PER_S}}
             result['kernel_ms_per_step'] = {k: v['ms'] for k, v in others.items()}     # from one extra untimed step
-        if world == 1 and not args.no_cpu_baseline and not dry:
-            result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64], wl['n'] if not wl['fast'] else 256, wl['fast'])
+        if world == 1 and not args.no_cpu_baseline and not dry and not wl.get('confmat'):
+            result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64], wl['n'] if not wl['fast'] else 256, wl['fast'], L)
     if comm:
         comm.close()
     elif dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if eng is not None:
+        s2s.engine.close()              # free the device memory before the other workloads run as child processes
+        s2s.engine = None
     if rank == 0:
+        if world == 1 and not dist_on and args.workload == 'c3' and not args.no_others and not dry:
+            result['other_workloads'] = other_workloads()
         print(json.dumps(result))
     return 0
+
+
+def other_workloads():
+    """The other single-GPU workloads, each as a child process of this (finished) run so that the driver's one default
+    invocation times them too: configs[1] (c2), configs[3] (c4) and the OCR-D processor's call (page).  Bounded: a few
+    steps each, no CPU baseline; a workload that fails reports its error instead of failing the headline."""
+    out = {}
+    for name, extra in (('c2', ['--steps', '20', '--warmup', '3']), ('c4', ['--steps', '5', '--warmup', '2']),
+                        ('page', ['--steps', '3', '--warmup', '1'])):
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--no-cpu-baseline', '--no-others'] + extra
+        env = {k: v for k, v in os.environ.items() if not k.startswith('CASV_BENCH_')}
+        try:
+            t0 = time.perf_counter()
+            proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            line = [x for x in proc.stdout.decode().splitlines() if x.startswith('{')]
+            if proc.returncode != 0 or not line:
+                out[name] = {'error': 'exit code %d: %s' % (proc.returncode, proc.stderr.decode()[-300:])}
+                continue
+            r = json.loads(line[-1])
+            keep = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype') if k in r}
+            keep['workload'] = r['config']['workload']
+            if 'roofline' in r:
+                keep['roofline'] = {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_us')
+                                    if k in r['roofline']}
+                if 'whole_path' in r['roofline']:
+                    keep['roofline']['whole_path_frac'] = r['roofline']['whole_path']['frac']
+            for k in ('kernel_ms_per_step', 'realign_ms_per_step'):
+                if k in r:
+                    keep[k] = r[k]
+            keep['wall_s'] = time.perf_counter() - t0
+            out[name] = keep
+        except Exception as err:            # a measurement aid must not take the headline down
+            out[name] = {'error': repr(err)}
+    return out
 
 
 def main():
@@ -430,21 +531,30 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-others', action='store_true', help='do not time c2 / c4 / page after the default c3 run')
     ap.add_argument('--graph', type=int, default=0, help='replay the decode step from a hipGraph')
-    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'],
-                    help='c3 = beamed decode (the BASELINE metric, default); c2 = greedy decode (configs[1]); '
-                         'c4 = train step (configs[3]); c5 = 8192 lines per GPU per step (configs[4])')
+    ap.add_argument('--workload', default=None, choices=['c2', 'c3', 'c4', 'c5', 'page'],
+                    help='c3 = beamed decode (the BASELINE metric; default on one GPU); c5 = 8192 lines per GPU per step '
+                         '(configs[4]; default with --gpus > 1); c2 = greedy decode (configs[1]); c4 = train step (configs[3]); '
+                         'page = the OCR-D processor call (40 confusion-network lines, 256 hypotheses per step, alignments)')
     ap.add_argument('--lines-per-gpu', type=int, default=0, help='override the lines each GPU decodes per step')
     ap.add_argument('--alignments', type=int, default=0,
                     help='1 = also return the soft alignments (window form), as the OCR-D processor asks for (wrapper/transcode.py:110-115)')
+    ap.add_argument('--dump-records', default=None, help='rank 0 saves the gathered records of the last step to this .npy file (tests)')
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error('--gpus must be positive')
+    if args.workload is None:
+        # BASELINE configs[4] is what the multi-GPU metric is quoted on: 64k lines over 8 GPUs = 8192 per GPU per step
+        args.workload = 'c5' if (args.gpus > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1) else 'c3'
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
-        if args.workload == 'c4':
-            ap.error('the train step (c4) is a single-GPU workload')
+        if args.workload in ('c4', 'page'):
+            ap.error('the train step (c4) and the page call are single-GPU workloads')
         os.environ['CASV_BENCH_CHILD'] = '1'
-        return launch_ranks(args.gpus, sys.argv[1:])
+        argv = sys.argv[1:]
+        if '--workload' not in argv:
+            argv = argv + ['--workload', args.workload]
+        return launch_ranks(args.gpus, argv)
     if args.workload == 'c4':
         return train_bench(args)
     return decode_bench(args)

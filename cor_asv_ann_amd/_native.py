@@ -67,6 +67,11 @@ SIGNATURES = {
     'casv_comm_all_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     'casv_comm_all_reduce_max': (c_int, [c_void_p, POINTER(c_double)]),
     'casv_comm_destroy': (c_int, [c_void_p]),
+    'casv_records_reset': (c_int, [c_void_p, c_int32, c_int32]),
+    'casv_records_append': (c_int, [c_void_p, c_int32]),
+    'casv_records_read': (c_int, [c_void_p, c_void_p]),
+    'casv_records_device_ptr': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    'casv_comm_all_gather_records': (c_int, [c_void_p, c_void_p]),
     'casv_get_stat': (c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
     'casv_synchronize': (c_int, [c_void_p]),
 }

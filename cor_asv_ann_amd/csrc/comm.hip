@@ -76,6 +76,22 @@ extern "C" int casv_comm_all_gather(casv_model* m, const void* send, void* recv,
     return CASV_OK;
 }
 
+// The all-gather of SURVEY.md section 8e straight from the device: every rank's record buffer (casv_records_reset /
+// casv_records_append: packed by a kernel where the decode results lie) -> all ranks' records on the host, rank-major.
+// No host-side packing and no host-to-device copy in front of the collective.
+extern "C" int casv_comm_all_gather_records(casv_model* m, int32_t* recv) {
+    if (!m || !recv) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->comm) return fail(CASV_ERR_STATE, "casv_comm_init first");
+    if (!m->rec.p || !m->rec_rows) return fail(CASV_ERR_STATE, "casv_records_reset first");
+    HIPCHK(hipSetDevice(m->device));
+    const size_t n = (size_t)m->rec_rows * (2 * m->rec_S + 4) * 4;
+    if (int rc = m->comm_recv.ensure(n * m->comm_world)) return rc;
+    NCHK(g_rccl.AllGather(m->rec.p, m->comm_recv.p, n, ncclChar, reinterpret_cast<ncclComm_t>(m->comm), m->stream));
+    HIPCHK(hipMemcpyAsync(recv, m->comm_recv.p, n * m->comm_world, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return CASV_OK;
+}
+
 extern "C" int casv_comm_all_reduce_max(casv_model* m, double* value) {
     if (!m || !value) return fail(CASV_ERR_ARG, "null argument");
     if (!m->comm) return fail(CASV_ERR_STATE, "casv_comm_init first");

@@ -181,6 +181,15 @@ void launch_softmax(const SoftmaxArgs& a, hipStream_t stream);
 void launch_embed_sparse(const float* E, const int* idx, const float* val, float* x0,
                          int rows, int A, int V, int W, hipStream_t stream);
 void launch_advance_step(int* step_ptr, hipStream_t stream);
+// Source of the result records of one decode call (pack_records_kernel): row j * row_mul of idx / prob [rows][S];
+// beam: len / score per row (len == 0: no finished hypothesis -> the input line src_idx [B][T][A], slot 0);
+// batched greedy: len == nullptr, the line ends at its first `eos`, empty input lines (src_idx / src_val) give empty records.
+struct RecordSrc {
+    const int* idx; const float* prob; const int* len; const double* score;
+    const int* src_idx; const float* src_val;
+    int B, S, T, A, row_mul, eos;
+};
+void launch_pack_records(const RecordSrc& r, int* rec, hipStream_t stream);
 void launch_scatter_rows(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,
                          int dst_row_mul, hipStream_t stream);
 

@@ -128,6 +128,68 @@ void launch_greedy_extract_sparse(const float* a_base, const int* win_store, int
     hipLaunchKernelGGL(greedy_extract_sparse_kernel, dim3((B * S + 255) / 256), dim3(256), 0, stream, a_base, win_store, B, S, T, sp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Result records of the lines of the last decode call, packed where the results already lie (what
+// crosses the GPUs is one all-gather of fixed-width records).  Record of a line = 2S + 4 int32:
+// [0,S) characters, [S,2S) probabilities (bit patterns), length, score (float64, 2 words), 1 -- the layout of
+// cor_asv_ann_amd/sharding.py::pack_records.  A line without a finished hypothesis falls back to its input
+// (correct_lines, seq2seq.py:826-836: the input characters with probability 1, score 0).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pack_records_kernel(const RecordSrc r, int* __restrict__ rec) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    if (j >= r.B) return;
+    const int S = r.S, W = 2 * S + 4;
+    int* out = rec + (long long)j * W;
+    const long long row = (long long)j * r.row_mul;
+    int len = 0;
+    double score = 0.0;
+    bool fallback = false;
+    if (r.len) {                                  // beam: the search's best result, or the fallback
+        len = r.len[row];
+        if (len > 0) score = r.score[row]; else fallback = true;
+    } else {                                      // batched greedy (seq2seq.py:1254-1263): up to the first end-of-line
+        int any = 0;
+        for (int k = lane; k < r.T * r.A; k += 64) any |= (r.src_idx[(long long)j * r.T * r.A + k] >= 0 && r.src_val[(long long)j * r.T * r.A + k] != 0.0f);
+        if (__any(any)) {
+            int first = S;
+            for (int s0 = 0; s0 < S && first == S; s0 += 64) {
+                const int s = s0 + lane;
+                const unsigned long long hit = __ballot(s < S && r.idx[row * S + s] == r.eos);
+                if (hit) first = s0 + __ffsll((long long)hit) - 1;
+            }
+            len = first < S ? first + 1 : S;
+            double acc = 0.0;
+            for (int s = lane; s < len; s += 64) acc += -log((double)r.prob[row * S + s]);
+            acc = wave_sum_d(acc);
+            score = acc / (double)(len > 0 ? len : 1);
+        }
+    }
+    if (fallback) {
+        for (int t = lane; t < r.T; t += 64) len += r.src_idx[((long long)j * r.T + t) * r.A] >= 0 ? 1 : 0;
+        len = (int)wave_sum((float)len);
+        len = len < S ? len : S;
+        for (int s = lane; s < S; s += 64) {
+            const int c = s < len ? r.src_idx[((long long)j * r.T + s) * r.A] : 0;
+            out[s] = c > 0 ? c : 0;
+            out[S + s] = s < len ? __float_as_int(1.0f) : 0;
+        }
+    } else {
+        for (int s = lane; s < S; s += 64) {
+            out[s] = s < len ? r.idx[row * S + s] : 0;
+            out[S + s] = s < len ? __float_as_int(r.prob[row * S + s]) : 0;
+        }
+    }
+    if (lane == 0) {
+        out[2 * S] = len;
+        const long long bits = __double_as_longlong(score);
+        out[2 * S + 1] = (int)(unsigned)(bits & 0xffffffffLL); out[2 * S + 2] = (int)(unsigned)((unsigned long long)bits >> 32);
+        out[2 * S + 3] = 1;
+    }
+}
+void launch_pack_records(const RecordSrc& r, int* rec, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_records_kernel, dim3(r.B), dim3(64), 0, stream, r, rec);
+}
+
 __global__ void advance_step_kernel(int* step_ptr) { *step_ptr += 1; }
 void launch_advance_step(int* step_ptr, hipStream_t stream) {
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, stream, step_ptr);

@@ -115,7 +115,7 @@ struct casv_model {
     DevBuf st_a, st_p, ctx, wq, logits, prev, pin, apos, amax1, d_step, d_line, d_nan;
     DevBuf o_idx, o_prob, o_align, st_win, sp_lo, sp_w;
     // what the last decode call left on the device (casv_get_alignments_sparse): 0 nothing, 1 greedy, 2 beam
-    int last_decode = 0, last_S = 0, last_rows = 0; unsigned long long last_signature = 0;
+    int last_decode = 0, last_S = 0, last_rows = 0, last_mode = 0; unsigned long long last_signature = 0;
     BeamState last_beam{}; BeamParams last_beam_params{};
     // beam
     DevBuf b_parent, b_chr, b_prob, b_cum, b_len, b_exp, b_k, b_rejpos, b_pos, b_is1, b_count, b_created;
@@ -132,6 +132,7 @@ struct casv_model {
     // configuration or any device buffer changes
     hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; std::string step_graph_key;
     void* comm = nullptr; int comm_rank = 0, comm_world = 1; DevBuf comm_send, comm_recv;     // RCCL communicator (comm.hip)
+    DevBuf rec; int rec_rows = 0, rec_S = 0;              // result records of this rank's lines, packed on the device (casv_records_*)
     int* pin_active = nullptr; hipEvent_t ev_active[2] = {nullptr, nullptr};   // beam decode: unfinished-line count, read one chunk behind
     int stat_beam[3] = {0, 0, 0};                         // last beam decode: most new hypotheses of one line in one step; rows stepped
                                                           // and distinct parent expansions among them (N <= 16 only)

@@ -65,7 +65,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     DevBuf* bufs[] = {&m->E, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
         &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->Hc, &m->cfin,
         &m->hfin, &m->u, &m->st_a, &m->st_p, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
-        &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->a0, &m->st_win, &m->sp_lo, &m->sp_w, &m->b_parent, &m->b_chr, &m->b_prob,
+        &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->a0, &m->rec, &m->st_win, &m->sp_lo, &m->sp_w, &m->b_parent, &m->b_chr, &m->b_prob,
         &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos, &m->b_pos, &m->b_is1, &m->b_count, &m->b_created,
         &m->b_gkey, &m->b_gid, &m->b_qkey, &m->b_qid, &m->b_qn, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_beamnode, &m->b_nact,
         &m->b_done, &m->b_steps, &m->b_active, &m->bo_idx, &m->bo_prob, &m->bo_len, &m->bo_score,
@@ -482,7 +482,8 @@ extern "C" int casv_get_encoder_outputs(casv_model* m, float* enc_out, float* st
 static unsigned long long decode_buffers_signature(const casv_model* m) {
     unsigned long long h = 1469598103934665603ull;
     for (const DevBuf* b : {&m->st_a, &m->st_win, &m->b_parent, &m->b_chr, &m->b_prob, &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos,
-                            &m->b_count, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_created})
+                            &m->b_count, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_created, &m->bo_idx, &m->bo_prob, &m->bo_len,
+                            &m->bo_score, &m->o_idx, &m->o_prob, &m->d_idx, &m->d_val})
         h = (h ^ (unsigned long long)(uintptr_t)b->p) * 1099511628211ull;
     return h;
 }
@@ -880,7 +881,7 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
         HIPCHK(hipStreamSynchronize(m->stream));
     }
     if (m->prof.on) m->prof.collect();
-    m->last_decode = 1; m->last_S = S; m->last_rows = B; m->last_signature = decode_buffers_signature(m);
+    m->last_decode = 1; m->last_S = S; m->last_rows = B; m->last_mode = mode; m->last_signature = decode_buffers_signature(m);
     (void)nanflag;
     if (nan_before_end && mode == 1) return fail(CASV_ERR_NAN, "All-NaN slice encountered");
     return CASV_OK;
@@ -1034,6 +1035,62 @@ extern "C" int casv_get_alignments_sparse(casv_model* m, int32_t K, int32_t* out
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_lo, sp.lo, n * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(out_w, sp.w, n * K * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return CASV_OK;
+}
+
+// ---- result records on the device (multi-GPU gather) ----
+extern "C" int casv_records_reset(casv_model* m, int32_t rows, int32_t S) {
+    if (!m) return fail(CASV_ERR_ARG, "null argument");
+    if (rows < 1 || S < 1 || S > 2 * CASV_MAX_T) return fail(CASV_ERR_ARG, "bad record buffer shape rows=%d S=%d", rows, S);
+    HIPCHK(hipSetDevice(m->device));
+    const size_t bytes = (size_t)rows * (2 * S + 4) * 4;
+    if (int rc = m->rec.ensure(bytes)) return rc;
+    HIPCHK(hipMemsetAsync(m->rec.p, 0, bytes, m->stream));
+    m->rec_rows = rows; m->rec_S = S;
+    return CASV_OK;
+}
+
+extern "C" int casv_records_append(casv_model* m, int32_t row_offset) {
+    if (!m) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->rec.p || !m->rec_rows) return fail(CASV_ERR_STATE, "casv_records_reset first");
+    if (!m->last_decode) return fail(CASV_ERR_STATE, "no decode call to take results from");
+    if (m->last_signature != decode_buffers_signature(m)) { m->last_decode = 0; return fail(CASV_ERR_STATE, "the decode results have been released"); }
+    if (m->last_S != m->rec_S) return fail(CASV_ERR_ARG, "the last decode ran %d steps, the record buffer holds %d", m->last_S, m->rec_S);
+    const int B = m->B;
+    if (row_offset < 0 || row_offset + B > m->rec_rows) return fail(CASV_ERR_ARG, "rows [%d, %d) outside the record buffer of %d rows", row_offset, row_offset + B, m->rec_rows);
+    HIPCHK(hipSetDevice(m->device));
+    RecordSrc r{};
+    r.B = B; r.S = m->last_S; r.T = m->T; r.A = m->A; r.eos = m->eos;
+    r.src_idx = m->d_idx.as<int>(); r.src_val = m->d_val.as<float>();
+    if (!r.src_idx || m->A < 1) return fail(CASV_ERR_STATE, "the lines of the last decode were not encoded by casv_encode");
+    if (m->last_decode == 2) {
+        r.idx = m->bo_idx.as<int>(); r.prob = m->bo_prob.as<float>(); r.len = m->bo_len.as<int>(); r.score = m->bo_score.as<double>();
+        r.row_mul = m->last_rows / B;                   // max_results rows per line, best first
+    } else {
+        if (m->last_mode != 0) return fail(CASV_ERR_STATE, "records are defined for the batched greedy mode (0) and the beam");
+        r.idx = m->o_idx.as<int>(); r.prob = m->o_prob.as<float>(); r.len = nullptr; r.score = nullptr; r.row_mul = 1;
+    }
+    launch_pack_records(r, m->rec.as<int>() + (size_t)row_offset * (2 * m->rec_S + 4), m->stream);
+    HIPCHK(hipGetLastError());
+    return CASV_OK;
+}
+
+extern "C" int casv_records_device_ptr(casv_model* m, void** ptr, int64_t* bytes) {
+    if (!m || !ptr) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->rec.p || !m->rec_rows) return fail(CASV_ERR_STATE, "casv_records_reset first");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));            // whoever reads through the pointer uses another stream
+    *ptr = m->rec.p;
+    if (bytes) *bytes = (int64_t)m->rec_rows * (2 * m->rec_S + 4) * 4;
+    return CASV_OK;
+}
+
+extern "C" int casv_records_read(casv_model* m, int32_t* out) {
+    if (!m || !out) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->rec.p || !m->rec_rows) return fail(CASV_ERR_STATE, "casv_records_reset first");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipMemcpyAsync(out, m->rec.p, (size_t)m->rec_rows * (2 * m->rec_S + 4) * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     return CASV_OK;
 }

@@ -241,6 +241,27 @@ class HipEngine(object):
         nv.check(self.lib.casv_get_alignments_sparse(self.handle, K, nv.ptr(lo), nv.ptr(w)))
         return lo, w
 
+    # -- result records on the device (sharding.py) ------------------------------------------
+    def records_reset(self, rows, steps):
+        """A zeroed device buffer of `rows` result records of `steps` steps (2*steps+4 int32 each)."""
+        self._rec_shape = (int(rows), 2 * int(steps) + 4)
+        nv.check(self.lib.casv_records_reset(self.handle, int(rows), int(steps)))
+
+    def records_append(self, row_offset):
+        """Pack the best result of every line of the last decode call into records [row_offset, row_offset + B)."""
+        nv.check(self.lib.casv_records_append(self.handle, int(row_offset)))
+
+    def records_read(self):
+        out = np.empty(self._rec_shape, np.int32)
+        nv.check(self.lib.casv_records_read(self.handle, nv.ptr(out)))
+        return out
+
+    def records_device_ptr(self):
+        """(device address, bytes) of the record buffer, after the handle's stream has drained."""
+        p, n = c_void_p(), c_int64()
+        nv.check(self.lib.casv_records_device_ptr(self.handle, byref(p), byref(n)))
+        return p.value, n.value
+
     def stat(self, key):
         v = c_int64()
         nv.check(self.lib.casv_get_stat(self.handle, key.encode(), byref(v)))

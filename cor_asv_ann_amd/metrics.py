@@ -20,8 +20,19 @@ What the reference computes (`lib/alignment.py:140-486`), restated here:
   code points of UAX #29.  For alphabetic scripts with European punctuation (the domain of this tool) that yields the
   same tokens; scripts that need dictionaries or per-script tables (Thai, CJK ideographs) come out one character per
   token.
+
+Deliberate divergences from the reference's EFFECTIVE behaviour (both pinned in tests/test_metrics.py):
+  * 'historic_latin' normalisation.  The reference's `normalize()` pops the single-code-point keys out of the module-global
+    `L2_HISTLAT_EQV` while it builds its translation table (alignment.py:318-320 `equivalences.pop(key)`), so only the very
+    FIRST string normalised in a process gets the single-character replacements (ligatures such as U+FB01, PUA letters,
+    macron -> tilde); every later call applies the multi-code-point replacements only.  `normalize_text` applies the whole
+    table on every call -- what the table is evidently for.  On text containing such characters the CER/WER of `evaluate()`
+    therefore differ from figures produced by the reference; `reference_quirks(True)` (or CASV_METRICS_REFERENCE_QUIRKS=1 in
+    the environment) reproduces the reference's process-global pop so that published numbers stay comparable.
+  * `splitwords` derives Word_Break classes from General_Category instead of uniseg's tables (above).
 """
 import logging
+import os
 import unicodedata
 from bisect import bisect_left, insort_left
 from difflib import SequenceMatcher
@@ -91,6 +102,16 @@ _L2_PAIRS = [
 L2_REPLACEMENTS = dict(_L2_PAIRS)
 
 
+# Compatibility with the reference's effective behaviour (module docstring): [enabled, single-character keys already popped]
+_QUIRKS = [os.environ.get('CASV_METRICS_REFERENCE_QUIRKS', '') == '1', False]
+
+
+def reference_quirks(enable=True):
+    """Reproduce (True) or not (False, default) the reference's process-global pop of the single-code-point replacements
+    (alignment.py:318-320); switching it on starts a fresh "process": the next string normalised is the first one."""
+    _QUIRKS[0], _QUIRKS[1] = bool(enable), False
+
+
 def normalize_text(seq, normalization=None, gtlevel=1):
     """alignment.py:309-326.  Lists (word tokens) are normalised element-wise."""
     if isinstance(seq, list):
@@ -101,6 +122,10 @@ def normalize_text(seq, normalization=None, gtlevel=1):
         if gtlevel >= 3:
             return seq
         single = {k: v for k, v in L2_REPLACEMENTS.items() if len(k) == 1}
+        if _QUIRKS[0]:
+            if _QUIRKS[1]:
+                single = {}              # the reference popped them from its global table during the first call
+            _QUIRKS[1] = True
         for key, value in L2_REPLACEMENTS.items():
             if len(key) > 1:
                 seq = seq.replace(key, value)        # multi-code-point keys first, in table order

@@ -87,6 +87,33 @@ def all_gather_records(rec, n_total, device=None, group=None):
     return np.concatenate(parts, axis=0)
 
 
+class _DeviceRecords(object):
+    """`__cuda_array_interface__` view of the engine's record buffer: lets torch wrap the device memory the library
+    packed the records into, without a copy."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': '<i4', 'data': (int(ptr), False), 'version': 2,
+                                         'strides': None}
+
+
+def all_gather_device_records(engine, n_total, device, group=None):
+    """The all-gather of `all_gather_records`, fed from the engine's device-resident record buffer (engine.records_reset /
+    records_append: every rank holds ceil(n_total / world) records, zero-padded): no host-side packing, no host-to-device
+    copy.  `device` = the torch device of this rank's GPU (the one the engine runs on)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    per = -(-n_total // world)
+    ptr, nbytes = engine.records_device_ptr()               # (waits for the engine's stream)
+    width = engine._rec_shape[1]
+    assert engine._rec_shape[0] == per and nbytes == per * width * 4
+    mine = torch.as_tensor(_DeviceRecords(ptr, (per, width)), device=device)
+    out = torch.empty((world * per, width), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    out = out.cpu().numpy().reshape(world, per, width)
+    return np.concatenate([out[r, :shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0]] for r in range(world)], axis=0)
+
+
 class NativeComm(object):
     """The all-gather of result records through the C ABI (`casv_comm_*`: RCCL on the model handle's device and stream) --
     no torch in the product path.  The 128-byte RCCL id travels from rank 0 to the others over a plain TCP socket
@@ -115,6 +142,18 @@ class NativeComm(object):
         mine[:rec.shape[0]] = rec
         out = np.empty((self.world * per, width), np.int32)
         self.nv.check(self.engine.lib.casv_comm_all_gather(self.engine.handle, self.nv.ptr(mine), self.nv.ptr(out), mine.nbytes))
+        out = out.reshape(self.world, per, width)
+        return np.concatenate([out[r, :shard_bounds(n_total, self.world, r)[1] - shard_bounds(n_total, self.world, r)[0]]
+                               for r in range(self.world)], axis=0)
+
+    def all_gather_device_records(self, n_total):
+        """The same from the engine's device-resident record buffer (engine.records_reset / records_append): the
+        collective reads the records where the pack kernel wrote them."""
+        per = -(-n_total // self.world)
+        width = self.engine._rec_shape[1]
+        assert self.engine._rec_shape[0] == per
+        out = np.empty((self.world * per, width), np.int32)
+        self.nv.check(self.engine.lib.casv_comm_all_gather_records(self.engine.handle, self.nv.ptr(out)))
         out = out.reshape(self.world, per, width)
         return np.concatenate([out[r, :shard_bounds(n_total, self.world, r)[1] - shard_bounds(n_total, self.world, r)[0]]
                                for r in range(self.world)], axis=0)

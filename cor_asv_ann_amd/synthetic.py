@@ -94,3 +94,23 @@ def make_lines(n, length, seed, voc_size=256):
     idx = np.concatenate([idx, np.ones((n, 1), dtype=idx.dtype)], axis=1).astype(np.int32)
     lines = [''.join(i_c[int(i)] for i in row) for row in idx]
     return lines, idx
+
+
+def make_confmat_lines(n, length, seed, voc_size=256):
+    """n synthetic confusion-network lines as the OCR-D wrapper hands them to `correct_lines(lines, conf=lines)`
+    (wrapper/transcode.py:236-277,110-115): a line is a list of chunks, a chunk a list of (characters, confidence)
+    alternatives, best first -- here single characters, 1 to 3 alternatives per position (60 % / 28 % / 12 %), the
+    confidences of a position summing to at most 1; the last chunk is the end of line.  `length` positions + '\n'."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    _, i_c = make_vocabulary(voc_size)
+    lines = []
+    for _ in range(n):
+        line = []
+        for _ in range(length):
+            k = int(rng.choice([1, 2, 3], p=[0.60, 0.28, 0.12]))
+            chars = rng.choice(np.arange(2, voc_size), size=k, replace=False)
+            conf = np.sort(rng.dirichlet(np.ones(k) * 0.7) * rng.uniform(0.7, 1.0))[::-1]
+            line.append([(i_c[int(c)], float(p)) for c, p in zip(chars, conf)])
+        line.append([('\n', 1.0)])
+        lines.append(line)
+    return lines

@@ -180,6 +180,21 @@ int casv_comm_all_gather(casv_model* m, const void* send, void* recv, int64_t by
 int casv_comm_all_reduce_max(casv_model* m, double* value);
 int casv_comm_destroy(casv_model* m);
 
+/* Result records packed on the device, so that the gather needs no host-side packing and no host-to-device copy: one record
+ * per line = 2S+4 int32 words -- S character indices, S probabilities (bit patterns), length, score (float64, 2 words), 1 --
+ * the layout of cor_asv_ann_amd/sharding.py.  casv_records_reset: a zeroed buffer of `rows` records of S steps on the handle's
+ * device; casv_records_append: the best result of every line of the LAST casv_decode_beam (max_results rows per line: the
+ * first) or casv_decode_greedy (mode 0) call goes to records [row_offset, row_offset + B) -- a line without a finished
+ * hypothesis gets what correct_lines falls back to (its input characters, probability 1, score 0; seq2seq.py:826-836), an
+ * empty padding line an empty record; casv_records_read: the buffer to the host; casv_records_device_ptr: its device address
+ * (after the handle's stream has drained) for a host program that runs the collective itself (torch.distributed);
+ * casv_comm_all_gather_records: RCCL all-gather of every rank's buffer, result (world * rows records, rank order) to the host. */
+int casv_records_reset(casv_model* m, int32_t rows, int32_t S);
+int casv_records_append(casv_model* m, int32_t row_offset);
+int casv_records_read(casv_model* m, int32_t* out);
+int casv_records_device_ptr(casv_model* m, void** ptr, int64_t* bytes);
+int casv_comm_all_gather_records(casv_model* m, int32_t* recv);
+
 /* Measurement support for bench.py: per-kernel HIP-event timing on the library's stream.
  * casv_profile(m, 1) starts recording for all kernel classes, casv_profile(m, 2) only for "lstm_gemm" (fewer
  * event records inside a timed region), casv_profile(m, 0) stops; casv_profile_read returns, for kernel class `name`

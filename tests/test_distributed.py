@@ -151,3 +151,94 @@ def test_bench_two_ranks_on_one_gpu():
     out = lines[0]
     assert out['n_gpus'] == 2 and out['gathered_records'] == 128 and out['data'] == 'synthetic'
     assert out['value'] > 0 and sum(out['kernel_ms_per_step'].values()) > 0 and len(out['ms_per_step_by_rank']) == 2
+
+
+def _c5_lines():
+    from cor_asv_ann_amd.synthetic import make_lines
+    import bench
+    wl = bench.WORKLOADS['c5']
+    return wl, make_lines(wl['lines'], wl['length'], wl['seed'], voc_size=wl['voc'])[0]
+
+
+@pytest.mark.gpu
+def test_one_rank_of_configs4_through_the_native_rccl_gather(tmp_path):
+    """BASELINE configs[4] as far as one GPU goes: ONE rank's share of the 64k-line job -- 8192 lines, decoded in eight
+    1024-line batches, result records packed on the device after every batch, ONE RCCL all-gather per step through the C
+    ABI (world = 1), exactly the code path rank r of `bench.py --gpus 8` runs.
+      * all 8192 records arrive, in line order;
+      * batch 3 (lines 3072..4095) equals those 1024 lines decoded alone (lines are independent units, SURVEY 8e);
+      * the device-packed records equal the records the host packs from the returned strings (the other gather path);
+      * a second run gives the same bits (determinism)."""
+    import numpy as np
+    from cor_asv_ann_amd import sharding
+    import bench
+    env = {'CASV_BENCH_FORCE_DIST': '1', 'CASV_BENCH_GATHER': 'native', 'MASTER_PORT': '29611'}
+    dump = str(tmp_path / 'rec.npy')
+    code, lines, err = _run_bench(env, '--workload', 'c5', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--dump-records', dump)
+    assert code == 0, err
+    out = lines[0]
+    assert out['gathered_records'] == 8192 and out['config']['lines_per_gpu'] == 8192 and out['config']['lines_per_decode_call'] == 1024
+    assert out['config']['gather'].startswith('casv_comm') and out['config']['records'] == 'device-packed'
+    assert out['metric'] == bench.METRIC and out['value'] > 0
+    rec = np.load(dump)
+    assert rec.shape == (8192, 2 * 202 + 4)
+    idx, prob, length, score, found = sharding.unpack_records(rec)
+    assert (length > 0).all() and (length <= 202).all() and (found == 1).all()
+
+    # batch 3 alone, through the facade, and the host-side packing of its strings
+    wl, all_lines = _c5_lines()
+    s2s, _, _ = bench.make_model(0, wl['depth'], wl['width'], wl['n'], wl['emb'], wl['voc'])
+    chunk = all_lines[3 * 1024:4 * 1024]
+    o, p, s, _ = s2s.correct_lines(chunk, fast=False, greedy=False, alignments=False)
+    want = sharding.records_from_lines(o, p, s, s2s._codepoint_lut(), 202)
+    assert np.array_equal(rec[3 * 1024:4 * 1024], want)
+    # ... and once more from the device, after a different batch has been through the same handle in between
+    eng = s2s._require_engine()
+    s2s.correct_lines(all_lines[:64], fast=False, greedy=False, alignments=False)
+    s2s.correct_lines(chunk, fast=False, greedy=False, alignments=False)
+    eng.records_reset(1024, 202)
+    eng.records_append(0)
+    assert np.array_equal(eng.records_read(), want)
+    s2s.engine.close()
+
+    dump2 = str(tmp_path / 'rec2.npy')
+    code, lines2, err = _run_bench(dict(env, MASTER_PORT='29613', CASV_BENCH_RECORDS='host'), '--workload', 'c5', '--steps', '1', '--warmup', '0',
+                                   '--no-cpu-baseline', '--dump-records', dump2)
+    assert code == 0, err
+    assert lines2[0]['config']['records'] == 'host-packed'
+    assert np.array_equal(np.load(dump2), rec)
+
+
+@pytest.mark.gpu
+def test_torch_rccl_gather_reads_the_device_records_in_place():
+    """The default gather of `bench.py --gpus N` (torch.distributed, backend nccl = RCCL) fed from the library's device-resident
+    record buffer through `__cuda_array_interface__`: one rank here, same code as rank r of N."""
+    code, lines, err = _run_bench({'CASV_BENCH_FORCE_DIST': '1', 'MASTER_PORT': '29615'}, '--workload', 'c5', '--lines-per-gpu', '256',
+                                  '--steps', '1', '--warmup', '0', '--no-cpu-baseline')
+    assert code == 0, err
+    out = lines[0]
+    assert out['gathered_records'] == 256 and out['config']['gather'] == 'torch.distributed/nccl' and out['config']['records'] == 'device-packed'
+
+
+@pytest.mark.gpu
+def test_two_gpus_over_real_rccl_when_the_box_has_them():
+    """`bench.py --gpus 2` over RCCL/xGMI -- runs wherever two devices are visible (the one-GPU lease of the build skips)."""
+    import cor_asv_ann_amd._native as nv
+    if nv.load().casv_device_count() < 2:
+        pytest.skip('one GPU on this box: the N > 1 RCCL launch is the driver\'s (8-GPU node)')
+    for gather in ('', 'native'):
+        code, lines, err = _run_bench({'CASV_BENCH_GATHER': gather} if gather else {}, '--gpus', '2', '--lines-per-gpu', '1024', '--steps', '1',
+                                      '--warmup', '1', '--no-cpu-baseline')
+        assert code == 0, err
+        out = lines[0]
+        assert out['n_gpus'] == 2 and out['gathered_records'] == 2048 and out['config']['records'] == 'device-packed'
+        assert len(out['ms_per_step_by_rank']) == 2
+
+
+def test_multi_gpu_launch_defaults_to_the_configs4_shape():
+    """`--gpus N > 1` without a --workload is BASELINE configs[4]: 8192 lines per GPU per step in 1024-line batches."""
+    code, lines, err = _run_bench({'CASV_BENCH_DRY_RUN': '1', 'CASV_BENCH_BACKEND': 'gloo'}, '--gpus', '2', '--steps', '1', '--warmup', '0')
+    assert code == 0, err
+    out = lines[0]
+    assert out['config']['lines_per_gpu'] == 8192 and out['gathered_records'] == 16384 and 'configs[4]' in out['config']['workload']
+    assert out['config']['lines_per_decode_call'] == 1024

@@ -120,3 +120,24 @@ def test_word_segmentation():
     assert ''.join(words('Any text; re-joins: exactly!\n')) == 'Any text; re-joins: exactly!\n'
     assert splitwords('אב"ג カタカナ') == ['אב"ג', 'カタカナ']
     assert all(unicodedata.category(w[0])[0] in 'LN' for w in splitwords('Die 3 Haſen, und der Igel!'))
+
+
+def test_historic_latin_normalisation_and_the_reference_quirk():
+    """The reference pops the single-code-point replacements out of its global table during the first normalisation of a
+    process (alignment.py:318-320), so only that first string gets them.  Here every call applies the whole table; the
+    compatibility switch reproduces the reference's effective behaviour (cor_asv_ann_amd/metrics.py docstring)."""
+    from cor_asv_ann_amd import metrics
+    lig, plain = 'de\ufb01nire', 'definire'                    # U+FB01 LATIN SMALL LIGATURE FI: a single-code-point key
+    assert metrics.normalize_text(lig, 'historic_latin') == plain
+    assert metrics.normalize_text(lig, 'historic_latin') == plain                       # ... on every call
+    a = metrics.Alignment(0)
+    assert a.get_adjusted_distance(lig + '\n', plain + '\n', normalization='historic_latin')[0] == 0
+    assert a.get_adjusted_distance(lig + '\n', plain + '\n', normalization='historic_latin')[0] == 0
+    metrics.reference_quirks(True)
+    try:
+        assert metrics.normalize_text(lig, 'historic_latin') == plain                   # the first string of the "process"
+        assert metrics.normalize_text(lig, 'historic_latin') == lig                     # popped: later strings keep the ligature
+        assert a.get_adjusted_distance(lig + '\n', plain + '\n', normalization='historic_latin')[0] > 0
+    finally:
+        metrics.reference_quirks(False)
+    assert metrics.normalize_text(lig, 'historic_latin') == plain
