@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
         const int plen = s.n_len[nbase + node];
         const double ppos = s.n_pos[nbase + node];
         const int pis1 = s.n_is1[nbase + node];
-        const double pos = s.apos[s.att_by_prev ? s.prev_cur[r] : r];
+        const double pos = s.apos[r];
         double mis = 0.0;
         int srcpos = 0;
         if (plen > 1) {
@@ -246,9 +246,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
         const int node = s.beam_node[r];
         const int plen = s.n_len[nbase + node];
         const double pcum = s.n_cum[nbase + node];
-        const int ai = s.att_by_prev ? s.prev_cur[r] : r;
-        const double pos = s.apos[ai];
-        const int is1 = s.amax1[ai];
+        const double pos = s.apos[r];
+        const int is1 = s.amax1[r];
         const int beampos = r_beampos[i], srcpos = r_srcpos[i];
         int rej = r_rej[i];
         float vals[VPL];
@@ -525,7 +524,7 @@ __global__ void beam_extract_kernel(const BeamState s, const BeamParams p, const
         for (int j = 0; j < len && j < s.S; ++j) {
             const int nd = chain[j];
             const int rp = s.n_rejpos[nbase + nd];
-            const float* src = o.a_base + (long long)s.n_exp[nbase + (o.by_parent ? s.n_parent[nbase + nd] : nd)] * s.T;
+            const float* src = o.a_base + (long long)s.n_exp[nbase + nd] * s.T;
             float* dst = o.align + (ob * s.S + j) * s.T;
             for (int t = tid; t < s.T; t += blockDim.x) dst[t] = rp >= 0 ? (t == rp ? 1.0f : 0.0f) : src[t];
         }
@@ -550,7 +549,7 @@ __global__ void beam_extract_sparse_kernel(const BeamState s, const BeamParams p
     for (int j = tid; j < len && j < s.S; j += blockDim.x) {
         const int nd = chain[j];
         const int rp = s.n_rejpos[nbase + nd];
-        const long long exp = s.n_exp[nbase + (o.by_parent ? s.n_parent[nbase + nd] : nd)];
+        const long long exp = s.n_exp[nbase + nd];
         float* w = sp.w + (ob * s.S + j) * sp.K;
         int lo;
         if (rp >= 0) {

@@ -226,10 +226,7 @@ struct BeamState {
     int* line_steps;            // [B]
     int* active_lines;          // [0] lines still searching, [1] statistic: most new keys of any line in any step
     // step io
-    int* prev;                  // [R] parent expansions of the NEXT step's rows (written by the step kernel)
-    // Attention computed ahead, per expansion (engine.hip, launch_step): apos / amax1 are then indexed by the expansion a row
-    // continues -- prev_cur[r], this step's parents (a different buffer from `prev`: another kernel reads it meanwhile)
-    const int* prev_cur; int att_by_prev;
+    int* prev;                  // [R]
     float* p_in;                // [R][V]
     const float* p_base;        // score store
     const float* logits;        // [R][Vp] of this step: the kernel turns them into the step's row of the score store itself
@@ -247,9 +244,6 @@ void beam_prof_dump(int steps);      // diagnostic build: phase times of the bea
 struct BeamOut {
     int* idx; float* prob; int* len; double* score; int* rejpos; float* align; int* n_found; int* n_steps;
     const float* a_base;
-    // attention computed ahead: the alignment of a node lies with the expansion its PARENT node was created in (a_base and
-    // the window store are then indexed by that expansion; the caller passes them shifted by one slot)
-    int by_parent;
 };
 void launch_beam_extract(const BeamState& s, const BeamParams& p, const BeamOut& o, hipStream_t stream);
 // Window form of the alignments: (lo, K weights) per result row and step; lo = -1 marks an all-NaN row.

@@ -114,12 +114,6 @@ struct casv_model {
     std::vector<DevBuf> st_h, st_c;
     DevBuf st_a, st_p, ctx, wq, logits, prev, pin, apos, amax1, d_step, d_line, d_nan;
     DevBuf o_idx, o_prob, o_align, st_win, sp_lo, sp_w;
-    // Beamed decode with the attention computed AHEAD (launch_step): context / position / one-hot flag per expansion, the
-    // second stream the attention rows run on beside logits + beam step, its fork / join events
-    DevBuf st_ctx, st_apos, st_amax1;
-    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int attn_ahead = 1;                                   // option "attn_ahead": 1 (default) on for eager beamed decoding, 0 off
-    bool aa = false, last_aa = false;                     // this / the last beamed decode used it
     // what the last decode call left on the device (casv_get_alignments_sparse): 0 nothing, 1 greedy, 2 beam
     int last_decode = 0, last_S = 0, last_rows = 0, last_mode = 0; unsigned long long last_signature = 0;
     BeamState last_beam{}; BeamParams last_beam_params{};

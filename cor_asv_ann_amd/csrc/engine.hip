@@ -80,8 +80,6 @@ extern "C" void casv_model_destroy(casv_model* m) {
     (void)casv_train_release(m);
     (void)casv_comm_destroy(m);
     if (m->pin_active) { (void)hipHostFree(m->pin_active); for (int k = 0; k < 2; ++k) (void)hipEventDestroy(m->ev_active[k]); }
-    for (DevBuf* b : {&m->st_ctx, &m->st_apos, &m->st_amax1}) b->release();
-    if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); (void)hipEventDestroy(m->ev_fork); (void)hipEventDestroy(m->ev_join); }
     if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
     if (m->step_graph) (void)hipGraphDestroy(m->step_graph);
     for (auto e : m->prof.pool) (void)hipEventDestroy(e);
@@ -496,15 +494,13 @@ static int ensure_session(casv_model* m, int R, int S) {
         if (int rc = m->st_h[n].ensure(slots * W * 4)) return rc;
         if (int rc = m->st_c[n].ensure(slots * W * 4)) return rc;
     }
-    // (one slot more for the alignment and window stores: with the attention computed ahead, slot q + 1 holds what the
-    // expansions of slot q hand to their children, slot 0 the initial alignment)
-    if (int rc = m->st_a.ensure((slots + R) * T * 4)) return rc;
+    if (int rc = m->st_a.ensure(slots * T * 4)) return rc;
     if (int rc = m->st_p.ensure(slots * Vp * 4)) return rc;
-    if (int rc = m->st_win.ensure((slots + R) * 4)) return rc;
+    if (int rc = m->st_win.ensure(slots * 4)) return rc;
     if (int rc = m->ctx.ensure((size_t)R * C * 4)) return rc;
     if (int rc = m->wq.ensure((size_t)R * W * 4)) return rc;
     if (int rc = m->logits.ensure((size_t)R * Vp * 4)) return rc;
-    if (int rc = m->prev.ensure((size_t)2 * R * 4)) return rc;      // two buffers: the parents of this step's and of the next step's rows
+    if (int rc = m->prev.ensure((size_t)R * 4)) return rc;
     if (int rc = m->pin.ensure((size_t)R * Vp * 4)) return rc;
     if (int rc = m->apos.ensure((size_t)R * 8)) return rc;
     if (int rc = m->amax1.ensure((size_t)R * 4)) return rc;
@@ -530,63 +526,15 @@ static int init_root(casv_model* m, int rows_per_line) {
     return 0;
 }
 
-// The attention rows of one launch (attention.py:526-575).  `aa_slot` < 0: the step's own attention (reads the parents'
-// alignment rows through `prev`, writes slot step + 1, context rows by row).  `aa_slot` >= 0: attention computed AHEAD for the
-// expansions of that slot (see launch_step) -- on the second stream, stores indexed by expansion, shifted by one slot.
-static void launch_attention_rows(casv_model* m, const int* prev, const int* line, int rows_per_line, const int* step_ptr, int step_imm,
-                                  const int* live, int aa_slot) {
-    const int W = m->W, C = m->C, T = m->T, R = m->R;
-    const bool ahead = aa_slot >= 0;
-    AttnArgs a{};
-    a.wq = m->wq.as<float>(); a.u = m->u.as<float>(); a.enc = m->enc_out; a.va = m->va.as<float>(); a.bv = m->bv.as<float>();
-    a.prev = prev; a.line = line; a.rows_per_line = rows_per_line;
-    a.R = R; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
-    a.step_ptr = step_ptr; a.step_imm = step_imm; a.nrows = nullptr;
-    a.u_line = (long long)T * W; a.u_time = W; a.enc_line = (long long)T * C; a.enc_time = C; a.win_out = nullptr;
-    if (ahead) {
-        a.a_base = m->st_a.as<float>() + (size_t)R * T;                  // slot q of this view = slot q + 1 of the store
-        a.win_store = m->st_win.as<int>() + R;
-        a.ctx = m->st_ctx.as<float>() + (size_t)aa_slot * R * C;
-        a.apos = m->st_apos.as<double>() + (size_t)aa_slot * R; a.amax1 = m->st_amax1.as<int>() + (size_t)aa_slot * R;
-        a.nact = nullptr; a.nact_group = 0;     // every row: the step kernel rewrites the live counts while these rows run
-    } else {
-        a.a_base = m->st_a.as<float>(); a.win_store = m->st_win.as<int>();
-        a.ctx = m->ctx.as<float>(); a.apos = m->apos.as<double>(); a.amax1 = m->amax1.as<int>();
-        a.nact = live; a.nact_group = m->skip_group;
-    }
-    hipStream_t st = ahead ? m->stream2 : m->stream;
-    const bool timed = m->prof.on && !m->prof.only_lstm;
-    const double win = 2.0 * m->cfg.window_width + 1;
-    hipEvent_t e0{}, e1{};
-    if (timed) {
-        e0 = m->prof.get(); (void)hipEventRecord(e0, st);
-        m->prof.flops[PC_ATTN] += (double)R * win * (4.0 * W + 2.0 * C); m->prof.bytes[PC_ATTN] += 4.0 * R * (win * (W + C) + W + 2.0 * T + C);
-        m->prof.launches[PC_ATTN] += 1;
-    }
-    launch_attention(a, st);
-    if (timed) { e1 = m->prof.get(); (void)hipEventRecord(e1, st); m->prof.recs.push_back({e0, e1, PC_ATTN}); }
-}
-
 // One decoder_model step on R rows (seq2seq.py:416-480).  beam=true reads the input rows from `pin`,
 // otherwise from the previous slot of the score store (the fed-back softmax, seq2seq.py:1252).
-//
-// m->aa (beamed decoding, eager launches): the attention is computed AHEAD.  attention_call (attention.py:526-575) reads the
-// cell's previous output h_{t-1} and the previous alignment -- both belong to the state a hypothesis inherits from the
-// expansion that created it (seq2seq.py:1438-1442,1521: every child of an expansion is handed the same `states`), not the
-// character fed in.  So the context, the alignment row and the position statistics of step s + 1 are a function of the
-// EXPANSION (s, r) alone: they are computed once per expansion, right after its top layer -- the query GEMM h'.W_a, then the
-// attention rows on a second stream beside the logits GEMM and the beam step kernel (three latency-bound kernels that were in
-// series with the GEMMs) -- and stored per expansion; the children gather context / position / flag through their parent
-// index like any other state.  The query leaves the launch of layer 1 (where its 256 tiles of K = W were an extra half round
-// behind the 1024 tiles of the layer).  Same arithmetic on the same operands: identical results (tested).
 static void launch_step(casv_model* m, bool beam, int mode, const int* line, int rows_per_line,
                         int* o_idx, float* o_prob, const int* step_ptr, int step_imm, bool softmax = true) {
-    const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, D = m->D, R = m->R;
+    const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
     const long long RW = (long long)R * W;
-    const bool aa = beam && m->aa && !step_ptr;
     // previous-step rows of the state stores: the beam gathers its parents' expansions through `prev`; without a beam
     // row r of step t simply continues row r of step t-1 (slot arithmetic, no index array and no kernel to fill one)
-    const int* prev = beam ? m->prev.as<int>() + (aa ? (size_t)(step_imm & 1) * R : 0) : nullptr;
+    const int* prev = beam ? m->prev.as<int>() : nullptr;
     auto hseg = [&](float* base, int off) {
         return beam ? mkseg(base, W, W, off, prev) : mkseg(base, W, W, off, nullptr, RW, 1, 0);
     };
@@ -600,19 +548,14 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         return mkseg(m->st_h[n - 1].as<float>(), W, W, 0, nullptr, RW, 1, 1);
     };
     auto xwidth = [&](int n) { return n == 1 ? Vp : W; };
-    // attention query: h . W_a + b_UW (attention.py:539).  Per step it is taken from the parents' h (`prev` rows of the slots
-    // before) and depends only on the previous step, so it shares the launch of layer 1 (a job with the plain epilogue)
-    // instead of waiting behind the lower layers; ahead, it is taken from this step's own output rows.
-    auto query = [&](bool ahead) {
-        GemmArgs gq{};
-        gq.nseg = 1;
-        gq.a[0] = ahead ? mkseg(m->st_h[D].as<float>(), W, W, 0, nullptr, RW, 1, 1) : hseg(m->st_h[D].as<float>(), 0);
-        gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W;
-        gq.out = mkslot(m->wq.as<float>(), W);
-        gq.step_ptr = step_ptr; gq.step_imm = step_imm;
-        gq.nact = live; gq.nact_group = m->skip_group;
-        return gq;
-    };
+    // attention query of this step: h_{t-1} . W_a + b_UW (attention.py:539) -- depends only on the previous step, so it
+    // shares the launch of layer 1 (a job with the plain epilogue) instead of waiting behind the lower layers
+    GemmArgs gq{};
+    gq.nseg = 1; gq.a[0] = hseg(m->st_h[D].as<float>(), 0);
+    gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W;
+    gq.out = mkslot(m->wq.as<float>(), W);
+    gq.step_ptr = step_ptr; gq.step_imm = step_imm;
+    gq.nact = live; gq.nact_group = m->skip_group;
     auto lower = [&](int n) {               // layer n < D on [x | h]
         GemmArgs g{};
         g.nseg = 2;
@@ -627,30 +570,34 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.nact = live; g.nact_group = m->skip_group;
         return g;
     };
-    if (aa) {
-        // the attention rows of the parents' expansions (previous step's launch on the second stream) must have landed before
-        // anything of this step runs: they then never share the chip with the GEMMs (measured: co-resident attention waves cost
-        // the GEMMs more than the attention takes alone)
-        (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
-        if (D >= 2) { GemmArgs g = lower(1); run_gemm(m, EPI_LSTM, g); }
+    if (D >= 2) {
+        GemmBatch b{};
+        b.g[0] = lower(1); b.g[1] = gq; b.g[1].epi_plain = 1; b.count = 2;
+        run_gemm_batch(m, EPI_LSTM, b);
     } else {
-        GemmArgs gq = query(false);
-        if (D >= 2) {
-            GemmBatch b{};
-            b.g[0] = lower(1); b.g[1] = gq; b.g[1].epi_plain = 1; b.count = 2;
-            run_gemm_batch(m, EPI_LSTM, b);
-        } else {
-            run_gemm(m, EPI_PLAIN, gq);
-        }
-        // the attention rows need only the query: ahead of the remaining layers
-        launch_attention_rows(m, prev, line, rows_per_line, step_ptr, step_imm, live, -1);
+        run_gemm(m, EPI_PLAIN, gq);
+    }
+    {   // the attention rows need only the query: ahead of the remaining layers, which can then share one launch
+        AttnArgs a{};
+        a.wq = m->wq.as<float>(); a.u = m->u.as<float>(); a.enc = m->enc_out; a.va = m->va.as<float>(); a.bv = m->bv.as<float>();
+        a.a_base = m->st_a.as<float>(); a.prev = prev; a.line = line; a.rows_per_line = rows_per_line;
+        a.ctx = m->ctx.as<float>(); a.R = R; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
+        a.step_ptr = step_ptr; a.step_imm = step_imm; a.apos = m->apos.as<double>(); a.amax1 = m->amax1.as<int>(); a.nrows = nullptr;
+        a.u_line = (long long)T * W; a.u_time = W; a.enc_line = (long long)T * C; a.enc_time = C; a.win_out = nullptr;
+        a.win_store = m->st_win.as<int>();
+        a.nact = live; a.nact_group = m->skip_group;
+        hipEvent_t ev{};
+        const double win = 2.0 * m->cfg.window_width + 1;
+        m->prof_begin(PC_ATTN, (double)R * win * (4.0 * W + 2.0 * C), 4.0 * R * (win * (W + C) + W + 2.0 * T + C), ev);
+        launch_attention(a, m->stream);
+        m->prof_end(PC_ATTN, ev);
     }
     GemmArgs gtop{};
     {   // top cell on [x | ctx] (attention.py:341-342, seq2seq.py:343-349)
         GemmArgs& g = gtop;
         g.nseg = 3;
         g.a[0] = xseg(D);
-        g.a[1] = aa ? mkseg(m->st_ctx.as<float>(), C, C, xwidth(D), prev) : mkseg(m->ctx.as<float>(), C, C, xwidth(D));
+        g.a[1] = mkseg(m->ctx.as<float>(), C, C, xwidth(D));
         g.a[2] = hseg(m->st_h[D].as<float>(), xwidth(D) + C);
         g.Bt = m->dec[D].wt.as<float>(); g.bias = m->dec[D].bias.as<float>();
         g.M = R; g.N = 4 * W; g.Ktot = xwidth(D) + C + W;
@@ -662,15 +609,6 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
     }
     for (int n = 2; n < D; ++n) { GemmArgs g = lower(n); run_gemm(m, EPI_LSTM, g); }
     run_gemm(m, EPI_LSTM, gtop);
-    if (aa) {
-        // query of the NEXT step from this step's h', then its attention rows on the second stream
-        GemmArgs gq = query(true);
-        run_gemm(m, EPI_PLAIN, gq);
-        (void)hipEventRecord(m->ev_fork, m->stream);
-        (void)hipStreamWaitEvent(m->stream2, m->ev_fork, 0);
-        launch_attention_rows(m, prev, line, rows_per_line, nullptr, step_imm, live, step_imm + 1);
-        (void)hipEventRecord(m->ev_join, m->stream2);
-    }
     {   // tied output projection (seq2seq.py:379)
         GemmArgs g{};
         g.nseg = 1; g.a[0] = mkseg(m->st_h[D].as<float>(), W, W, 0, nullptr, RW, 1, 1);
@@ -691,21 +629,6 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         launch_softmax(a, m->stream);
         m->prof_end(PC_SOFTMAX, ev);
     }
-}
-
-// Attention ahead for the ROOT expansions (slot 0), before the first step: query from the encoder's final state of the top
-// layer, previous alignment = the initial one (slot 0 of the alignment store).
-static void launch_root_attention(casv_model* m, int rows_per_line) {
-    const int W = m->W, D = m->D, R = m->R;
-    GemmArgs gq{};
-    gq.nseg = 1; gq.a[0] = mkseg(m->st_h[D].as<float>(), W, W, 0);
-    gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W;
-    gq.out = mkslot(m->wq.as<float>(), W);
-    run_gemm(m, EPI_PLAIN, gq);
-    (void)hipEventRecord(m->ev_fork, m->stream);
-    (void)hipStreamWaitEvent(m->stream2, m->ev_fork, 0);
-    launch_attention_rows(m, nullptr, nullptr, rows_per_line, nullptr, -1, nullptr, 0);
-    (void)hipEventRecord(m->ev_join, m->stream2);
 }
 
 extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, const float* p_in,
@@ -982,20 +905,6 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     const int B = m->B, T = m->T, R = B * N, MR = bp->max_results;
     m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, R, S)) return rc;
-    // attention computed ahead, per expansion (launch_step): eager launches only (a captured graph's kernels cannot alternate
-    // between the two parent-index buffers)
-    m->aa = m->attn_ahead != 0 && !(m->use_graph && !m->prof.on);
-    if (m->aa) {
-        const size_t slots = (size_t)(S + 1) * R;
-        if (int rc = m->st_ctx.ensure(slots * m->C * 4)) return rc;
-        if (int rc = m->st_apos.ensure(slots * 8)) return rc;
-        if (int rc = m->st_amax1.ensure(slots * 4)) return rc;
-        if (!m->stream2) {
-            HIPCHK(hipStreamCreate(&m->stream2));
-            HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
-        }
-    }
     if (int rc = init_root(m, N)) return rc;
     BeamState s{};
     s.B = B; s.T = T; s.V = m->V; s.S = S; s.R = R;
@@ -1024,10 +933,8 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     s.f_key = m->b_fkey.as<double>(); s.f_id = m->b_fid.as<int>(); s.f_n = m->b_fn.as<int>(); s.f_total = m->b_ftotal.as<int>();
     s.beam_node = m->b_beamnode.as<int>(); s.nact = m->b_nact.as<int>();
     s.line_done = m->b_done.as<int>(); s.line_steps = m->b_steps.as<int>(); s.active_lines = m->b_active.as<int>();
-    s.prev = m->prev.as<int>(); s.prev_cur = m->prev.as<int>(); s.att_by_prev = m->aa ? 1 : 0;
-    s.p_in = m->pin.as<float>(); s.p_base = m->st_p.as<float>();
-    s.apos = m->aa ? m->st_apos.as<double>() : m->apos.as<double>(); s.amax1 = m->aa ? m->st_amax1.as<int>() : m->amax1.as<int>();
-    s.src_rej = m->d_srcrej.as<int>();
+    s.prev = m->prev.as<int>(); s.p_in = m->pin.as<float>(); s.p_base = m->st_p.as<float>();
+    s.apos = m->apos.as<double>(); s.amax1 = m->amax1.as<int>(); s.src_rej = m->d_srcrej.as<int>();
     s.step_ptr = m->d_step.as<int>();
     BeamParams p{};
     p.N = N; p.width_in = bp->beam_width_in; p.width_out = bp->beam_width_out; p.max_results = MR;
@@ -1037,18 +944,13 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     // extra load per workgroup from the start when a line's N rows span whole tiles (beams fill up over the first
     // steps), otherwise once a line has finished; not under graph replay, whose kernel arguments are fixed at capture.
     m->skip_nact = (N >= 128 && !m->use_graph) ? m->b_nact.as<int>() : nullptr; m->skip_group = N;
-    launch_beam_init(s, p, m->stream);              // (fills the first of the two parent-index buffers)
-    if (m->aa) launch_root_attention(m, N);
+    launch_beam_init(s, p, m->stream);
     auto body = [&](const int* step_ptr, int step_imm) {
         launch_step(m, true, -1, nullptr, N, nullptr, nullptr, step_ptr, step_imm, false);
         hipEvent_t ev{};
         m->prof_begin(PC_BEAM, 0.0, 4.0 * R * (2.0 * m->Vp), ev);
         BeamState sb = s;
         sb.step_ptr = step_ptr; sb.step_imm = step_imm; sb.logits = m->logits.as<float>();
-        if (m->aa && !step_ptr) {      // this step's parents / the next step's: alternate buffers
-            sb.prev_cur = m->prev.as<int>() + (size_t)(step_imm & 1) * R;
-            sb.prev = m->prev.as<int>() + (size_t)((step_imm + 1) & 1) * R;
-        } else sb.att_by_prev = 0;
         launch_beam_step(sb, p, m->stream);
         m->prof_end(PC_BEAM, ev);
     };
@@ -1082,12 +984,10 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
         pending = slot; slot ^= 1;
     }
     m->skip_nact = nullptr; m->skip_group = 0;
-    if (m->aa) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));     // the last attention rows on the second stream
     BeamOut o{};
     o.idx = m->bo_idx.as<int>(); o.prob = m->bo_prob.as<float>(); o.len = m->bo_len.as<int>(); o.score = m->bo_score.as<double>();
     o.rejpos = m->bo_rej.as<int>(); o.align = out_align ? m->bo_align.as<float>() : nullptr; o.n_found = m->bo_found.as<int>();
-    o.n_steps = m->bo_nsteps.as<int>();
-    o.a_base = m->st_a.as<float>() + (m->aa ? (size_t)R * T : 0); o.by_parent = m->aa ? 1 : 0;
+    o.n_steps = m->bo_nsteps.as<int>(); o.a_base = m->st_a.as<float>();
     HIPCHK(hipMemsetAsync(m->bo_idx.p, 0, OR * S * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->bo_prob.p, 0, OR * S * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->bo_rej.p, 0xff, OR * S * 4, m->stream));
@@ -1107,8 +1007,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     HIPCHK(hipMemcpyAsync(m->stat_beam, m->b_active.as<int>() + 1, 12, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->prof.on) m->prof.collect();
-    m->last_decode = 2; m->last_S = S; m->last_rows = (int)OR; m->last_beam = s; m->last_beam_params = p; m->last_aa = m->aa;
-    m->aa = false;
+    m->last_decode = 2; m->last_S = S; m->last_rows = (int)OR; m->last_beam = s; m->last_beam_params = p;
     m->last_signature = decode_buffers_signature(m);
     return CASV_OK;
 }
@@ -1130,8 +1029,7 @@ extern "C" int casv_get_alignments_sparse(casv_model* m, int32_t K, int32_t* out
         HIPCHK(hipMemsetAsync(sp.lo, 0, n * 4, m->stream));
         HIPCHK(hipMemsetAsync(sp.w, 0, n * K * 4, m->stream));
         BeamOut o{};
-        o.a_base = m->st_a.as<float>() + (m->last_aa ? (size_t)m->last_beam.R * m->T : 0); o.by_parent = m->last_aa ? 1 : 0;
-        if (m->last_aa) sp.win_store = m->st_win.as<int>() + m->last_beam.R;
+        o.a_base = m->st_a.as<float>();
         launch_beam_extract_sparse(m->last_beam, m->last_beam_params, o, sp, m->stream);
     }
     HIPCHK(hipGetLastError());
@@ -1279,10 +1177,6 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
     if (!strcmp(key, "persistent")) {
         if (value < -1 || value > 1) return fail(CASV_ERR_ARG, "persistent must be -1 (by batch size), 0 (per-step kernels) or 1 (always)");
         m->persist_mode = (int)value; return CASV_OK;
-    }
-    if (!strcmp(key, "attn_ahead")) {
-        if (value < 0 || value > 1) return fail(CASV_ERR_ARG, "attn_ahead must be 0 (attention inside every step) or 1 (computed ahead, per expansion)");
-        m->attn_ahead = (int)value; return CASV_OK;
     }
     if (!strcmp(key, "eos")) {
         if (value < 0 || value >= m->V) return fail(CASV_ERR_ARG, "eos index %lld outside the vocabulary", (long long)value);

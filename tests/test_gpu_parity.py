@@ -232,38 +232,6 @@ def test_graph_replay_equals_eager():
     eng.close()
 
 
-@pytest.mark.parametrize('d,W,V,B,L,N,es', [(1, 64, 40, 7, 14, 4, 10.0), (2, 128, 64, 9, 20, 4, 16.0), (4, 128, 256, 6, 30, 8, 64.0),
-                                              (3, 96, 640, 5, 12, 32, 20.0), (2, 64, 96, 3, 10, 160, 12.0)])
-def test_attention_computed_ahead_equals_attention_inside_the_step(d, W, V, B, L, N, es):
-    """Beamed decoding computes the attention rows of step s + 1 per EXPANSION, right after its top layer (children share
-    their parent's state, seq2seq.py:1438-1442,1521), on a second stream beside logits + beam step (option "attn_ahead", the
-    default).  Same arithmetic on the same operands as the attention inside every step: every output -- characters,
-    probabilities, scores, rejection marks, dense alignment rows, window-form alignments, search statistics -- is identical
-    bit for bit, for all results of every line (incl. wide beams, where dead rows are skipped)."""
-    cfg = ModelConfig(depth=d, width=W, voc_size=V)
-    weights = make_weights(cfg, emb_scale=es)
-    _, idx = make_lines(B, L, 11, voc_size=V)
-    eng = _engine(cfg, weights)
-    res = {}
-    for mode in (0, 1, 0):
-        eng.set_option('attn_ahead', mode)
-        eng.encode(idx)
-        dense = eng.decode_beam(batch_size=N, max_results=3, want_align=True)
-        sparse = eng.decode_beam(batch_size=N, max_results=3, want_align='sparse')
-        res.setdefault(mode, []).append((dense, sparse))
-    (d0, s0), (d1, s1) = res[0][0], res[1][0]
-    for k in ('idx', 'prob', 'len', 'score', 'rej', 'n_found', 'n_steps'):
-        assert np.array_equal(d0[k], d1[k]), k
-        assert np.array_equal(s0[k], s1[k]), k
-    assert d0['len'].max() > 0
-    assert np.array_equal(d0['align'], d1['align'], equal_nan=True)
-    assert np.array_equal(s0['align_sparse'][0], s1['align_sparse'][0])
-    assert np.array_equal(s0['align_sparse'][1], s1['align_sparse'][1], equal_nan=True)
-    # ... and going back and forth between the two flows on one handle changes nothing
-    assert np.array_equal(res[0][1][0]['idx'], d0['idx']) and np.array_equal(res[0][1][0]['align'], d0['align'], equal_nan=True)
-    eng.close()
-
-
 def test_decoder_step_at_full_width_rows():
     """Three teacher-forced decoder steps at the metric's row count: R = 8192 rows (1024 lines x 8 hypotheses), depth 4,
     width 512 -- the shape at which the launcher takes 128x128 tiles in XCD-aware order with the three-segment
