@@ -318,7 +318,7 @@ def decode_bench(args):
         eng = s2s._require_engine()
         if args.graph:
             eng.set_option('graph', 1)
-        for opt in ('persistent', 'tile', 'attn_ahead'):      # A/B switches for experiments: CASV_OPT_<NAME>=value
+        for opt in ('persistent', 'tile'):      # A/B switches for experiments: CASV_OPT_<NAME>=value
             if os.environ.get('CASV_OPT_' + opt.upper()):
                 eng.set_option(opt, int(os.environ['CASV_OPT_' + opt.upper()]))
         lut = s2s._codepoint_lut()
@@ -473,6 +473,7 @@ def decode_bench(args):
                                # the other roofline of SURVEY 8(d): not the binding one at fp32
                                'hbm_bytes_per_char': qpc,
                                'hbm_frac': chars / elapsed * qpc / world / PEAK_HBM_BYTES_PER_S}}
+        if others:
             result['kernel_ms_per_step'] = {k: v['ms'] for k, v in others.items()}     # from one extra untimed step
         if world == 1 and not args.no_cpu_baseline and not dry and not wl.get('confmat'):
             result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64], wl['n'] if not wl['fast'] else 256, wl['fast'], L)
