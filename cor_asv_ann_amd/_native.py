@@ -9,6 +9,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libcor_asv_ann_hip.so')
+if os.environ.get('CASV_LIB_PATH'):          # measurement aid: A/B of two builds of the library on one box
+    LIB_PATH = os.environ['CASV_LIB_PATH']
 
 CASV_ERR_NAN = -5
 

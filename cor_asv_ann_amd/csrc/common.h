@@ -130,6 +130,16 @@ struct GemmBatch {
     int count;
 };
 
+// C[M][N] (+)= sum_k A[k][m] * B[k][n] for operands that lie K-major (gemm_tn.hip: weight gradients of the train step).
+// lda / ldb / M / N multiples of 4, 16-byte aligned bases; rows m >= Mstore are computed but not stored (padded operand).
+struct TnArgs {
+    const float* A; long long lda; const float* B; long long ldb; float* C; long long ldc;
+    int M, Mstore, N, K;
+    int accumulate;      // C += (gradient sums) instead of C =
+    int out_zeroed;      // C = with a split K: the caller has cleared C already
+    float* colsum;       // optional [Mstore]: += sum_k A[k][m] (the bias gradient that goes with a weight gradient)
+};
+void launch_gemm_tn(const TnArgs& g, hipStream_t stream);
 void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream);
 void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream);
 void launch_gemm_skinny(int epi, const GemmBatch& b, int ksplit, hipStream_t stream);

@@ -17,6 +17,8 @@
 // four MFMAs (the k order inside a tile is permuted identically for A and B, which a sum allows).
 // Small launches take the 32x128-tile variant of gemm_skinny.hip instead (plan_gemm; same values bit for bit).
 #include "common.h"
+#include <cstdlib>
+#include <cstdio>
 
 namespace casv {
 
@@ -114,6 +116,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         gt.a[0] = *reinterpret_cast<const f32x4*>(pa0); gt.a[1] = *reinterpret_cast<const f32x4*>(pa1);
         gt.b[0] = *reinterpret_cast<const f32x4*>(bp[0] + kb); gt.b[1] = *reinterpret_cast<const f32x4*>(bp[1] + kb);
     };
+    // The same four loads hidden from the compiler's wait bookkeeping (steady state only).  hipcc's s_waitcnt in front of
+    // the LDS store of tile kt + 2 counts in order and drains the loads of tile kt + 3 with it (issued one tile earlier):
+    // the prefetch was one tile deep for every second tile.  Issued from asm statements the loads are invisible to that
+    // bookkeeping; CASV_TILE_FULL waits with a counted vmcnt(4) instead -- the four loads of the tile about to be stored
+    // have landed, the four of the next tile stay in flight -- so every tile's operands have two tile times to arrive.
+    auto load_tile_asm = [&](GTile& gt, int kt_rel) {
+        const int kt = kt_rel * KS + grp + kt_begin;
+        const long long m1 = (kt >= c0 && kt < c1) ? -1LL : 0LL, m2 = (kt >= c1) ? -1LL : 0LL;
+        const int ko = kt - ((int)m1 & c0) - ((int)m2 & c1);
+        const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * BK;
+        const char* pa0 = (const char*)ap0[0] + (d1_0 & m1) + (d2_0 & m2) + (long long)ko * (BK * 4);
+        const char* pa1 = (const char*)ap0[1] + (d1_1 & m1) + (d2_1 & m2) + (long long)ko * (BK * 4);
+        const float* pb0 = bp[0] + kb; const float* pb1 = bp[1] + kb;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[0]) : "v"(pa0));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[1]) : "v"(pa1));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[0]) : "v"(pb0));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[1]) : "v"(pb1));
+    };
     auto store_tile = [&](const GTile& gt, int buf) {
         float* sa = smem + buf * 2 * TILE_FLOATS + r0 * LDW + 4 * kc;
         float* sb = sa + TILE_FLOATS;
@@ -175,14 +195,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     if (ntiles > 1) load_tile(g1, 1);
     if (ntiles > 0) store_tile(g0, 0);
     if (ntiles > 1) store_tile(g1, 1);
-    if (ntiles > 2) load_tile(g0, 2);
-    if (ntiles > 3) load_tile(g1, 3);
-    __syncthreads();
-    if (ntiles > 0) read_frags(f0, 0);
-    // The first steady-state step stores tile 2 into LDS buffer 0: every wave must have taken its fragments of tile 0
-    // out of it first.  (Without this barrier only the latency of the tile-2 global loads kept a fast wave's store
-    // behind a slow wave's read -- not enough once other kernels share the CU.)
-    __syncthreads();
 
     // Steady state (tiles kt+1..kt+4 exist, no conditionals): while the 32 MFMAs of tile kt issue from FC,
     //   LDS[kt&1] <- G (tile kt+2, requested two steps ago; the buffer's old content, tile kt, sits in FC)
@@ -191,8 +203,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     // so a wave has no memory-only phase in which its SIMD partner's MFMA stream starves its instruction issue.
 #define CASV_TILE_FULL(FC, FN, G, KT)                                                     \
     {                                                                                     \
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(G.a[0]), "+v"(G.a[1]), "+v"(G.b[0]), "+v"(G.b[1]));  \
         store_tile(G, (KT) & 1);                                                          \
-        load_tile(G, (KT) + 4);                                                           \
+        load_tile_asm(G, (KT) + 4);                                                       \
         read_frags(FN, ((KT) + 1) & 1);                                                   \
         mma(FC);                                                                          \
         _Pragma("unroll") for (int q_ = 0; q_ < 18; ++q_) {                               \
@@ -213,9 +226,29 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         __syncthreads();                                                                  \
     }
     int kt = 0;
-    for (; kt + 5 < nt_min; kt += 2) {          // both wave groups have all the tiles of the steady state
-        CASV_TILE_FULL(f0, f1, g0, kt)
-        CASV_TILE_FULL(f1, f0, g1, kt + 1)
+    if (nt_min > 5) {
+        // Tiles 2 and 3 are requested the hidden way already: a compiler-tracked load pending on ANY path into the loop would
+        // put a full vmcnt(0) at the loop head, executed in every iteration.  (The cell-state loads above are older than
+        // every tile load, so the counted waits cover them too.)
+        load_tile_asm(g0, 2); load_tile_asm(g1, 3);
+        __syncthreads();
+        read_frags(f0, 0);
+        // The first steady-state step stores tile 2 into LDS buffer 0: every wave must have taken its fragments of tile 0
+        // out of it first.  (Without this barrier only the latency of the tile-2 global loads kept a fast wave's store
+        // behind a slow wave's read -- not enough once other kernels share the CU.)
+        __syncthreads();
+        for (; kt + 5 < nt_min; kt += 2) {          // both wave groups have all the tiles of the steady state
+            CASV_TILE_FULL(f0, f1, g0, kt)
+            CASV_TILE_FULL(f1, f0, g1, kt + 1)
+        }
+        // loads issued by the asm statements are still in flight: they land before the compiler-scheduled rest touches them
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0.a[0]), "+v"(g0.a[1]), "+v"(g0.b[0]), "+v"(g0.b[1]), "+v"(g1.a[0]), "+v"(g1.a[1]), "+v"(g1.b[0]), "+v"(g1.b[1]));
+    } else {
+        if (ntiles > 2) load_tile(g0, 2);
+        if (ntiles > 3) load_tile(g1, 3);
+        __syncthreads();
+        if (ntiles > 0) read_frags(f0, 0);
+        __syncthreads();
     }
     for (; kt + 1 < nt_max; kt += 2) {          // same barrier count for both groups
         CASV_TILE_STEP(f0, f1, g0, kt)
@@ -374,6 +407,16 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
     const int grid = p.blocks * b.count * p.ksplit;
     p.skinny = g_tile_mode == 1 || (g_tile_mode < 0 && (grid <= 128 || (grid > ncu && grid < 2 * ncu)));
     if (p.skinny) p.ksplit = choose_ksplit(p.sblocks * b.count, 1024);
+    {   // experiment switch (measurement only): CASV_PLAN_SMALLM="skinny,ksplit" for split-K-able launches of at most 1024 rows
+        static const char* env = getenv("CASV_PLAN_SMALLM");
+        if (env && splittable && b.g[0].ksplit < 0 && b.g[0].M <= 1024) {
+            int sk = 0, ks = 1;
+            if (sscanf(env, "%d,%d", &sk, &ks) == 2) {
+                const int ktiles = count_ktiles(b.g[0]);
+                p.skinny = sk != 0; p.ksplit = ks < 1 ? 1 : (ks > ktiles ? ktiles : ks);
+            }
+        }
+    }
     return p;
 }
 bool gemm_is_skinny(int epi, const GemmBatch& b) { return plan_gemm(epi, b).skinny; }

@@ -39,7 +39,6 @@ struct TrainState {
     DevBuf e_idx, e_val, d_in, d_out, d_w, m_enc, m_dec, m_cell;
     DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, CTX, RecIn, prev, logits, dG, d_enc, du, DWQ, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
     std::vector<DevBuf> O, DO;             // masked layer outputs (encoder O[n], decoder DO[n])
-    DevBuf T1, T2, T3;                     // transposition scratch
     DevBuf loss, normsq;
     int find(const std::string& n) const { for (size_t i = 0; i < tens.size(); ++i) if (tens[i].name == n) return (int)i; return -1; }
     float* W_(int i) { return tens[i].w.as<float>(); }
@@ -109,7 +108,7 @@ int casv_train_release(casv_model* m) {
     DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
         &ts->m_cell, &ts->X0, &ts->H1, &ts->u, &ts->Y0, &ts->Ym, &ts->WQ, &ts->Ast, &ts->WIN, &ts->CTX, &ts->RecIn, &ts->prev,
         &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl, &ts->dYl, &ts->dOin, &ts->dcbuf2, &ts->dvaP, &ts->dbvP,
-        &ts->T1, &ts->T2, &ts->T3, &ts->loss, &ts->normsq};
+        &ts->loss, &ts->normsq};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : ts->O) b.release();
     for (auto& b : ts->DO) b.release();
@@ -193,6 +192,18 @@ static GemmArgs plain_gemm(const float* A, long long lda, int M, int K, const fl
     return g;
 }
 
+// C[M][N] += A^T . B for operands as the forward / backward passes left them: A [K][lda], B [K][ldb] (gemm_tn.hip)
+static void run_gemm_tn(casv_model* m, const float* A, long long lda, int M, int Mstore, const float* B, long long ldb, int N, long long K,
+                        float* C, long long ldc, float* colsum = nullptr) {
+    TnArgs g{};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.Mstore = Mstore; g.N = N; g.K = (int)K; g.accumulate = 1;
+    g.colsum = colsum;
+    hipEvent_t ev{};
+    m->prof_begin(PC_GEMM, 2.0 * Mstore * (double)N * (double)K, 4.0 * ((double)K * (M + N) + (double)Mstore * N), ev);
+    launch_gemm_tn(g, m->stream);
+    m->prof_end(PC_GEMM, ev);
+}
+
 // One recurrent step of a layer as a GEMM job; k = processing index (time t = k, or len-1-k when reversed).
 static GemmArgs layer_step_job(casv_model* m, TLayer& l, int k, const float* h0, const float* c0, const float* rec_in /*top cell*/) {
     TrainState* ts = m->train;
@@ -225,24 +236,16 @@ static void layer_input_gemm(casv_model* m, TLayer& l, const float* x, long long
     run_gemm(m, EPI_PLAIN, g);
 }
 
-// weight gradients of one layer from dZ (in l.Z), its inputs x and its recurrent-side inputs rec [len*B][kr]
+// weight gradients of one layer from dZ (in l.Z), its inputs x and its recurrent-side inputs rec [len*B][kr]: both
+// contractions run over the rows = time x batch, on the operands as they lie
 static int layer_weight_grads(casv_model* m, TLayer& l, const float* x, long long ldx, const float* rec, long long ldrec) {
     TrainState* ts = m->train;
     const int W = m->W;
     const long long rows = (long long)l.len * ts->B;
-    const long long ldT = (rows + 31) & ~31LL;
     if (ts->tens[l.iwx].frozen) return 0;
-    HIPCHK(hipMemsetAsync(ts->T1.p, 0, (size_t)4 * W * ldT * 4, m->stream));
-    launch_transpose(l.Z.as<float>(), (int)rows, 4 * W, 4 * W, ts->T1.as<float>(), ldT, m->stream);
-    HIPCHK(hipMemsetAsync(ts->T2.p, 0, (size_t)l.kx * ldT * 4, m->stream));
-    launch_transpose(x, (int)rows, l.kx, ldx, ts->T2.as<float>(), ldT, m->stream);
-    GemmArgs g1 = plain_gemm(ts->T1.as<float>(), ldT, 4 * W, (int)ldT, ts->T2.as<float>(), l.kx, nullptr, ts->G_(l.iwx), l.kx, 1);
-    run_gemm(m, EPI_PLAIN, g1);
-    HIPCHK(hipMemsetAsync(ts->T3.p, 0, (size_t)l.kr * ldT * 4, m->stream));
-    launch_transpose(rec, (int)rows, l.kr, ldrec, ts->T3.as<float>(), ldT, m->stream);
-    GemmArgs g2 = plain_gemm(ts->T1.as<float>(), ldT, 4 * W, (int)ldT, ts->T3.as<float>(), l.kr, nullptr, ts->G_(l.iwr), l.kr, 1);
-    run_gemm(m, EPI_PLAIN, g2);
-    launch_colsum(l.Z.as<float>(), rows, 4 * W, 4 * W, ts->G_(l.ib), m->stream);
+    // (the bias gradient = column sums of dZ rides in the first of the two launches)
+    run_gemm_tn(m, l.Z.as<float>(), 4 * W, 4 * W, 4 * W, x, ldx, l.kx, rows, ts->G_(l.iwx), l.kx, ts->G_(l.ib));
+    run_gemm_tn(m, l.Z.as<float>(), 4 * W, 4 * W, 4 * W, rec, ldrec, l.kr, rows, ts->G_(l.iwr), l.kr);
     return 0;
 }
 
@@ -365,8 +368,6 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     ENS(ts->dfin, (size_t)2 * D * B * W * 4) ENS(ts->dcbuf, (size_t)B * W * 4) ENS(ts->HP, LB * W * 4)
     ENS(ts->dX0, TB * W * 4) ENS(ts->dXtop, UB * W * 4) ENS(ts->dXl, TB * 2 * W * 4) ENS(ts->dYl, UB * W * 4) ENS(ts->dOin, TB * 2 * W * 4)
     ENS(ts->dcbuf2, (size_t)B * W * 4) ENS(ts->dvaP, (size_t)B * W * 4) ENS(ts->dbvP, (size_t)B * 4)
-    const long long ldTmax = (LB + 31) & ~31LL;
-    ENS(ts->T1, (size_t)4 * W * ldTmax * 4) ENS(ts->T2, (size_t)std::max(2 * W, Vp) * ldTmax * 4) ENS(ts->T3, (size_t)(C + W) * ldTmax * 4)
     for (auto& l : ts->layers) {
         const bool enc = l.name.compare(0, 3, "enc") == 0;
         l.len = enc ? T : U;
@@ -487,13 +488,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     float* dlog = ts->logits.as<float>();
     // tied projection: dE += dlogits^T . G ; dG = dlogits . E
     {
-        const long long ldT = (UB + 31) & ~31LL;
-        HIPCHK(hipMemsetAsync(ts->T2.p, 0, (size_t)Vp * ldT * 4, st));
-        launch_transpose(dlog, (int)UB, Vp, Vp, ts->T2.as<float>(), ldT, st);
-        HIPCHK(hipMemsetAsync(ts->T3.p, 0, (size_t)W * ldT * 4, st));
-        launch_transpose(top.hs, (int)UB, W, W, ts->T3.as<float>(), ldT, st);
-        GemmArgs g = plain_gemm(ts->T2.as<float>(), ldT, V, (int)ldT, ts->T3.as<float>(), W, nullptr, ts->G_(ts->iE), W, 1);
-        run_gemm(m, EPI_PLAIN, g);
+        run_gemm_tn(m, dlog, Vp, Vp, V, top.hs, W, W, UB, ts->G_(ts->iE), W);      // (the padding columns of dlogits are zero)
         GemmArgs g2 = plain_gemm(dlog, Vp, (int)UB, Vp, ts->ETp.as<float>(), W, nullptr, ts->dG.as<float>(), W);
         run_gemm(m, EPI_PLAIN, g2);
     }
@@ -550,22 +545,11 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         if (int rc = layer_weight_grads(m, top, ts->Ym.as<float>(), W, ts->RecIn.as<float>(), kr)) return rc;
         // attention parameters: dWaT = DWQ^T . Hprev ; dbUW = colsum(DWQ) ; u path
         if (!ts->tens[ts->iWaT].frozen) {
-            const long long ldT = (UB + 31) & ~31LL;
-            HIPCHK(hipMemsetAsync(ts->T1.p, 0, (size_t)W * ldT * 4, st));
-            launch_transpose(ts->DWQ.as<float>(), (int)UB, W, W, ts->T1.as<float>(), ldT, st);
-            // T3 still holds RecIn^T [kr][ldT]: rows C.. are h_prev^T
-            GemmArgs gw = plain_gemm(ts->T1.as<float>(), ldT, W, (int)ldT, ts->T3.as<float>() + (size_t)C * ldT, W, nullptr, ts->G_(ts->iWaT), W, 1);
-            run_gemm(m, EPI_PLAIN, gw);
-            launch_colsum(ts->DWQ.as<float>(), UB, W, W, ts->G_(ts->ibUW), st);
+            // the h_prev of every step are columns C.. of the cell's recurrent-side inputs
+            run_gemm_tn(m, ts->DWQ.as<float>(), W, W, W, ts->RecIn.as<float>() + C, kr, W, UB, ts->G_(ts->iWaT), W, ts->G_(ts->ibUW));
         }
         {
-            const long long ldT = (TB + 31) & ~31LL;
-            HIPCHK(hipMemsetAsync(ts->T1.p, 0, (size_t)W * ldT * 4, st));
-            launch_transpose(ts->du.as<float>(), (int)TB, W, W, ts->T1.as<float>(), ldT, st);
-            HIPCHK(hipMemsetAsync(ts->T2.p, 0, (size_t)C * ldT * 4, st));
-            launch_transpose(enc_out, (int)TB, C, C, ts->T2.as<float>(), ldT, st);
-            GemmArgs gu = plain_gemm(ts->T1.as<float>(), ldT, W, (int)ldT, ts->T2.as<float>(), C, nullptr, ts->G_(ts->iUT), C, 1);
-            run_gemm(m, EPI_PLAIN, gu);
+            run_gemm_tn(m, ts->du.as<float>(), W, W, W, enc_out, C, C, TB, ts->G_(ts->iUT), C);
             GemmArgs gd = plain_gemm(ts->du.as<float>(), W, (int)TB, W, ts->UaN.as<float>(), C, nullptr, ts->d_enc.as<float>(), C, 1);
             run_gemm(m, EPI_PLAIN, gd);
         }

@@ -117,42 +117,55 @@ void launch_mul_rowmask(const float* in, long long ld_in, const float* mask, lon
 }
 
 // ---- softmax + weighted categorical cross-entropy (Keras), dlogits in place ----
+// One wave per row, a workgroup's waves walk the rows with the grid's stride; the loss terms are summed per wave and per
+// workgroup first (float64) and reach the accumulator as ONE atomic per workgroup: 52 224 adds to a single address -- one per
+// row -- were 0.63 ms of the step (profiles/r02_train_kernel_stats.csv: softmax_ce_kernel), every one serialised behind the
+// others at the memory side.
 __global__ __launch_bounds__(256) void softmax_ce_kernel(float* __restrict__ logits, const int* __restrict__ target,
                                                          const float* __restrict__ weight, long long rows, int B, int U, int V,
                                                          int Vp, float inv_count, double* __restrict__ loss, int want_grad) {
-    const int lane = threadIdx.x & 63;
-    const long long r = blockIdx.x * 4LL + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    float* x = logits + r * Vp;
-    float m = -INFINITY;
-    for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
-    m = wave_butterfly(m, [](float a, float b) { return fmaxf(a, b); });
-    float sum = 0.f;
-    for (int v = lane; v < V; v += 64) sum += expf(x[v] - m);
-    sum = wsum(sum);
-    const long long src = (r % B) * U + r / B;        // row r = t*B + b  <-  (b, t) of the caller's (B,U) arrays
-    const int tg = target[src];
-    const float wgt = weight[src];
-    float pt = 0.f;
-    if (tg >= 0 && tg < V) pt = expf(x[tg] - m) / sum;
-    const bool ok = tg >= 0 && pt > 1e-7f && pt < 1.0f - 1e-7f;      // tf.clip_by_value passes gradient inside only
-    if (lane == 0 && tg >= 0) {
-        const float pc = fminf(fmaxf(pt, 1e-7f), 1.0f - 1e-7f);
-        atomicAdd(loss, (double)(-logf(pc) * wgt * inv_count));
-    }
-    if (want_grad) {
-        const float sc = ok ? wgt * inv_count : 0.0f;
-        for (int v = lane; v < Vp; v += 64) {
-            float gvl = 0.f;
-            if (v < V) gvl = (expf(x[v] - m) / sum - (v == tg ? 1.0f : 0.0f)) * sc;
-            x[v] = gvl;
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double mine = 0.0;
+    for (long long r = blockIdx.x * 4LL + wave; r < rows; r += 4LL * gridDim.x) {
+        float* x = logits + r * Vp;
+        float m = -INFINITY;
+        for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+        m = wave_butterfly(m, [](float a, float b) { return fmaxf(a, b); });
+        float sum = 0.f;
+        for (int v = lane; v < V; v += 64) sum += expf(x[v] - m);
+        sum = wsum(sum);
+        const long long src = (r % B) * U + r / B;        // row r = t*B + b  <-  (b, t) of the caller's (B,U) arrays
+        const int tg = target[src];
+        const float wgt = weight[src];
+        float pt = 0.f;
+        if (tg >= 0 && tg < V) pt = expf(x[tg] - m) / sum;
+        const bool ok = tg >= 0 && pt > 1e-7f && pt < 1.0f - 1e-7f;      // tf.clip_by_value passes gradient inside only
+        if (tg >= 0) {
+            const float pc = fminf(fmaxf(pt, 1e-7f), 1.0f - 1e-7f);
+            mine += (double)(-logf(pc) * wgt * inv_count);               // (the same value in every lane)
         }
+        if (want_grad) {
+            const float sc = ok ? wgt * inv_count : 0.0f;
+            for (int v = lane; v < Vp; v += 64) {
+                float gvl = 0.f;
+                if (v < V) gvl = (expf(x[v] - m) / sum - (v == tg ? 1.0f : 0.0f)) * sc;
+                x[v] = gvl;
+            }
+        }
+    }
+    if (lane == 0) part[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s4 = part[0] + part[1] + part[2] + part[3];
+        if (s4 != 0.0) atomicAdd(loss, s4);
     }
 }
 void launch_softmax_ce(float* logits, const int* target, const float* weight, int B, int U, int V, int Vp, float inv_count,
                        double* loss, int want_grad, hipStream_t st) {
     const long long rows = (long long)B * U;
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, target, weight, rows, B, U, V,
+    const long long wgs = std::min<long long>((rows + 3) / 4, 2048);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)wgs), dim3(256), 0, st, logits, target, weight, rows, B, U, V,
                        Vp, inv_count, loss, want_grad);
 }
 
@@ -289,36 +302,48 @@ void launch_colsum(const float* in, long long rows, int cols, long long ld, floa
     hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, in, rows, cols, ld, out, rpb);
 }
 
-// ---- embedding regulariser (seq2seq.py:530-553): value and gradient; one workgroup ----
-__global__ __launch_bounds__(1024) void reg_kernel(const float* __restrict__ E, float* __restrict__ dE, int V, int W,
-                                                   double* __restrict__ loss, int want_grad) {
-    __shared__ float red[1024];
-    const int tid = threadIdx.x;
-    float acc = 0.f;
-    for (int w = tid; w < W; w += 1024) {
-        float s = 0.f;
-        for (int v = 1; v < V; ++v) s += E[(long long)v * W + w];
-        const float mr = s / (float)(V - 1);
-        const float d = E[w] - mr;
-        acc += d * d;
-        if (want_grad) atomicAdd(dE + w, 2.0f * d);
-    }
-    for (int v = tid; v < V; v += 1024) {
-        float n = 0.f;
-        for (int w = 0; w < W; ++w) { const float e = E[(long long)v * W + w]; n += e * e; }
-        acc += 0.01f * (1.0f - n) * (1.0f - n);
-        if (want_grad) {
-            const float k = -0.04f * (1.0f - n);
-            for (int w = 0; w < W; ++w) atomicAdd(dE + (long long)v * W + w, k * E[(long long)v * W + w]);
-        }
-    }
-    red[tid] = acc;
+// ---- embedding regulariser (seq2seq.py:530-553): value and gradient ----
+//   1 * sum_w (E[0][w] - stopgrad(mean_{v>=1} E[v][w]))^2  +  0.01 * sum_v (1 - |E[v]|^2)^2
+// Two small grids instead of one workgroup walking the whole table (0.54 ms of the step): columns in blocks of 64 (four row
+// groups per block meet in LDS), rows one wave each.  The gradient is added in place: every contribution to dE of this step
+// has been queued on the same stream before.
+__global__ __launch_bounds__(256) void reg_cols_kernel(const float* __restrict__ E, float* __restrict__ dE, int V, int W,
+                                                       double* __restrict__ loss, int want_grad) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6, w = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (w < W) for (int v = 1 + g; v < V; v += 4) s += E[(long long)v * W + w];
+    part[g][c] = s;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) atomicAdd(loss, (double)red[0]);
+    float sq = 0.f;
+    if (g == 0 && w < W) {
+        const float mr = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / (float)(V - 1);
+        const float d = E[w] - mr;
+        sq = d * d;
+        if (want_grad) dE[w] += 2.0f * d;
+    }
+    if (g == 0) {
+        sq = wsum(sq);
+        if (c == 0) atomicAdd(loss, (double)sq);
+    }
+}
+__global__ __launch_bounds__(256) void reg_rows_kernel(const float* __restrict__ E, float* __restrict__ dE, int V, int W,
+                                                       double* __restrict__ loss, int want_grad) {
+    const int lane = threadIdx.x & 63, v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const float* row = E + (long long)v * W;
+    float n = 0.f;
+    for (int w = lane; w < W; w += 64) n += row[w] * row[w];
+    n = wsum(n);
+    if (want_grad) {
+        const float k = -0.04f * (1.0f - n);
+        for (int w = lane; w < W; w += 64) dE[(long long)v * W + w] += k * row[w];
+    }
+    if (lane == 0) atomicAdd(loss, (double)(0.01f * (1.0f - n) * (1.0f - n)));
 }
 void launch_reg(const float* E, float* dE, int V, int W, double* loss, int want_grad, hipStream_t st) {
-    hipLaunchKernelGGL(reg_kernel, dim3(1), dim3(1024), 0, st, E, dE, V, W, loss, want_grad);
+    hipLaunchKernelGGL(reg_cols_kernel, dim3((W + 63) / 64), dim3(256), 0, st, E, dE, V, W, loss, want_grad);
+    hipLaunchKernelGGL(reg_rows_kernel, dim3((V + 3) / 4), dim3(256), 0, st, E, dE, V, W, loss, want_grad);
 }
 
 // ---- global gradient norm and Adam (Keras Adam(clipnorm)) ----
