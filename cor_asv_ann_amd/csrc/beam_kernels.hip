@@ -82,13 +82,12 @@ void beam_prof_dump(int steps) {
 
 // VPL = vocabulary entries per lane (V <= 64 * VPL); NWV = waves per workgroup (one wave expands one hypothesis row)
 template <int VPL, int NWV>
-__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <= 4 ? 8 : 1, 8))) void beam_step_kernel(const BeamState s, const BeamParams p) {
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <= 4 && NWV <= 8 ? 8 : (NWV > 8 ? 4 : 1), 8))) void beam_step_kernel(const BeamState s, const BeamParams p) {
     constexpr int NT = 64 * NWV;
-    // dynamic LDS: [sort_cap new keys (f64)] [q_stage old keys (f64)] [sort_cap new ids] [q_stage old ids] [7 x (N+1) row records]
+    // dynamic LDS: [sort_cap new keys (f64)] [q_stage old keys (f64)] [pop_cap head keys (f64)] [sort_cap new ids] [q_stage old ids]
+    // [7 x (N+1) row records] [pop_cap head ids] [pop_cap head characters]
     extern __shared__ __attribute__((aligned(16))) unsigned char beam_smem[];
     __shared__ int sh_nnew, sh_nb, sh_done;
-    __shared__ int pop_id[64], pop_chr[64];
-    __shared__ double pop_key[64];
 
     const int line = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int step = s.step_ptr ? *s.step_ptr : s.step_imm;
@@ -97,9 +96,14 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
     const int CMAX = (p.width_in < V ? p.width_in : V) + 1;      // children per expansion: <= min(width_in, V) + the late rejection
     const int cap = p.sort_cap;                    // new keys the LDS holds (a power of two)
     const int q_stage = p.q_stage;                 // entries of the old queue staged in LDS (0: search in HBM)
+    // The head of the merged queue -- the entries the pop loop of phase C walks, N plus as many finished hypotheses as it meets on
+    // the way -- is kept in LDS while the merge writes it: one thread walks it serially, and at N = 256 (the reference's default
+    // batch_size) a walk through global memory was two dependent round trips per entry.
+    const int pop_cap = p.pop_cap;
     double* s_key = reinterpret_cast<double*>(beam_smem);
     double* o_key = s_key + cap;
-    int* s_id = reinterpret_cast<int*>(o_key + q_stage);
+    double* pop_key = o_key + q_stage;
+    int* s_id = reinterpret_cast<int*>(pop_key + pop_cap);
     int* o_id = s_id + cap;
     int* r_count = o_id + q_stage;
     int* r_off = r_count + (N + 1);
@@ -108,6 +112,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
     int* r_srcpos = r_rej + (N + 1);
     int* r_nan = r_srcpos + (N + 1);
     int* r_rejlate = r_nan + (N + 1);
+    int* pop_id = r_rejlate + (N + 1);
+    int* pop_chr = pop_id + pop_cap;
     const int nact = s.nact[line];
     const long long nbase = (long long)line * s.node_cap;
     if (tid == 0) s.line_steps[line] = step + 1;
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(nk[mid], ni[mid], k, id)) lo = mid + 1; else hi = mid; }
             const int pos = i + lo;
             if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
-            if (pos < 64) { pop_key[pos] = k; pop_id[pos] = id; }
+            if (pos < pop_cap) { pop_key[pos] = k; pop_id[pos] = id; }
         }
         for (int j = tid; j < nnew; j += NT) {
             const double k = nk[j]; const int id = ni[j];
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (before(ok[mid], oi[mid], k, id)) lo = mid + 1; else hi = mid; }
             const int pos = j + lo;
             if (pos < qcap) { nkey[pos] = k; nid[pos] = id; }
-            if (pos < 64) { pop_key[pos] = k; pop_id[pos] = id; }
+            if (pos < pop_cap) { pop_key[pos] = k; pop_id[pos] = id; }
         }
     };
     if (!big) { if (staged) merge(s_key, s_id, o_key, o_id); else merge(s_key, s_id, okey, oid); }
@@ -400,8 +406,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
 
     BPROF(4);
     // ---------------- C: pop the next beam ----------------
-    const int pre = qn < 64 ? qn : 64;
-    if (tid < pre) pop_chr[tid] = s.n_chr[nbase + pop_id[tid]];
+    const int pre = qn < pop_cap ? qn : pop_cap;
+    for (int i = tid; i < pre; i += NT) pop_chr[i] = s.n_chr[nbase + pop_id[i]];
     __syncthreads();
     if (tid == 0) {
         int nb = 0, h = 0;
@@ -410,9 +416,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
         int* fid = s.f_id + (long long)line * s.f_cap;
         double b0 = 0.0;
         while (h < qn && nb < N) {
-            const int id = h < 64 ? pop_id[h] : nid[h];
-            const int chr = h < 64 ? pop_chr[h] : s.n_chr[nbase + id];
-            const double key = h < 64 ? pop_key[h] : nkey[h];
+            const int id = h < pre ? pop_id[h] : nid[h];
+            const int chr = h < pre ? pop_chr[h] : s.n_chr[nbase + id];
+            const double key = h < pre ? pop_key[h] : nkey[h];
             if (chr == p.eos) {                    // '\n': finished hypothesis -> final_beam (s2s:1402)
                 ++ftot;
                 int ppos = fn;
@@ -468,9 +474,10 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
 #endif
 }
 // LDS plan of one launch: sort capacity (new keys held at once), staged entries of the old queue, bytes.
-size_t beam_lds_bytes(int N, int width_in, int V, int q_cap, int* sort_cap, int* q_stage) {
+size_t beam_lds_bytes(int N, int width_in, int V, int q_cap, int* sort_cap, int* q_stage, int* pop_cap) {
     const int cm = (width_in < V ? width_in : V) + 1;
-    const size_t rows = (size_t)7 * (N + 1) * 4;
+    *pop_cap = N + 64;                                   // the N hypotheses popped plus finished ones met on the way (more: from HBM)
+    const size_t rows = (size_t)7 * (N + 1) * 4 + (size_t)(*pop_cap) * 16;
     int cap = 1;
     while (cap < N * cm && cap < BEAM_SORT_CAP) cap <<= 1;
     while (cap > 256 && rows + (size_t)cap * 12 > 56 * 1024) cap >>= 1;
@@ -480,16 +487,20 @@ size_t beam_lds_bytes(int N, int width_in, int V, int q_cap, int* sort_cap, int*
     return base + (size_t)(*q_stage) * 12 + 16;
 }
 void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream) {
-    int q_stage = 0, sort_cap = 0;
-    const size_t lds = beam_lds_bytes(p.N, p.width_in, s.V, s.q_cap, &sort_cap, &q_stage);
+    int q_stage = 0, sort_cap = 0, pop_cap = 0;
+    const size_t lds = beam_lds_bytes(p.N, p.width_in, s.V, s.q_cap, &sort_cap, &q_stage, &pop_cap);
     BeamParams pp = p;
-    pp.q_stage = q_stage; pp.sort_cap = sort_cap;
+    pp.q_stage = q_stage; pp.sort_cap = sort_cap; pp.pop_cap = pop_cap;
     const int vpl = (s.V + 63) / 64;
     const bool wide = p.N >= 8;          // eight waves: one hypothesis row per wave at the default N = 8
+    // Wide beams (the reference's default batch_size = 256 hypotheses per step, seq2seq.py:111,1414) on few lines (a page of
+    // the OCR-D processor is ~40): one workgroup per line leaves most of the chip idle and walks 256 rows with 8 waves --
+    // sixteen waves per line halve the row loops (expansion, selection, next inputs) and the sort / merge passes.
+    const bool huge = p.N >= 64;
 #define CASV_BEAM_LAUNCH(VPL_, NWV_) hipLaunchKernelGGL((beam_step_kernel<VPL_, NWV_>), dim3(s.B), dim3(64 * NWV_), lds, stream, s, pp)
-    if (vpl <= 4) { if (wide) CASV_BEAM_LAUNCH(4, 8); else CASV_BEAM_LAUNCH(4, 4); }
-    else if (vpl <= 8) { if (wide) CASV_BEAM_LAUNCH(8, 8); else CASV_BEAM_LAUNCH(8, 4); }
-    else if (vpl <= 16) { if (wide) CASV_BEAM_LAUNCH(16, 8); else CASV_BEAM_LAUNCH(16, 4); }
+    if (vpl <= 4) { if (huge) CASV_BEAM_LAUNCH(4, 16); else if (wide) CASV_BEAM_LAUNCH(4, 8); else CASV_BEAM_LAUNCH(4, 4); }
+    else if (vpl <= 8) { if (huge) CASV_BEAM_LAUNCH(8, 16); else if (wide) CASV_BEAM_LAUNCH(8, 8); else CASV_BEAM_LAUNCH(8, 4); }
+    else if (vpl <= 16) { if (huge) CASV_BEAM_LAUNCH(16, 16); else if (wide) CASV_BEAM_LAUNCH(16, 8); else CASV_BEAM_LAUNCH(16, 4); }
     else if (vpl <= 32) { if (wide) CASV_BEAM_LAUNCH(32, 8); else CASV_BEAM_LAUNCH(32, 4); }
     else { if (wide) CASV_BEAM_LAUNCH(64, 8); else CASV_BEAM_LAUNCH(64, 4); }
 #undef CASV_BEAM_LAUNCH

@@ -209,6 +209,7 @@ struct BeamParams {
     double threshold_in, rejection, cost0;
     int q_stage;   // set by launch_beam_step: entries of the old queue staged in LDS
     int sort_cap;  // set by launch_beam_step: new keys sorted in LDS at once
+    int pop_cap;   // set by launch_beam_step: entries at the head of the merged queue kept in LDS for the pop loop
     int eos;       // vocabulary index of the end-of-line character
 };
 

@@ -116,6 +116,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         gt.a[0] = *reinterpret_cast<const f32x4*>(pa0); gt.a[1] = *reinterpret_cast<const f32x4*>(pa1);
         gt.b[0] = *reinterpret_cast<const f32x4*>(bp[0] + kb); gt.b[1] = *reinterpret_cast<const f32x4*>(bp[1] + kb);
     };
+    // The first tiles of the prologue when they all lie in segment 0 (every launch of the decoder and encoder: the layer input
+    // comes first and is at least four tiles wide): addressed without the segment masks, i.e. without waiting for the row
+    // indices of the gathered segments behind it (the parents' h rows) -- one dependent memory round trip less in front of
+    // the first MFMA of every workgroup.
+    auto load_tile_seg0 = [&](GTile& gt, int kt) {
+        gt.a[0] = *reinterpret_cast<const f32x4*>(ap0[0] + kt * BK); gt.a[1] = *reinterpret_cast<const f32x4*>(ap0[1] + kt * BK);
+        gt.b[0] = *reinterpret_cast<const f32x4*>(bp[0] + koff0 + kt * BK); gt.b[1] = *reinterpret_cast<const f32x4*>(bp[1] + koff0 + kt * BK);
+    };
     // The same four loads hidden from the compiler's wait bookkeeping (steady state only).  hipcc's s_waitcnt in front of
     // the LDS store of tile kt + 2 counts in order and drains the loads of tile kt + 3 with it (issued one tile earlier):
     // the prefetch was one tile deep for every second tile.  Issued from asm statements the loads are invisible to that
@@ -191,8 +199,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     Frag f0, f1;
     GTile g0, g1;
     // prologue: LDS[0] <- tile 0, LDS[1] <- tile 1, F0 <- LDS[0]; G0 <- tile 2, G1 <- tile 3
-    if (ntiles > 0) load_tile(g0, 0);
-    if (ntiles > 1) load_tile(g1, 1);
+    if (KS == 1 && kt_begin == 0 && c0 >= 2 && ntiles > 1) { load_tile_seg0(g0, 0); load_tile_seg0(g1, 1); }
+    else {
+        if (ntiles > 0) load_tile(g0, 0);
+        if (ntiles > 1) load_tile(g1, 1);
+    }
     if (ntiles > 0) store_tile(g0, 0);
     if (ntiles > 1) store_tile(g1, 1);
 
@@ -407,16 +418,6 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
     const int grid = p.blocks * b.count * p.ksplit;
     p.skinny = g_tile_mode == 1 || (g_tile_mode < 0 && (grid <= 128 || (grid > ncu && grid < 2 * ncu)));
     if (p.skinny) p.ksplit = choose_ksplit(p.sblocks * b.count, 1024);
-    {   // experiment switch (measurement only): CASV_PLAN_SMALLM="skinny,ksplit" for split-K-able launches of at most 1024 rows
-        static const char* env = getenv("CASV_PLAN_SMALLM");
-        if (env && splittable && b.g[0].ksplit < 0 && b.g[0].M <= 1024) {
-            int sk = 0, ks = 1;
-            if (sscanf(env, "%d,%d", &sk, &ks) == 2) {
-                const int ktiles = count_ktiles(b.g[0]);
-                p.skinny = sk != 0; p.ksplit = ks < 1 ? 1 : (ks > ktiles ? ktiles : ks);
-            }
-        }
-    }
     return p;
 }
 bool gemm_is_skinny(int epi, const GemmBatch& b) { return plan_gemm(epi, b).skinny; }
