@@ -418,6 +418,15 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
     const int grid = p.blocks * b.count * p.ksplit;
     p.skinny = g_tile_mode == 1 || (g_tile_mode < 0 && (grid <= 128 || (grid > ncu && grid < 2 * ncu)));
     if (p.skinny) p.ksplit = choose_ksplit(p.sblocks * b.count, 1024);
+    // Split-K launches of few rows (the train step's per-time-step data GEMMs: 512 rows, K = 2048): 32x128 tiles with just enough
+    // K splits for ONE round of workgroups.  As 128x128 tiles they needed eight splits to fill the chip, and the eight partial
+    // tiles per output went through float atomics -- 16.8 MB per launch at the memory side's ~1.3 TB/s = 13 of the launch's
+    // 36 us.  Measured on the train step of configs[3] (splits 2 / 3 / 4 / 6 / 8 of 32x128 tiles: 90.2 / 91.8 / 87.9 / 89.9 /
+    // 94.2 ms per step; 128x128 tiles with four splits 103.2; before 94.1).
+    if (g_tile_mode < 0 && splittable && b.g[0].ksplit < 0 && b.g[0].M <= 1024) {
+        p.skinny = true;
+        p.ksplit = choose_ksplit(p.sblocks * b.count, 512);
+    }
     return p;
 }
 bool gemm_is_skinny(int epi, const GemmBatch& b) { return plan_gemm(epi, b).skinny; }
