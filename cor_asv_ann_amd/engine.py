@@ -40,23 +40,118 @@ def weight_shapes(depth, width, voc_size):
     return shapes
 
 
+def _pad_blocks(a, axis, blocks, W, Wp):
+    """Along `axis`, `a` consists of `blocks` consecutive blocks of W entries: widen every block to Wp with zeros."""
+    if W == Wp:
+        return a
+    a = np.asarray(a)
+    shape = list(a.shape)
+    assert shape[axis] == blocks * W, (shape, axis, blocks, W)
+    a = np.moveaxis(a, axis, -1).reshape(a.shape[:axis] + a.shape[axis + 1:] + (blocks, W))
+    out = np.zeros(a.shape[:-1] + (Wp,), a.dtype)
+    out[..., :W] = a
+    out = out.reshape(out.shape[:-2] + (blocks * Wp,))
+    return np.ascontiguousarray(np.moveaxis(out, -1, axis))
+
+
+def _strip_blocks(a, axis, blocks, W, Wp):
+    """Inverse of _pad_blocks."""
+    if W == Wp:
+        return a
+    a = np.asarray(a)
+    a = np.moveaxis(a, axis, -1)
+    a = a.reshape(a.shape[:-1] + (blocks, Wp))[..., :W]
+    a = a.reshape(a.shape[:-2] + (blocks * W,))
+    return np.ascontiguousarray(np.moveaxis(a, -1, axis))
+
+
+def _width_blocks(name, depth):
+    """(blocks along axis 0, blocks along axis 1 or None) of the hidden width in a Keras-layout tensor of weight_shapes()."""
+    d = depth
+    top = 'dec%d_' % d
+    if name == 'E':
+        return (None, 1)
+    if name in ('att_va', 'att_bUW'):
+        return (1, None)
+    if name == 'att_bv':
+        return (None, None)
+    if name == 'att_U':
+        return (2 if d == 1 else 1, 1)
+    if name == 'att_Wa':
+        return (1, 1)
+    if name.endswith('_b'):
+        return (4, None)
+    if name.endswith('_R'):
+        return (1, 4)
+    if name.endswith('_K'):
+        if name == 'enc2_K':
+            return (2, 4)
+        if name == top + 'K':
+            return (3 if d == 1 else 2, 4)       # input + context (2W wide at depth 1)
+        return (1, 4)
+    raise KeyError(name)
+
+
 class HipEngine(object):
-    """One model handle on one HIP device."""
+    """One model handle on one HIP device.
+
+    Hidden widths that are not a multiple of 32 (the C ABI's tile granularity; the reference's `--width` takes any integer) are
+    padded here with dead units: every tensor crosses the ABI widened to the next multiple of 32, block by block, with zeros.
+    That is exact, not approximate: a unit whose incoming weights, outgoing weights and biases are all zero has gate
+    pre-activations 0, hence c' = f*c + i*tanh(0) = 0 and h = o*tanh(0) = 0 at every step, feeds nothing into any real unit,
+    reads nothing from one, has zero attention weight (v_a = 0) -- and receives exactly zero gradient, so Adam leaves it at zero."""
 
     def __init__(self, depth, width, voc_size, device=0, window_width=5, residual_connections=False,
                  deep_bidirectional_encoder=False, bridge_dense=False, lm=False, stateful=False):
         self.lib = nv.load()
         self.depth, self.width, self.voc_size = int(depth), int(width), int(voc_size)
+        if self.width < 1:
+            raise ValueError('width must be positive')
+        self.pwidth = (self.width + 31) // 32 * 32            # what the device sees
         self.ctx_width = 2 * self.width if self.depth == 1 else self.width
+        self.cblocks = 2 if self.depth == 1 else 1
         self.window_width = int(window_width)
-        cfg = nv.Config(self.depth, self.width, self.voc_size, int(window_width), int(bool(residual_connections)),
+        cfg = nv.Config(self.depth, self.pwidth, self.voc_size, int(window_width), int(bool(residual_connections)),
                         int(bool(deep_bidirectional_encoder)), int(bool(bridge_dense)), int(bool(lm)),
                         int(bool(stateful)))
         handle = c_void_p()
         nv.check(self.lib.casv_model_create(byref(cfg), int(device), byref(handle)))
         self.handle = handle
         self.shapes = weight_shapes(self.depth, self.width, self.voc_size)
+        self.pshapes = weight_shapes(self.depth, self.pwidth, self.voc_size)
         self.B = self.T = 0
+
+    # -- dead-unit padding (class docstring) ---------------------------------------------------
+    def _pad_weight(self, name, a):
+        W, Wp = self.width, self.pwidth
+        if W == Wp:
+            return a
+        b0, b1 = _width_blocks(name, self.depth)
+        a = np.asarray(a, np.float32).reshape(self.shapes[name])
+        if b0:
+            a = _pad_blocks(a, 0, b0, W, Wp)
+        if b1:
+            a = _pad_blocks(a, 1, b1, W, Wp)
+        return a
+
+    def _strip_weight(self, name, a):
+        W, Wp = self.width, self.pwidth
+        if W == Wp:
+            return a
+        b0, b1 = _width_blocks(name, self.depth)
+        a = np.asarray(a).reshape(self.pshapes[name])
+        if b0:
+            a = _strip_blocks(a, 0, b0, W, Wp)
+        if b1:
+            a = _strip_blocks(a, 1, b1, W, Wp)
+        return a
+
+    def _padw(self, a, blocks=1):
+        """Widen the LAST axis (blocks x width) of a state / output array."""
+        return _pad_blocks(np.asarray(a, np.float32), np.asarray(a).ndim - 1, blocks, self.width, self.pwidth)
+
+    def _stripw(self, a, blocks=1):
+        return _strip_blocks(a, np.asarray(a).ndim - 1, blocks, self.width, self.pwidth)
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -77,15 +172,16 @@ class HipEngine(object):
             a = nv.carray(weights[name], np.float32)
             if tuple(a.shape) != tuple(shape) and a.size != int(np.prod(shape)):
                 raise ValueError('weight "%s" has shape %s, expected %s' % (name, a.shape, shape))
+            a = nv.carray(self._pad_weight(name, a), np.float32)
             nv.check(self.lib.casv_set_weight(self.handle, name.encode(), nv.ptr(a), a.size))
         nv.check(self.lib.casv_commit_weights(self.handle))
 
     def get_weights(self):
         out = {}
-        for name, shape in self.shapes.items():
+        for name, shape in self.pshapes.items():
             a = np.empty(shape, np.float32)
             nv.check(self.lib.casv_get_weight(self.handle, name.encode(), nv.ptr(a), a.size))
-            out[name] = a
+            out[name] = self._strip_weight(name, a)
         return out
 
     # -- encoder -------------------------------------------------------------------------------
@@ -113,31 +209,33 @@ class HipEngine(object):
 
     def set_encoder_outputs(self, enc_out, states, a0=None, src_rej=None):
         """Install encoder outputs computed elsewhere: enc_out (B,T,C), states [h1,c1,...,hd,cd] each (B,W), a0 (B,T) or None."""
-        enc_out = nv.carray(enc_out, np.float32)
+        enc_out = nv.carray(self._padw(enc_out, self.cblocks), np.float32)
         B, T = enc_out.shape[:2]
-        st = nv.carray(np.stack([np.asarray(x, np.float32).reshape(B, self.width) for x in states[:2 * self.depth]]), np.float32)
+        st = nv.carray(self._padw(np.stack([np.asarray(x, np.float32).reshape(B, self.width) for x in states[:2 * self.depth]])), np.float32)
         a0 = None if a0 is None else nv.carray(np.asarray(a0, np.float32).reshape(B, T), np.float32)
         src_rej = None if src_rej is None else nv.carray(src_rej, np.int32)
         nv.check(self.lib.casv_set_encoder_outputs(self.handle, B, T, nv.ptr(enc_out), nv.ptr(st), nv.ptr(a0), nv.ptr(src_rej)))
         self.B, self.T = B, T
 
     def encoder_outputs(self):
-        enc = np.empty((self.B, self.T, self.ctx_width), np.float32)
-        st = np.empty((2 * self.depth, self.B, self.width), np.float32)
+        enc = np.empty((self.B, self.T, self.cblocks * self.pwidth), np.float32)
+        st = np.empty((2 * self.depth, self.B, self.pwidth), np.float32)
         nv.check(self.lib.casv_get_encoder_outputs(self.handle, nv.ptr(enc), nv.ptr(st)))
+        enc, st = self._stripw(enc, self.cblocks), self._stripw(st)
         return enc, [st[i] for i in range(2 * self.depth)]
 
     def decoder_step(self, line, p_in, states, a_in):
         line = nv.carray(line, np.int32)
         R = line.shape[0]
         p_in = nv.carray(p_in, np.float32)
-        st = nv.carray(np.stack(states[:2 * self.depth]), np.float32)
+        st = nv.carray(self._padw(np.stack(states[:2 * self.depth])), np.float32)
         a_in = nv.carray(a_in, np.float32)
         probs = np.empty((R, self.voc_size), np.float32)
         st_out = np.empty_like(st)
         a_out = np.empty((R, self.T), np.float32)
         nv.check(self.lib.casv_decoder_step(self.handle, R, nv.ptr(line), nv.ptr(p_in), nv.ptr(st), nv.ptr(a_in),
                                             nv.ptr(probs), nv.ptr(st_out), nv.ptr(a_out)))
+        st_out = self._stripw(st_out)
         return probs, [st_out[i] for i in range(2 * self.depth)] + [a_out]
 
     # -- decode loops --------------------------------------------------------------------------
@@ -194,10 +292,12 @@ class HipEngine(object):
         U = dec_in.shape[1]
         m_enc = m_dec = m_cell = None
         if masks is not None:
-            m_enc = nv.carray(np.concatenate([np.asarray(x, np.float32).ravel() for x in masks['enc']]), np.float32)
+            # (dead units are multiplied by zero whatever their mask says)
+            m_enc = nv.carray(np.concatenate([self._padw(np.asarray(x, np.float32).ravel(), 2 if n == 0 else 1)
+                                              for n, x in enumerate(masks['enc'])]), np.float32)
             if self.depth > 1:
-                m_dec = nv.carray(np.concatenate([np.asarray(x, np.float32).ravel() for x in masks['dec']]), np.float32)
-            m_cell = nv.carray(masks['cell'], np.float32)
+                m_dec = nv.carray(np.concatenate([self._padw(np.asarray(x, np.float32).ravel()) for x in masks['dec']]), np.float32)
+            m_cell = nv.carray(self._padw(np.asarray(masks['cell'], np.float32), 1 + self.cblocks), np.float32)
         loss, norm = c_double(), c_double()
         nv.check(self.lib.casv_train_step(self.handle, int(mode), B, T, U, A, nv.ptr(enc_idx), nv.ptr(enc_val), nv.ptr(dec_in),
                                           nv.ptr(dec_out), nv.ptr(weights), nv.ptr(m_enc), nv.ptr(m_dec), nv.ptr(m_cell),
@@ -206,10 +306,10 @@ class HipEngine(object):
 
     def train_gradients(self):
         out = {}
-        for name, shape in self.shapes.items():
+        for name, shape in self.pshapes.items():
             a = np.empty(shape, np.float32)
             nv.check(self.lib.casv_train_get_gradient(self.handle, name.encode(), nv.ptr(a), a.size))
-            out[name] = a
+            out[name] = self._strip_weight(name, a)
         return out
 
     def train_weights(self):

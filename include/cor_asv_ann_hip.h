@@ -45,7 +45,8 @@ typedef enum {
  * both published models use the default topology (wrapper/ocrd-tool.json:61-74). */
 typedef struct {
     int32_t depth;          /* seq2seq.py:117 */
-    int32_t width;          /* seq2seq.py:115; must be a multiple of 32 */
+    int32_t width;          /* seq2seq.py:115; must be a multiple of 32 (any other width: pad with dead units, as
+                             * cor_asv_ann_amd/engine.py does -- all-zero weights keep a unit at h = c = 0, exactly) */
     int32_t voc_size;       /* seq2seq.py:123 */
     int32_t window_width;   /* attention.py:515, seq2seq.py:347 (5) */
     int32_t residual_connections, deep_bidirectional_encoder, bridge_dense, lm, stateful;

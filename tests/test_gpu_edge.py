@@ -214,3 +214,44 @@ def test_rccl_leg_of_the_c_abi_with_one_rank():
     assert comm.max(3.25) == 3.25
     comm.close()
     eng.close()
+
+
+@pytest.mark.parametrize('d,W', [(1, 20), (2, 100), (3, 72)])
+def test_any_width_decodes_like_the_oracle(d, W):
+    """The reference's `--width` takes any integer; the device works in multiples of 32.  The engine pads every tensor with
+    dead units (all-zero weights: h = c = 0 at every step, zero attention weight, zero gradient) -- exact, so a width-100 model
+    behaves like the oracle's width-100 model: encoder outputs, all three decoding modes, alignments."""
+    from oracle import ModelConfig, make_weights, make_lines, vectorize_lines
+    from oracle.decode import OracleModel, correct_lines
+    from cor_asv_ann_amd.seq2seq import Sequence2Sequence
+    V = 48
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    weights = make_weights(cfg, emb_scale=10.0)
+    om = OracleModel(cfg, weights, batch_size=4)
+    lines, _ = make_lines(5, 11, 23, voc_size=V)
+    s2s = Sequence2Sequence()
+    s2s.depth, s2s.width, s2s.batch_size = d, W, 4
+    s2s.mapping, s2s.voc_size = om.mapping, V
+    s2s.configure()
+    s2s.set_weights(weights)
+    s2s.status = 2
+    enc_in, _, _, _ = vectorize_lines(om, lines, [[] for _ in lines])
+    want_enc = om.encode(enc_in)
+    got_enc = s2s.encoder_model.predict_on_batch(enc_in)
+    assert got_enc[0].shape == want_enc[0].shape == (5, 12, 2 * W if d == 1 else W)
+    assert np.allclose(got_enc[0], want_enc[0], rtol=2e-4, atol=2e-6)
+    for a, b in zip(got_enc[1:-1], want_enc[1:-1]):
+        assert a.shape == (5, W) and np.allclose(a, b, rtol=2e-4, atol=2e-6)
+    for fast, greedy in ((True, True), (False, False)):
+        want = correct_lines(om, lines, fast=fast, greedy=greedy)
+        got = s2s.correct_lines(lines, fast=fast, greedy=greedy, alignments='dense')
+        assert got[0] == want[0]
+        assert np.allclose(got[2], want[2], atol=1e-4)
+        for j in range(len(lines)):
+            assert np.allclose(got[1][j], want[1][j], rtol=2e-4, atol=2e-6)
+            assert len(got[3][j]) == len(want[3][j])
+            for a, b in zip(got[3][j], want[3][j]):
+                assert np.allclose(a, np.asarray(b, np.float32), rtol=2e-4, atol=1e-5)
+    w_back = s2s._require_engine().get_weights()
+    for k, v in weights.items():
+        assert w_back[k].shape == np.asarray(v).shape and np.array_equal(w_back[k], np.asarray(v, np.float32)), k

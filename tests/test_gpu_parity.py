@@ -161,7 +161,9 @@ def test_argument_errors_are_reported():
     from cor_asv_ann_amd.engine import HipEngine
     from cor_asv_ann_amd._native import NativeError
     with pytest.raises(NativeError):
-        HipEngine(2, 100, 64)                       # width not a multiple of 32
+        HipEngine(9, 64, 64)                        # depth out of range (any width is fine: dead-unit padding, engine.py)
+    with pytest.raises(ValueError):
+        HipEngine(2, 0, 64)
     cfg = ModelConfig(depth=1, width=32, voc_size=16)
     eng = HipEngine(1, 32, 16)
     with pytest.raises(NativeError):

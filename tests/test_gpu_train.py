@@ -15,7 +15,9 @@ def _idx(a):
 
 
 @pytest.mark.parametrize('d,W,V,B,L,es,with_masks', [(1, 32, 40, 4, 9, 3.0, False), (2, 32, 40, 4, 9, 3.0, True),
-                                                     (3, 64, 96, 8, 12, 6.0, True), (4, 64, 96, 6, 10, 8.0, False)])
+                                                     (3, 64, 96, 8, 12, 6.0, True), (4, 64, 96, 6, 10, 8.0, False),
+                                                     # widths that are no multiple of 32 (dead-unit padding, engine.py)
+                                                     (1, 20, 24, 3, 7, 3.0, True), (2, 50, 40, 4, 9, 4.0, True)])
 def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks):
     from cor_asv_ann_amd.engine import HipEngine
     cfg = ModelConfig(depth=d, width=W, voc_size=V)
