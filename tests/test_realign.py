@@ -2,7 +2,7 @@
 cell-by-cell restatement in oracle/realign.py."""
 import numpy as np
 
-from cor_asv_ann_amd.realign import SparseAlignment, alignment2path, dense_to_sparse
+from cor_asv_ann_amd.realign import SparseAlignment, alignment2path, alignment2path_py, dense_to_sparse
 from oracle.realign import alignment2path as oracle_path
 
 
@@ -64,6 +64,8 @@ def test_path_from_windows_equals_dense_viterbi():
         assert (np.isnan(got[1]) and np.isnan(want[1])) or abs(got[1] - want[1]) < 1e-5
         got2 = alignment2path(dense, i_max, j_max, min_score)           # the reference's list form works too
         assert got2[0] == want[0]
+        got3 = alignment2path_py(sp, i_max, j_max, min_score)           # the Python loop behind the native search
+        assert got3[0] == want[0] and ((np.isnan(got3[1]) and np.isnan(want[1])) or abs(got3[1] - want[1]) < 1e-5)
         checked += 1
     assert checked == 300
 
@@ -137,3 +139,24 @@ def test_sparse_alignment_stays_lazy_until_rows_are_looked_at():
     assert all(np.array_equal(a, b) for a, b in zip(fresh, dense))
     empty = SparseAlignment(np.zeros(0, np.int32), np.zeros((0, 11), np.float32), 9)
     assert len(empty) == 0 and not empty and list(empty) == [] and np.asarray(empty).shape == (0, 9)
+
+
+def test_native_search_is_the_one_that_runs_and_agrees_on_long_lines():
+    """`alignment2path` goes through `casv_realign_path` (host code of the library: no device needed); on page-sized lines it
+    returns what the Python loop and the dense restatement return, a good deal faster."""
+    import time
+    from cor_asv_ann_amd import realign
+    assert realign._native_lib() is not None
+    rng = np.random.default_rng(11)
+    t_native = t_py = 0.0
+    for case in range(40):
+        T = int(rng.integers(30, 120)); n_out = int(rng.integers(30, 120))
+        sp = _random_alignment(rng, n_out, T, nan_rows=case % 5 == 0)
+        i_max, j_max = int(rng.integers(1, T + 1)), int(rng.integers(1, n_out + 1))
+        t0 = time.perf_counter(); a = alignment2path(sp, i_max, j_max, 1 / 640.); t1 = time.perf_counter()
+        b = alignment2path_py(sp, i_max, j_max, 1 / 640.); t2 = time.perf_counter()
+        t_native += t1 - t0; t_py += t2 - t1
+        want = oracle_path([row for row in np.asarray(sp)], i_max, j_max, 1 / 640.)
+        assert a[0] == b[0] == want[0], case
+        assert (np.isnan(a[1]) and np.isnan(want[1])) or (abs(a[1] - want[1]) < 1e-5 + 1e-6 * abs(a[1]) and abs(a[1] - b[1]) < 1e-9), case   # (the dense restatement sums in float32)
+    assert t_native < 0.5 * t_py, (t_native, t_py)
