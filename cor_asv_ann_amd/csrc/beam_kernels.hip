@@ -80,8 +80,181 @@ void beam_prof_dump(int steps) {
 #define BPROF(slot)
 #endif
 
-// VPL = vocabulary entries per lane (V <= 64 * VPL); NWV = waves per workgroup (one wave expands one hypothesis row)
-template <int VPL, int NWV>
+// Phase A1 for expansion row i of `line` (one wave): the row's softmax (when the step hands over logits), the rejection
+// candidate (seq2seq.py:1457-1470) written over its score, the beam width from the relative threshold (:1472-1480), the
+// ranks of index 0 and of the rejection index => number of children.  The row's final scores stay in `vals`
+// (lane + 64 k; -inf beyond V) and in the score store.
+template <int VPL>
+__device__ __forceinline__ RowRec expand_row_scores(const BeamState& s, const BeamParams& p, const int line, const int i, const int step,
+                                                    const int lane, float (&vals)[VPL]) {
+    const int N = p.N, V = s.V, Vp = (V + 31) & ~31, T = s.T, R = s.R;
+    const long long nbase = (long long)line * s.node_cap;
+    const int r = line * N + i;
+    const long long exp = (long long)(step + 1) * R + r;
+    float* sc = const_cast<float*>(s.p_base) + exp * Vp;
+    const int node = s.beam_node[r];
+    const int plen = s.n_len[nbase + node];
+    const double ppos = s.n_pos[nbase + node];
+    const int pis1 = s.n_is1[nbase + node];
+    const double pos = s.apos[r];
+    double mis = 0.0;
+    int srcpos = 0;
+    if (plen > 1) {
+        mis = fabs(pos - ppos - 1.0);
+        if (pis1) srcpos = (int)ppos + 1;
+        else srcpos = (pos == pos && fabs(pos) < 1e9) ? (int)rint(pos) : -1;
+    }
+    int rej = -1;
+    if (p.rejection != 0.0 && (mis < 0.1 || pis1) && srcpos >= 0 && srcpos < T)
+        rej = s.src_rej[line * T + srcpos];           // -1: input row all zero (np.any false)
+    bool anynan = false;
+    if (s.logits) {
+        // the row's softmax (decode_kernels.hip softmax_kernel: per-lane partial results over v = lane, lane + 64, ... in
+        // ascending order, the same butterflies, expf(x - m) / sum), written to the score store and kept in registers
+        const float* x = s.logits + (long long)r * Vp;
+        float m = -INFINITY, nn = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int v = lane + 64 * k;
+            vals[k] = v < V ? x[v] : 0.0f;
+            if (v < V) { m = fmaxf(m, vals[k]); nn += (vals[k] != vals[k]) ? 1.0f : 0.0f; }
+        }
+        m = wave_butterfly(m, [](float a, float b) { return fmaxf(a, b); });
+        if (wave_butterfly(nn, [](float a, float b) { return a + b; }) > 0.0f) m = __builtin_nanf("");
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) if (lane + 64 * k < V) sum += expf(vals[k] - m);
+        sum = wave_butterfly(sum, [](float a, float b) { return a + b; });
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int v = lane + 64 * k;
+            const float pv = v < V ? expf(vals[k] - m) / sum : 0.0f;
+            if (v < Vp) sc[v] = pv;                      // columns V..Vp-1: exact zeros (K padding of the next step's GEMM)
+            vals[k] = v < V ? pv : -INFINITY;
+            if (v < V && pv != pv) anynan = true;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int v = lane + 64 * k;
+            vals[k] = v < V ? sc[v] : -INFINITY;
+            if (v < V && vals[k] != vals[k]) anynan = true;
+        }
+    }
+    anynan = __any(anynan);
+    if (rej >= 0) {
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int v = lane + 64 * k;
+            if (v == rej && (double)vals[k] < p.rejection) { vals[k] = (float)p.rejection; sc[v] = vals[k]; }
+        }
+    }
+    float hi = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) hi = fmaxf(hi, vals[k]);
+    hi = wave_butterfly(hi, [](float a, float b) { return fmaxf(a, b); });
+    const double thr = (double)hi * p.threshold_in;
+    float v0 = __shfl(vals[0], 0, 64);                  // score of index 0
+    float vr = 0.f;
+    if (rej >= 0) {
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) if (lane + 64 * k == rej) vr = vals[k];
+        vr = wave_butterfly(vr, [](float a, float b) { return fmaxf(a, b); });   // scores are >= 0
+    }
+    int cnt = 0, rank0 = 0, rankr = 0;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        const int v = lane + 64 * k;
+        if (v < V) {
+            cnt += ((double)vals[k] >= thr) ? 1 : 0;
+            rank0 += better(vals[k], v, v0, 0) ? 1 : 0;
+            if (rej >= 0) rankr += better(vals[k], v, vr, rej) ? 1 : 0;
+        }
+    }
+    {
+        auto add = [](int a, int b) { return a + b; };
+        cnt = wave_butterfly(cnt, add); rank0 = wave_butterfly(rank0, add); rankr = wave_butterfly(rankr, add);
+    }
+    rank0 += 1; rankr += 1;
+    const int beampos = cnt < p.width_in ? cnt : p.width_in;
+    int count = beampos - (rank0 <= beampos ? 1 : 0);          // '' never becomes a node (s2s:1505)
+    const int rejlate = (rej > 0 && rankr > beampos) ? 1 : 0;  // `if rej_idx:` is false for 0 (s2s:1498)
+    count += rejlate;
+    if (anynan) count = 0;
+    return RowRec{count, beampos, rej, srcpos, anynan ? 1 : 0, rejlate};
+}
+
+// The children of one expansion row in creation order (seq2seq.py:1482-1529), from its final scores `vals`: the beampos best
+// (score descending, ties towards the higher index), then the rejection candidate if it lies beyond them; index 0 ('') is
+// skipped.  emit(k, index, score, is_rejection) is called by every lane with the same arguments.  Returns the children made.
+template <int VPL, class Emit>
+__device__ __forceinline__ int select_children(const float (&vals)[VPL], const int V, const int beampos, const int rejlate, int rej,
+                                               const int lane, Emit emit) {
+    unsigned long long taken = 0;
+    int created = 0;
+    const int total = beampos + rejlate;
+    for (int ps = 1; ps <= total; ++ps) {
+        float bv = -INFINITY; int bi = -1;
+        if (ps <= beampos) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const int v = lane + 64 * k;
+                if (v < V && !((taken >> k) & 1ull) && (bi < 0 || better(vals[k], v, bv, bi))) { bv = vals[k]; bi = v; }
+            }
+            {
+                auto step = [&](const float ov, const int oi) { if (oi >= 0 && (bi < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; } };
+                step(lane_xor<32>(bv), lane_xor<32>(bi)); step(lane_xor<16>(bv), lane_xor<16>(bi)); step(lane_xor<8>(bv), lane_xor<8>(bi));
+                step(lane_xor<4>(bv), lane_xor<4>(bi)); step(lane_xor<2>(bv), lane_xor<2>(bi)); step(lane_xor<1>(bv), lane_xor<1>(bi));
+            }
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) if (lane + 64 * k == bi) taken |= 1ull << k;
+        } else {                                   // the rejection candidate beyond the beam width
+            bi = rej; bv = 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) if (lane + 64 * k == rej) bv = vals[k];
+            bv = wave_butterfly(bv, [](float a, float b) { return fmaxf(a, b); });
+        }
+        bool isrej = false;
+        if (rej >= 0 && bi == rej) { isrej = true; rej = -1; }
+        if (bi == 0) continue;
+        emit(created, bi, bv, isrej);
+        ++created;
+    }
+    return created;
+}
+
+// Wide beams (N >= 64 hypotheses per line: the reference's default batch_size = 256) on few lines: phase A -- everything that is
+// per ROW (softmax, rejection, child selection) -- runs as a grid of its own over all rows of all lines, one wave per row
+// (beam_expand_kernel), and leaves per row a record and the list of its children; the per-line kernel (SPLIT) then only numbers
+// the children, writes their node records (one thread per child), sorts, merges and pops.  With one workgroup per line doing
+// all of it, a page of 40 lines x 256 hypotheses kept 40 CUs busy for 0.45 ms per step, most of it walking rows.
+template <int VPL>
+__global__ __launch_bounds__(512) void beam_expand_kernel(const BeamState s, const BeamParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 8 + wave;
+    if (r >= s.R) return;
+    const int N = p.N, line = r / N, i = r - line * N;
+    const int step = s.step_ptr ? *s.step_ptr : s.step_imm;
+    if (s.line_done[line] || i >= s.nact[line] || step + 1 >= s.S) return;
+    const int CMAX = (p.width_in < s.V ? p.width_in : s.V) + 1;
+    float vals[VPL];
+    RowRec rc = expand_row_scores<VPL>(s, p, line, i, step, lane, vals);
+    int rej_k = -1;
+    if (rc.count > 0) {
+        short* ci = s.cand_idx + (long long)r * CMAX;
+        float* cv = s.cand_val + (long long)r * CMAX;
+        select_children<VPL>(vals, s.V, rc.beampos, rc.rejlate, rc.rej, lane, [&](const int k, const int bi, const float bv, const bool isrej) {
+            if (lane == 0) { ci[k] = (short)bi; cv[k] = bv; }
+            if (isrej) rej_k = k;
+        });
+    }
+    rc.rej = rej_k;                        // from here on: WHICH child is the rejection candidate (-1: none)
+    if (lane == 0) s.rowrec[r] = rc;
+}
+
+// VPL = vocabulary entries per lane (V <= 64 * VPL); NWV = waves per workgroup (one wave expands one hypothesis row);
+// SPLIT: phase A has run as beam_expand_kernel
+template <int VPL, int NWV, bool SPLIT>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <= 4 && NWV <= 8 ? 8 : (NWV > 8 ? 4 : 1), 8))) void beam_step_kernel(const BeamState s, const BeamParams p) {
     constexpr int NT = 64 * NWV;
     // dynamic LDS: [sort_cap new keys (f64)] [q_stage old keys (f64)] [pop_cap head keys (f64)] [sort_cap new ids] [q_stage old ids]
@@ -124,103 +297,19 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
     if (tid == 0 && line < 4096) { g_beam_wg[3 * line] = (unsigned)bt; g_beam_wg[3 * line + 1] = 0; }
 #endif
     // ---------------- A1: per row, rejection overwrite + child count ----------------
-    for (int i = wave; i < nact; i += NWV) {
-        const int r = line * N + i;
-        const long long exp = (long long)(step + 1) * R + r;
-        float* sc = const_cast<float*>(s.p_base) + exp * Vp;
-        const int node = s.beam_node[r];
-        const int plen = s.n_len[nbase + node];
-        const double ppos = s.n_pos[nbase + node];
-        const int pis1 = s.n_is1[nbase + node];
-        const double pos = s.apos[r];
-        double mis = 0.0;
-        int srcpos = 0;
-        if (plen > 1) {
-            mis = fabs(pos - ppos - 1.0);
-            if (pis1) srcpos = (int)ppos + 1;
-            else srcpos = (pos == pos && fabs(pos) < 1e9) ? (int)rint(pos) : -1;
-        }
-        int rej = -1;
-        if (p.rejection != 0.0 && (mis < 0.1 || pis1) && srcpos >= 0 && srcpos < T)
-            rej = s.src_rej[line * T + srcpos];           // -1: input row all zero (np.any false)
-        float vals[VPL];
-        bool anynan = false;
-        if (s.logits) {
-            // the row's softmax (decode_kernels.hip softmax_kernel: per-lane partial results over v = lane, lane + 64, ... in
-            // ascending order, the same butterflies, expf(x - m) / sum), written to the score store and kept in registers
-            const float* x = s.logits + (long long)r * Vp;
-            float m = -INFINITY, nn = 0.0f;
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) {
-                const int v = lane + 64 * k;
-                vals[k] = v < V ? x[v] : 0.0f;
-                if (v < V) { m = fmaxf(m, vals[k]); nn += (vals[k] != vals[k]) ? 1.0f : 0.0f; }
-            }
-            m = wave_butterfly(m, [](float a, float b) { return fmaxf(a, b); });
-            if (wave_butterfly(nn, [](float a, float b) { return a + b; }) > 0.0f) m = __builtin_nanf("");
-            float sum = 0.0f;
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) if (lane + 64 * k < V) sum += expf(vals[k] - m);
-            sum = wave_butterfly(sum, [](float a, float b) { return a + b; });
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) {
-                const int v = lane + 64 * k;
-                const float pv = v < V ? expf(vals[k] - m) / sum : 0.0f;
-                if (v < Vp) sc[v] = pv;                      // columns V..Vp-1: exact zeros (K padding of the next step's GEMM)
-                vals[k] = v < V ? pv : -INFINITY;
-                if (v < V && pv != pv) anynan = true;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) {
-                const int v = lane + 64 * k;
-                vals[k] = v < V ? sc[v] : -INFINITY;
-                if (v < V && vals[k] != vals[k]) anynan = true;
+    if (!SPLIT) {
+        for (int i = wave; i < nact; i += NWV) {
+            float vals[VPL];
+            const RowRec rc = expand_row_scores<VPL>(s, p, line, i, step, lane, vals);
+            if (lane == 0) {
+                r_count[i] = rc.count; r_beampos[i] = rc.beampos; r_rej[i] = rc.rej; r_srcpos[i] = rc.srcpos;
+                r_nan[i] = rc.nan; r_rejlate[i] = rc.rejlate;
             }
         }
-        anynan = __any(anynan);
-        if (rej >= 0) {
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) {
-                const int v = lane + 64 * k;
-                if (v == rej && (double)vals[k] < p.rejection) { vals[k] = (float)p.rejection; sc[v] = vals[k]; }
-            }
-        }
-        float hi = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < VPL; ++k) hi = fmaxf(hi, vals[k]);
-        hi = wave_butterfly(hi, [](float a, float b) { return fmaxf(a, b); });
-        const double thr = (double)hi * p.threshold_in;
-        float v0 = __shfl(vals[0], 0, 64);                  // score of index 0
-        float vr = 0.f;
-        if (rej >= 0) {
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) if (lane + 64 * k == rej) vr = vals[k];
-            vr = wave_butterfly(vr, [](float a, float b) { return fmaxf(a, b); });   // scores are >= 0
-        }
-        int cnt = 0, rank0 = 0, rankr = 0;
-#pragma unroll
-        for (int k = 0; k < VPL; ++k) {
-            const int v = lane + 64 * k;
-            if (v < V) {
-                cnt += ((double)vals[k] >= thr) ? 1 : 0;
-                rank0 += better(vals[k], v, v0, 0) ? 1 : 0;
-                if (rej >= 0) rankr += better(vals[k], v, vr, rej) ? 1 : 0;
-            }
-        }
-        {
-            auto add = [](int a, int b) { return a + b; };
-            cnt = wave_butterfly(cnt, add); rank0 = wave_butterfly(rank0, add); rankr = wave_butterfly(rankr, add);
-        }
-        rank0 += 1; rankr += 1;
-        const int beampos = cnt < p.width_in ? cnt : p.width_in;
-        int count = beampos - (rank0 <= beampos ? 1 : 0);          // '' never becomes a node (s2s:1505)
-        const int rejlate = (rej > 0 && rankr > beampos) ? 1 : 0;  // `if rej_idx:` is false for 0 (s2s:1498)
-        count += rejlate;
-        if (anynan) count = 0;
-        if (lane == 0) {
-            r_count[i] = count; r_beampos[i] = beampos; r_rej[i] = rej; r_srcpos[i] = srcpos;
-            r_nan[i] = anynan ? 1 : 0; r_rejlate[i] = rejlate;
+    } else {
+        for (int i = tid; i < nact; i += NT) {
+            const RowRec rc = s.rowrec[line * N + i];
+            r_count[i] = rc.count; r_rej[i] = rc.rej; r_srcpos[i] = rc.srcpos;      // r_rej: the child that is the rejection
         }
     }
     __syncthreads();
@@ -244,67 +333,54 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
 
     BPROF(1);
     // ---------------- A2: iterative selection, node records, keys ----------------
-    for (int i = wave; i < nact; i += NWV) {
-        if (r_count[i] == 0) continue;
-        const int r = line * N + i;
-        const long long exp = (long long)(step + 1) * R + r;
-        const float* sc = s.p_base + exp * Vp;
-        const int node = s.beam_node[r];
-        const int plen = s.n_len[nbase + node];
-        const double pcum = s.n_cum[nbase + node];
-        const double pos = s.apos[r];
-        const int is1 = s.amax1[r];
-        const int beampos = r_beampos[i], srcpos = r_srcpos[i];
-        int rej = r_rej[i];
-        float vals[VPL];
+    auto new_node = [&](const int i, const int k, const int bi, const float bv, const bool isrej, const int node, const int plen,
+                        const double pcum, const double pos, const int is1, const long long exp) {
+        const int slot = r_off[i] + k;
+        const int id = id0 + slot;
+        const float cost = -logf(bv);
+        const double cum = pcum + (double)cost;
+        const int len = plen + 1;
+        const long long g = nbase + id;
+        const int srcpos = r_srcpos[i];
+        s.n_parent[g] = node; s.n_chr[g] = bi; s.n_prob[g] = bv; s.n_cum[g] = cum; s.n_len[g] = len;
+        s.n_exp[g] = (int)exp; s.n_k[g] = k;
+        s.n_rejpos[g] = isrej ? srcpos : -1;
+        s.n_pos[g] = isrej ? (double)srcpos : pos;
+        s.n_is1[g] = isrej ? 1 : is1;
+        s.created[exp * CMAX + k] = (short)bi;
+        const double key = -(cum + p.cost0 * fabs((double)(len - T)));
+        if (big) { g0k[slot] = key; g0i[slot] = id; }
+        else { s_key[slot] = key; s_id[slot] = id; }
+    };
+    if (!SPLIT) {
+        for (int i = wave; i < nact; i += NWV) {
+            if (r_count[i] == 0) continue;
+            const int r = line * N + i;
+            const long long exp = (long long)(step + 1) * R + r;
+            const float* sc = s.p_base + exp * Vp;
+            const int node = s.beam_node[r];
+            const int plen = s.n_len[nbase + node];
+            const double pcum = s.n_cum[nbase + node];
+            const double pos = s.apos[r];
+            const int is1 = s.amax1[r];
+            float vals[VPL];
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; vals[k] = v < V ? sc[v] : -INFINITY; }
-        unsigned long long taken = 0;
-        int created = 0;
-        const int total = beampos + r_rejlate[i];
-        for (int ps = 1; ps <= total; ++ps) {
-            float bv = -INFINITY; int bi = -1;
-            if (ps <= beampos) {
-#pragma unroll
-                for (int k = 0; k < VPL; ++k) {
-                    const int v = lane + 64 * k;
-                    if (v < V && !((taken >> k) & 1ull) && (bi < 0 || better(vals[k], v, bv, bi))) { bv = vals[k]; bi = v; }
-                }
-                {
-                    auto step = [&](const float ov, const int oi) { if (oi >= 0 && (bi < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; } };
-                    step(lane_xor<32>(bv), lane_xor<32>(bi)); step(lane_xor<16>(bv), lane_xor<16>(bi)); step(lane_xor<8>(bv), lane_xor<8>(bi));
-                    step(lane_xor<4>(bv), lane_xor<4>(bi)); step(lane_xor<2>(bv), lane_xor<2>(bi)); step(lane_xor<1>(bv), lane_xor<1>(bi));
-                }
-#pragma unroll
-                for (int k = 0; k < VPL; ++k) if (lane + 64 * k == bi) taken |= 1ull << k;
-            } else {                                   // the rejection candidate beyond the beam width
-                bi = rej; bv = 0.f;
-#pragma unroll
-                for (int k = 0; k < VPL; ++k) if (lane + 64 * k == rej) bv = vals[k];
-                bv = wave_butterfly(bv, [](float a, float b) { return fmaxf(a, b); });
-            }
-            bool isrej = false;
-            if (rej >= 0 && bi == rej) { isrej = true; rej = -1; }
-            if (bi == 0) continue;
-            if (lane == 0) {
-                const int k = created;
-                const int slot = r_off[i] + k;
-                const int id = id0 + slot;
-                const float cost = -logf(bv);
-                const double cum = pcum + (double)cost;
-                const int len = plen + 1;
-                const long long g = nbase + id;
-                s.n_parent[g] = node; s.n_chr[g] = bi; s.n_prob[g] = bv; s.n_cum[g] = cum; s.n_len[g] = len;
-                s.n_exp[g] = (int)exp; s.n_k[g] = k;
-                s.n_rejpos[g] = isrej ? srcpos : -1;
-                s.n_pos[g] = isrej ? (double)srcpos : pos;
-                s.n_is1[g] = isrej ? 1 : is1;
-                s.created[exp * CMAX + k] = (short)bi;
-                const double key = -(cum + p.cost0 * fabs((double)(len - T)));
-                if (big) { g0k[slot] = key; g0i[slot] = id; }
-                else { s_key[slot] = key; s_id[slot] = id; }
-            }
-            ++created;
+            for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; vals[k] = v < V ? sc[v] : -INFINITY; }
+            select_children<VPL>(vals, V, r_beampos[i], r_rejlate[i], r_rej[i], lane, [&](const int k, const int bi, const float bv, const bool isrej) {
+                if (lane == 0) new_node(i, k, bi, bv, isrej, node, plen, pcum, pos, is1, exp);
+            });
+        }
+    } else {
+        // the children were chosen by beam_expand_kernel: one thread per child writes its node record
+        for (int c = tid; c < nnew; c += NT) {
+            int lo = 0, hi = nact;                          // row i with r_off[i] <= c < r_off[i + 1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (r_off[mid] <= c) lo = mid; else hi = mid; }
+            const int i = lo, k = c - r_off[i];
+            const int r = line * N + i;
+            const long long exp = (long long)(step + 1) * R + r;
+            const int node = s.beam_node[r];
+            new_node(i, k, (int)s.cand_idx[(long long)r * CMAX + k], s.cand_val[(long long)r * CMAX + k], k == r_rej[i], node,
+                     s.n_len[nbase + node], s.n_cum[nbase + node], s.apos[r], s.amax1[r], exp);
         }
     }
     __syncthreads();
@@ -497,12 +573,17 @@ void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t strea
     // the OCR-D processor is ~40): one workgroup per line leaves most of the chip idle and walks 256 rows with 8 waves --
     // sixteen waves per line halve the row loops (expansion, selection, next inputs) and the sort / merge passes.
     const bool huge = p.N >= 64;
-#define CASV_BEAM_LAUNCH(VPL_, NWV_) hipLaunchKernelGGL((beam_step_kernel<VPL_, NWV_>), dim3(s.B), dim3(64 * NWV_), lds, stream, s, pp)
-    if (vpl <= 4) { if (huge) CASV_BEAM_LAUNCH(4, 16); else if (wide) CASV_BEAM_LAUNCH(4, 8); else CASV_BEAM_LAUNCH(4, 4); }
-    else if (vpl <= 8) { if (huge) CASV_BEAM_LAUNCH(8, 16); else if (wide) CASV_BEAM_LAUNCH(8, 8); else CASV_BEAM_LAUNCH(8, 4); }
-    else if (vpl <= 16) { if (huge) CASV_BEAM_LAUNCH(16, 16); else if (wide) CASV_BEAM_LAUNCH(16, 8); else CASV_BEAM_LAUNCH(16, 4); }
+    // sixteen waves per line and phase A as a grid of its own (beam_expand_kernel) when the host has given it buffers
+    const bool split = huge && s.rowrec != nullptr;
+#define CASV_BEAM_LAUNCH(VPL_, NWV_) hipLaunchKernelGGL((beam_step_kernel<VPL_, NWV_, false>), dim3(s.B), dim3(64 * NWV_), lds, stream, s, pp)
+#define CASV_BEAM_SPLIT(VPL_) do { hipLaunchKernelGGL((beam_expand_kernel<VPL_>), dim3((s.R + 7) / 8), dim3(512), 0, stream, s, pp); \
+                                   hipLaunchKernelGGL((beam_step_kernel<VPL_, 16, true>), dim3(s.B), dim3(1024), lds, stream, s, pp); } while (0)
+    if (vpl <= 4) { if (split) CASV_BEAM_SPLIT(4); else if (huge) CASV_BEAM_LAUNCH(4, 16); else if (wide) CASV_BEAM_LAUNCH(4, 8); else CASV_BEAM_LAUNCH(4, 4); }
+    else if (vpl <= 8) { if (split) CASV_BEAM_SPLIT(8); else if (huge) CASV_BEAM_LAUNCH(8, 16); else if (wide) CASV_BEAM_LAUNCH(8, 8); else CASV_BEAM_LAUNCH(8, 4); }
+    else if (vpl <= 16) { if (split) CASV_BEAM_SPLIT(16); else if (huge) CASV_BEAM_LAUNCH(16, 16); else if (wide) CASV_BEAM_LAUNCH(16, 8); else CASV_BEAM_LAUNCH(16, 4); }
     else if (vpl <= 32) { if (wide) CASV_BEAM_LAUNCH(32, 8); else CASV_BEAM_LAUNCH(32, 4); }
     else { if (wide) CASV_BEAM_LAUNCH(64, 8); else CASV_BEAM_LAUNCH(64, 4); }
+#undef CASV_BEAM_SPLIT
 #undef CASV_BEAM_LAUNCH
 }
 

@@ -213,6 +213,9 @@ struct BeamParams {
     int eos;       // vocabulary index of the end-of-line character
 };
 
+// What phase A of the beam step finds out about one expansion row (beam_kernels.hip)
+struct RowRec { int count, beampos, rej, srcpos, nan, rejlate; };
+
 struct BeamState {
     // per line
     int B, T, V, S, R;          // R = B*N
@@ -246,6 +249,9 @@ struct BeamState {
     const int* src_rej;         // [B][T]
     const int* step_ptr;        // step number in device memory (graph replay), or nullptr: step_imm
     int step_imm;
+    // wide beams (N >= 64): phase A as its own grid -- per row its record and the list of its children in creation order
+    RowRec* rowrec;             // [R] or nullptr (then the per-line kernel does phase A itself)
+    short* cand_idx; float* cand_val;   // [R][min(beam_width_in, V) + 1]
 };
 void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t stream);
 void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream);

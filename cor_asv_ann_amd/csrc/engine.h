@@ -121,6 +121,7 @@ struct casv_model {
     DevBuf b_parent, b_chr, b_prob, b_cum, b_len, b_exp, b_k, b_rejpos, b_pos, b_is1, b_count, b_created;
     DevBuf b_gkey, b_gid, b_qkey, b_qid, b_qn, b_fkey, b_fid, b_fn, b_ftotal, b_beamnode, b_nact, b_done, b_steps, b_active;
     DevBuf bo_idx, bo_prob, bo_len, bo_score, bo_rej, bo_align, bo_found, bo_nsteps;
+    DevBuf b_rowrec, b_candidx, b_candval;                // wide beams: phase A's per-row results (beam_expand_kernel)
     // training session (train.hip)
     TrainState* train = nullptr;
     // options

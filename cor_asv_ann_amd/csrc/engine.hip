@@ -69,7 +69,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
         &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos, &m->b_pos, &m->b_is1, &m->b_count, &m->b_created,
         &m->b_gkey, &m->b_gid, &m->b_qkey, &m->b_qid, &m->b_qn, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_beamnode, &m->b_nact,
         &m->b_done, &m->b_steps, &m->b_active, &m->bo_idx, &m->bo_prob, &m->bo_len, &m->bo_score,
-        &m->bo_rej, &m->bo_align, &m->bo_found, &m->bo_nsteps};
+        &m->bo_rej, &m->bo_align, &m->bo_found, &m->bo_nsteps, &m->b_rowrec, &m->b_candidx, &m->b_candval};
     for (DevBuf* b : bufs) b->release();
     for (auto& l : m->enc) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
     for (LstmW* l : {&m->enc_fw, &m->enc_bw}) { l->pw.release(); l->pbias.release(); }
@@ -919,6 +919,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     ENS(m->b_beamnode, (size_t)R * 4) ENS(m->b_nact, (size_t)B * 4) ENS(m->b_done, (size_t)B * 4)
     ENS(m->b_steps, (size_t)B * 4) ENS(m->b_active, 16)
     ENS(m->b_gkey, (size_t)2 * B * s.g_cap * 8) ENS(m->b_gid, (size_t)2 * B * s.g_cap * 4)
+    if (N >= 64) { ENS(m->b_rowrec, (size_t)R * sizeof(RowRec)) ENS(m->b_candidx, (size_t)R * CM * 2) ENS(m->b_candval, (size_t)R * CM * 4) }
     const size_t OR = (size_t)B * MR;
     ENS(m->bo_idx, OR * S * 4) ENS(m->bo_prob, OR * S * 4) ENS(m->bo_len, OR * 4) ENS(m->bo_score, OR * 8) ENS(m->bo_rej, OR * S * 4)
     ENS(m->bo_found, (size_t)B * 4) ENS(m->bo_nsteps, (size_t)B * 4)
@@ -936,6 +937,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     s.prev = m->prev.as<int>(); s.p_in = m->pin.as<float>(); s.p_base = m->st_p.as<float>();
     s.apos = m->apos.as<double>(); s.amax1 = m->amax1.as<int>(); s.src_rej = m->d_srcrej.as<int>();
     s.step_ptr = m->d_step.as<int>();
+    if (N >= 64) { s.rowrec = m->b_rowrec.as<RowRec>(); s.cand_idx = m->b_candidx.as<short>(); s.cand_val = m->b_candval.as<float>(); }
     BeamParams p{};
     p.N = N; p.width_in = bp->beam_width_in; p.width_out = bp->beam_width_out; p.max_results = MR;
     p.threshold_in = bp->beam_threshold_in; p.rejection = bp->rejection_threshold; p.cost0 = bp->cost0; p.eos = m->eos;
