@@ -187,15 +187,47 @@ def train_bench(args):
     masks = {'enc': [keep(2 * WIDTH if n == 0 else WIDTH) for n in range(DEPTH)], 'dec': [keep(WIDTH) for _ in range(DEPTH - 1)],
              'cell': keep((B, 2 * WIDTH))}
     eng.train_begin()
+    facade = None
+    if args.facade:
+        # the batches as `Sequence2Sequence.train()` gets them: read from a TSV file, vectorised, degraded, dropout masks drawn --
+        # by the worker thread of training.prefetch while the device runs the step before (keras_train.py:133-145)
+        import tempfile
+        from cor_asv_ann_amd import training
+        from cor_asv_ann_amd.seq2seq import Sequence2Sequence
+        from cor_asv_ann_amd.synthetic import make_vocabulary
+        i_c = make_vocabulary(VOC)[1]
+        n_batches = args.warmup + args.steps
+        src_lines, sidx_all = make_lines(B * n_batches, LENGTH, 104, voc_size=VOC)
+        tgt_idx = sidx_all[:, :LENGTH].copy()
+        sub2 = rng.random(tgt_idx.shape) < 0.05
+        tgt_idx[sub2] = rng.integers(2, VOC, size=int(sub2.sum()))
+        tmp = tempfile.NamedTemporaryFile('w', suffix='.tsv', delete=False, encoding='utf-8')
+        for a, row in zip(src_lines, tgt_idx):
+            tmp.write('%s\t%s\n' % (a[:-1], ''.join(i_c[int(c)] for c in row)))
+        tmp.close()
+        s2s = Sequence2Sequence(device=0)
+        s2s.depth, s2s.width, s2s.batch_size, s2s.dropout = DEPTH, WIDTH, B, 0.2
+        s2s.mapping, s2s.voc_size = make_vocabulary(VOC), VOC
+        s2s.status = 1
+        facade = training.prefetch(training.train_batches(s2s, [tmp.name], None, np.random.default_rng(7)))
+
+    def one_step():
+        if facade is None:
+            return eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=1)
+        idx_, val_, din_, dout_, w_, masks_ = next(facade)
+        return eng.train_step(idx_, val_, din_, dout_, w_, masks_, mode=1)
     for _ in range(args.warmup):
-        eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=1)
+        one_step()
     eng.profile(True)
     eng.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, norm = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=1)
+        loss, norm = one_step()
     eng.synchronize()
     elapsed = time.perf_counter() - t0
+    if facade is not None:
+        facade.close()
+        os.unlink(tmp.name)
     pl, pg, ps = eng.profile_read('lstm_gemm'), eng.profile_read('gemm'), eng.profile_read('lstm_gemm_small')
     eng.profile(False)
     fl, ms = pl['flops'] + pg['flops'] + ps['flops'], pl['ms'] + pg['ms'] + ps['ms']
@@ -205,7 +237,8 @@ def train_bench(args):
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[3]: depth=4 width=512 V=256 train step, batch 512 x 100 chars, dropout 0.2, Adam(clipnorm 5)',
-                   'last_loss': loss, 'last_grad_norm': norm},
+                   'batches': 'read from a TSV file and vectorised by the worker thread of train() (training.prefetch)' if args.facade
+                              else 'one synthetic batch, resident on the host', 'last_loss': loss, 'last_grad_norm': norm},
         'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel (all GEMMs of the step)', 'achieved': fl / max(ms, 1e-9) / 1e9,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / max(ms, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS,
                      'traffic': None, 'launches': pl['launches'] + pg['launches'] + ps['launches'],
@@ -541,6 +574,9 @@ def main():
     ap.add_argument('--lines-per-gpu', type=int, default=0, help='override the lines each GPU decodes per step')
     ap.add_argument('--alignments', type=int, default=0,
                     help='1 = also return the soft alignments (window form), as the OCR-D processor asks for (wrapper/transcode.py:110-115)')
+    ap.add_argument('--facade', type=int, default=0,
+                    help='c4 only: 1 = every batch comes the way Sequence2Sequence.train() gets it (file -> lines -> index arrays, '
+                         'degradation, dropout masks), prepared by train()\'s worker thread while the device runs the step before')
     ap.add_argument('--dump-records', default=None, help='rank 0 saves the gathered records of the last step to this .npy file (tests)')
     args = ap.parse_args()
     if args.gpus < 1:

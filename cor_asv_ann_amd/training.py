@@ -1,11 +1,75 @@
 """Host side of `Sequence2Sequence.train()` (seq2seq.py:590-649 + lib/keras_train.py:27-438): epochs over the
 generator, validation, early stopping / NaN termination / per-epoch checkpoints.  Each batch is ONE call into
 the C ABI (`casv_train_step`), which runs forward, backward, clipping and Adam on the device."""
+import queue
 import signal
+import threading
 
 import numpy as np
 
 from . import keras_h5
+
+
+def prefetch(iterable, depth=2):
+    """Run `iterable` in a worker thread, `depth` items ahead of the consumer -- the reference feeds `train_on_batch` from a
+    `GeneratorEnqueuer` worker (keras_train.py:133-145) so that vectorising the next batch overlaps the device step; here the
+    C ABI call releases the GIL for the whole step, so a thread does.  Exceptions of the producer surface in the consumer;
+    a consumer that stops early (NaN loss, stop signal) releases the producer."""
+    q = queue.Queue(maxsize=max(1, depth))
+    done, stop = object(), threading.Event()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def work():
+        try:
+            for item in iterable:
+                if not put(('item', item)):
+                    return
+        except BaseException as err:            # handed to the consumer
+            put(('error', err))
+            return
+        put(('done', done))
+
+    thread = threading.Thread(target=work, name='casv-batch-prefetch', daemon=True)
+    thread.start()
+    try:
+        while True:
+            kind, item = q.get()
+            if kind == 'done':
+                return
+            if kind == 'error':
+                raise item
+            yield item
+    finally:
+        stop.set()
+        thread.join(timeout=5.0)
+
+
+def train_batches(s2s, filenames, split_rand, rng):
+    """One epoch of training batches in the form `casv_train_step` takes: index arrays of vectorize_lines, the random
+    degradation of seq2seq.py:909-915, the dropout keep-masks (drawn in this order per batch)."""
+    for batch in s2s.gen_lines(filenames, True, split_rand, True):
+        if not batch:
+            return                                 # end of epoch (kt:160-162)
+        src, conf, tgt, _ = batch
+        idx, val, dec_in, dec_out, w = batch_to_indices(s2s, src, tgt, conf)
+        idx, val = degrade(idx, val, rng)
+        yield idx, val, dec_in, dec_out, w, dropout_masks(s2s, len(src), rng)
+
+
+def validation_batches(s2s, filenames, split_rand):
+    for batch in s2s.gen_lines(filenames, True, split_rand, False):
+        if not batch:
+            return
+        src, conf, tgt, _ = batch
+        yield batch_to_indices(s2s, src, tgt, conf)
 
 
 def batch_to_indices(s2s, lines_source, lines_target, lines_conf):
@@ -76,13 +140,9 @@ def train_files(s2s, filenames, val_filenames=None):
         for epoch in range(s2s.epochs):
             total, nb = 0.0, 0
             nan = False
-            for batch in s2s.gen_lines(filenames, True, split_rand, True):
-                if not batch:
-                    break                              # end of epoch (kt:160-162)
-                src, conf, tgt, _ = batch
-                idx, val, dec_in, dec_out, w = batch_to_indices(s2s, src, tgt, conf)
-                idx, val = degrade(idx, val, rng)
-                loss, _ = engine.train_step(idx, val, dec_in, dec_out, w, dropout_masks(s2s, len(src), rng), mode=1)
+            # the next batches are vectorised by a worker thread while the device runs this one (kt:133-145)
+            for idx, val, dec_in, dec_out, w, masks in prefetch(train_batches(s2s, filenames, split_rand, rng)):
+                loss, _ = engine.train_step(idx, val, dec_in, dec_out, w, masks, mode=1)
                 if not np.isfinite(loss):
                     s2s.logger.warning('Batch %d: Invalid loss, terminating training', nb)   # TerminateOnNaN
                     nan = True
@@ -92,11 +152,7 @@ def train_files(s2s, filenames, val_filenames=None):
                     break
             vtotal, vn = 0.0, 0
             if not nan:
-                for batch in s2s.gen_lines(val_filenames or filenames, True, split_rand, False):
-                    if not batch:
-                        break
-                    src, conf, tgt, _ = batch
-                    idx, val, dec_in, dec_out, w = batch_to_indices(s2s, src, tgt, conf)
+                for idx, val, dec_in, dec_out, w in prefetch(validation_batches(s2s, val_filenames or filenames, split_rand)):
                     loss, _ = engine.train_step(idx, val, dec_in, dec_out, w, None, mode=0)
                     vtotal += loss; vn += 1
             val_loss = vtotal / vn if vn else float('nan')

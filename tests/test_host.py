@@ -219,3 +219,41 @@ def test_gen_lines_pickle_formats_and_bad_line_filter(tmp_path):
     assert src[0] == 'good line\n' and src[1] == ''
     (src, _, _, _), = list(s2s.gen_lines([str(bad)], repeat=False, train=False))
     assert src[:2] == ['qwertzuiop\n', 'good line\n']
+
+
+def test_batch_prefetch_runs_ahead_keeps_order_and_hands_errors_over():
+    """training.prefetch: the worker thread of `train()` (the reference's GeneratorEnqueuer, keras_train.py:133-145)."""
+    import threading
+    import time
+    from cor_asv_ann_amd.training import prefetch
+    seen = []
+
+    def slow_producer(n):
+        for i in range(n):
+            time.sleep(0.02)
+            seen.append((i, threading.current_thread().name))
+            yield i
+
+    t0 = time.perf_counter()
+    out = []
+    for item in prefetch(slow_producer(10), depth=2):
+        time.sleep(0.02)                 # the "device step": overlaps with the production of the next items
+        out.append(item)
+    elapsed = time.perf_counter() - t0
+    assert out == list(range(10)) and all(name == 'casv-batch-prefetch' for _, name in seen)
+    assert elapsed < 0.33, elapsed       # serial would be 0.4 s
+
+    def failing():
+        yield 1
+        raise KeyError('boom')
+    got = []
+    with pytest.raises(KeyError):
+        for item in prefetch(failing()):
+            got.append(item)
+    assert got == [1]
+    # a consumer that stops early releases the producer (it must not stay blocked on a full queue)
+    gen = prefetch(iter(range(1000)), depth=1)
+    assert next(gen) == 0
+    gen.close()
+    time.sleep(0.3)
+    assert not any(t.name == 'casv-batch-prefetch' and t.is_alive() for t in threading.enumerate())
