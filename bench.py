@@ -231,7 +231,7 @@ def train_bench(args):
     pl, pg, ps = eng.profile_read('lstm_gemm'), eng.profile_read('gemm'), eng.profile_read('lstm_gemm_small')
     eng.profile(False)
     fl, ms = pl['flops'] + pg['flops'] + ps['flops'], pl['ms'] + pg['ms'] + ps['ms']
-    print(json.dumps({
+    emit(json.dumps({
         'metric': 'trained chars/sec (1 GPU), depth-4 width-512 teacher-forced train step, 100-char lines',
         'value': B * LENGTH * args.steps / elapsed, 'unit': 'chars/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -378,17 +378,27 @@ def decode_bench(args):
         sync_dev = eng.synchronize
     t_gather = [0.0]
 
+    chunks = [lines[b0:b0 + batch] for b0 in range(0, len(lines), batch)]
+
+    def append_records(k):                      # in the device thread, right behind batch k's decode call: a small kernel
+        if dist_on and records == 'device':     # on the same stream packs its results where they lie
+            if eng.B != len(chunks[k]):         # (correct_lines decodes in several chunks only under a memory budget)
+                raise RuntimeError('the last decode call covered %d of %d lines: records must be appended per decode call' % (eng.B, len(chunks[k])))
+            eng.records_append(k * batch)
+
     def step():
         out_lines, probs, scores = [], [], []
         if dist_on and records == 'device':
             eng.records_reset(per_rank, S)
-        for b0 in range(0, len(lines), batch):
-            o, p, s = decode(lines[b0:b0 + batch])
-            if dist_on and records == 'device':
-                if eng.B != len(o):             # (correct_lines decodes in several chunks only under a memory budget)
-                    raise RuntimeError('the last decode call covered %d of %d lines: records must be appended per decode call' % (eng.B, len(o)))
-                eng.records_append(b0)          # a small kernel behind the decode, on the same stream
-            out_lines += o; probs += p; scores += s
+        if dry or wl.get('confmat') or len(chunks) == 1:
+            for k, chunk in enumerate(chunks):
+                o, p, s = decode(chunk)
+                append_records(k)
+                out_lines += o; probs += p; scores += s
+        else:
+            # several batches per step (configs[4]): batch k + 1 is vectorised and decoded while the strings of batch k are built
+            for o, p, s, _ in s2s.correct_batches(chunks, fast=wl['fast'], greedy=wl['fast'], alignments=want_align, after_decode=append_records):
+                out_lines += o; probs += p; scores += s
         if dist_on:
             # fixed-width records (characters, probabilities, length, score) -> RCCL all-gather
             t0 = time.perf_counter()
@@ -521,7 +531,7 @@ def decode_bench(args):
     if rank == 0:
         if world == 1 and not dist_on and args.workload == 'c3' and not args.no_others and not dry:
             result['other_workloads'] = other_workloads()
-        print(json.dumps(result))
+        emit(json.dumps(result))
     return 0
 
 
@@ -559,6 +569,29 @@ def other_workloads():
     return out
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """Keep this process's stdout for the ONE JSON line: file descriptor 1 is pointed at stderr for everything else (RCCL prints
+    a version banner to stdout when a communicator is created, libraries may print notices), the line itself goes to a private
+    duplicate of the original descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line)
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, (line + '\n').encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -592,6 +625,7 @@ def main():
         if '--workload' not in argv:
             argv = argv + ['--workload', args.workload]
         return launch_ranks(args.gpus, argv)
+    claim_stdout()
     if args.workload == 'c4':
         return train_bench(args)
     return decode_bench(args)

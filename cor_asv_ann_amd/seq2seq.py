@@ -452,7 +452,7 @@ class Sequence2Sequence(object):
             start = end
         return out, keep
 
-    def _greedy_results(self, idx, prob, align, nonpad):
+    def _greedy_results(self, idx, prob, align, nonpad, T=None):
         """Per-line bookkeeping of seq2seq.py:1254-1263 on the index/probability matrices, for all lines at once: length up
         to the first end-of-line, string, mean -log p."""
         B, S = idx.shape
@@ -476,18 +476,19 @@ class Sequence2Sequence(object):
                 lines.append(texts[j])
                 probs.append(flat[start:end])
                 scores.append(costs[j])
-                aligns.append(self._alignment_rows(align, j, end - start))
+                aligns.append(self._alignment_rows(align, j, end - start, T))
             start = end
         return lines, probs, scores, aligns
 
-    def _alignment_rows(self, align, j, n):
+    def _alignment_rows(self, align, j, n, T=None):
         """Alignment of result row j, first n steps: a SparseAlignment view over the window form, the reference's list
-        of T-wide rows for a dense array, [] when alignments were not requested."""
+        of T-wide rows for a dense array, [] when alignments were not requested.  T = the padded length of the batch the
+        row was decoded in (default: the engine's last batch)."""
         if align is None:
             return []
         if isinstance(align, tuple):
             lo, w = align
-            return SparseAlignment(lo[j, :n], w[j, :n], self.engine.T)
+            return SparseAlignment(lo[j, :n], w[j, :n], self.engine.T if T is None else T)
         return [align[j, k] for k in range(n)]
 
     def decode_batch_greedy(self, encoder_input_data):
@@ -580,34 +581,71 @@ class Sequence2Sequence(object):
 
     def correct_lines(self, lines, conf=None, fast=True, greedy=True, alignments=True):
         """seq2seq.py:782-842.  Each line must end in a newline.  Returns (lines, probability lists,
-        scores, alignments).  The alignment of a line is a `SparseAlignment`: a list-like view (`alignment[j][i]`, `len`,
+        scores, alignments).  The alignment of a line is a `SparseAlignment`: a list of T-wide rows (`alignment[j][i]`, `len`,
         iteration, `numpy.asarray`) over the window form the device returns -- 12 instead of T floats per character cross
-        PCIe, and `realign.alignment2path` consumes the windows directly.  Extensions: `alignments=False` skips the soft
-        alignments altogether, `alignments='dense'` returns the reference's lists of T-wide numpy rows."""
+        PCIe, the rows are built when first looked at, and `realign.alignment2path` consumes the windows directly.
+        Extensions: `alignments=False` skips the soft alignments altogether, `alignments='dense'` returns the reference's
+        lists of T-wide numpy rows."""
         assert not fast or greedy, "cannot decode in fast mode with beam search enabled"
         if not lines:
             return [], [], [], []
+        prepared = self._prepare_lines(lines, conf)
+        raw = self._decode_prepared(prepared, fast, greedy, alignments)
+        return self._results_of(lines, prepared, raw, fast, greedy, alignments)
+
+    def correct_batches(self, batches, fast=True, greedy=True, alignments=True, after_decode=None):
+        """`correct_lines` over a stream of batches -- an iterable of `lines` or of `(lines, conf)` -- as a three-stage pipeline:
+        a worker thread turns the next batch into index arrays, a second one drives the device (its C-ABI calls release the GIL),
+        and the caller's thread builds strings and lists from the batch before -- so the device does not wait for the Python on
+        either side of it (the reference decodes batch after batch, seq2seq.py:756-780).  Yields what `correct_lines` returns,
+        batch by batch, in order; identical results.  `after_decode(k)`, if given, runs in the device thread right after batch
+        k's decode call (its results still lie in the engine's buffers: e.g. `engine.records_append`)."""
+        assert not fast or greedy, "cannot decode in fast mode with beam search enabled"
+        from .training import prefetch
+        self._require_engine()
+        self._codepoint_table()                 # (the lookup tables exist before the stages' threads ask for them)
+
+        def prepared():
+            for item in batches:
+                lines, conf = item if isinstance(item, tuple) else (item, None)
+                yield lines, (self._prepare_lines(lines, conf) if lines else None)
+
+        def decoded():
+            for k, (lines, prep) in enumerate(prefetch(prepared(), depth=2)):
+                raw = self._decode_prepared(prep, fast, greedy, alignments) if lines else None
+                if after_decode is not None:
+                    after_decode(k)
+                yield lines, prep, raw
+
+        for lines, prep, raw in prefetch(decoded(), depth=1):
+            yield self._results_of(lines, prep, raw, fast, greedy, alignments) if lines else ([], [], [], [])
+
+    # the three stages of correct_lines ------------------------------------------------------------
+    def _prepare_lines(self, lines, conf):
+        """Host, before the device: strings / confidences -> index and value arrays."""
+        idx, val, _ = self._sparse_lines(lines, conf)
+        return idx, val
+
+    def _decode_prepared(self, prepared, fast, greedy, alignments):
+        """The device part: encode + decode, raw result arrays.  (The only stage that talks to the engine.)"""
         eng = self._require_engine()
         want_align = False if not alignments else (True if alignments == 'dense' else 'sparse')
-        idx, val, _ = self._sparse_lines(lines, conf)
+        idx, val = prepared
         B, T = idx.shape[:2]
         if T == 0:                  # nothing but padding lines
-            return self._finish(lines, [('', [], 0, []) for _ in range(B)])
+            return None
         if fast:
             eng.encode(idx, val)
             gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=want_align)
-            nonpad = ((idx >= 0) & (val != 0)).any(axis=(1, 2))     # np.any(encoder_input_data[j]), seq2seq.py:1255
-            return self._greedy_results(gi, gp, ga, nonpad)
+            return gi, gp, ga
         # the per-line modes never decode the empty padding lines of a partial batch (seq2seq.py:815-816) -- an
         # all-zero input row would also trip the greedy mode's NaN rule for the whole batch
-        live = [j for j, line in enumerate(lines) if line]
+        live = [j for j in range(B) if (idx[j] >= 0).any()]
         if greedy:
-            results = [('', [], 0, []) for _ in range(B)]
-            if live:
-                eng.encode(idx[live], val[live])
-                for j, r in zip(live, self._sequence_greedy_results(eng, len(live), want_align)):
-                    results[j] = r
-            return self._finish(lines, results)
+            if not live:
+                return live, []
+            eng.encode(idx[live], val[live])
+            return live, self._sequence_greedy_results(eng, len(live), want_align)
         # The search keeps every expansion's state on the device (nothing is recomputed, nothing crosses to the host):
         # S x (lines x N) rows of h, c per layer, scores and alignments.  Large beams (the reference's default
         # batch_size = 256 hypotheses per step) are therefore decoded in chunks of lines that fit a memory budget;
@@ -617,11 +655,31 @@ class Sequence2Sequence(object):
         per_line = 2 * T * self.batch_size * ((2 * self.depth * self.width + self.voc_size + 32 + T) * 4 + 60 * children)
         budget = float(os.environ.get('CASV_BEAM_MEMORY_GB', '96')) * 2 ** 30
         chunk = int(max(1, min(B, budget // max(per_line, 1))))
-        results = [('', [], 0, []) for _ in range(B)]
+        out = []
         for lo in range(0, len(live), chunk):
             rows = live[lo:lo + chunk]
             eng.encode(idx[rows], val[rows])
             res = eng.decode_beam(max_results=1, want_align=want_align, **self._beam_kwargs())
+            out.append((rows, res, eng.T))
+        return live, out
+
+    def _results_of(self, lines, prepared, raw, fast, greedy, alignments):
+        """Host, after the device: raw arrays -> strings, probability lists, scores, alignment views."""
+        idx, val = prepared
+        B = idx.shape[0]
+        if raw is None:
+            return self._finish(lines, [('', [], 0, []) for _ in range(B)])
+        if fast:
+            gi, gp, ga = raw
+            nonpad = ((idx >= 0) & (val != 0)).any(axis=(1, 2))     # np.any(encoder_input_data[j]), seq2seq.py:1255
+            return self._greedy_results(gi, gp, ga, nonpad, idx.shape[1])
+        live, out = raw
+        results = [('', [], 0, []) for _ in range(B)]
+        if greedy:
+            for j, r in zip(live, out):
+                results[j] = r
+            return self._finish(lines, results)
+        for rows, res, T in out:
             texts, keep = self._texts(res['idx'], res['len'])       # best result of every line of the chunk, in one go
             flat = res['prob'][keep].tolist()                       # likewise the probability lists: one conversion, then slices
             ends = np.cumsum(res['len']).tolist()
@@ -632,7 +690,7 @@ class Sequence2Sequence(object):
                 item = None
                 if n:
                     item = (texts[k], flat[ends[k] - n:ends[k]], scores_[k],
-                            self._alignment_rows(res.get('align_sparse', res['align']), k, n))
+                            self._alignment_rows(res.get('align_sparse', res['align']), k, n, T))
                 if item is None:
                     # the generator of the reference raises StopIteration here (seq2seq.py:826-836)
                     self.logger.error('cannot beam-decode input line %d: "%s"', j, input_line)
@@ -672,11 +730,15 @@ class Sequence2Sequence(object):
     def predict(self, filenames, fast=False, greedy=False, charmap=None):
         """seq2seq.py:756-780: generator of (filenames, lines, scores) per batch."""
         assert self.status == 2
-        for batch in self.gen_lines(filenames, repeat=False, unsupervised=True, charmap=charmap):
-            lines_source, lines_sourceconf, _, lines_filename = batch
-            lines_result, _, scores_result, _ = self.correct_lines(
-                lines_source, lines_sourceconf, fast=fast, greedy=greedy, alignments=False)
-            yield (lines_filename, lines_result, scores_result)
+        names = []
+
+        def batches():
+            for lines_source, lines_sourceconf, _, lines_filename in self.gen_lines(filenames, repeat=False, unsupervised=True, charmap=charmap):
+                names.append(lines_filename)
+                yield lines_source, lines_sourceconf
+        # batch k + 1 is read and vectorised, and the device runs on it, while this generator's consumer handles batch k
+        for k, (lines_result, _, scores_result, _) in enumerate(self.correct_batches(batches(), fast=fast, greedy=greedy, alignments=False)):
+            yield (names[k], lines_result, scores_result)
 
     def map_files(self, filenames):
         """Collect the character set of the files and grow the mapping (seq2seq.py:555-588)."""

@@ -255,3 +255,44 @@ def test_any_width_decodes_like_the_oracle(d, W):
     w_back = s2s._require_engine().get_weights()
     for k, v in weights.items():
         assert w_back[k].shape == np.asarray(v).shape and np.array_equal(w_back[k], np.asarray(v, np.float32)), k
+
+
+@pytest.mark.parametrize('mode', ['fast', 'greedy', 'beam'])
+def test_pipelined_batches_equal_one_call_per_batch(mode):
+    """`correct_batches` (vectorising, device and result building of consecutive batches overlapped in three stages) returns what
+    one `correct_lines` call per batch returns -- strings, probability lists, scores, alignment windows -- incl. ragged batches, a
+    padded partial batch, an empty one, confidences, and the per-batch hook running behind each batch's decode."""
+    cfg = ModelConfig(depth=2, width=64, voc_size=64)
+    weights = make_weights(cfg, emb_scale=14.0)
+    om = OracleModel(cfg, weights, batch_size=4)
+    from cor_asv_ann_amd.seq2seq import Sequence2Sequence
+    s2s = Sequence2Sequence()
+    s2s.depth, s2s.width, s2s.batch_size = 2, 64, 4
+    s2s.mapping, s2s.voc_size = om.mapping, 64
+    s2s.configure(); s2s.set_weights(weights); s2s.status = 2
+    rng = np.random.default_rng(3)
+    batches = []
+    for k, (n, L) in enumerate([(5, 9), (3, 17), (6, 4), (1, 12)]):
+        lines, _ = make_lines(n, L, 40 + k, voc_size=64)
+        if k == 1:
+            lines[1] = lines[1][:6] + '\n'
+        if k == 2:
+            lines += ['', '']                                   # padding of a partial batch (seq2seq.py:1009-1017)
+        conf = [list(rng.uniform(0.5, 1.0, len(line)).astype(np.float32)) for line in lines] if k == 3 else None
+        batches.append((lines, conf))
+    batches.insert(2, ([], None))
+    fast, greedy = mode == 'fast', mode != 'beam'
+    want = []
+    for lines, conf in batches:
+        try:
+            want.append(s2s.correct_lines(lines, conf, fast=fast, greedy=greedy))
+        except ValueError:                                      # the per-line greedy mode's NaN rule (seq2seq.py:1334)
+            pytest.skip('this seed trips the NaN rule of the per-line greedy mode')
+    seen = []
+    got = list(s2s.correct_batches(batches, fast=fast, greedy=greedy, after_decode=seen.append))
+    assert seen == list(range(len(batches))) and len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[0] == w[0] and g[1] == w[1] and g[2] == w[2]
+        assert len(g[3]) == len(w[3])
+        for a, b in zip(g[3], w[3]):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
