@@ -186,6 +186,8 @@ def train_bench(args):
     keep = lambda shape: ((rng.random(shape) >= 0.2) / 0.8).astype(np.float32)
     masks = {'enc': [keep(2 * WIDTH if n == 0 else WIDTH) for n in range(DEPTH)], 'dec': [keep(WIDTH) for _ in range(DEPTH - 1)],
              'cell': keep((B, 2 * WIDTH))}
+    if os.environ.get('CASV_OPT_PERSISTENT'):       # A/B switch: 0 = one launch per time step in the recurrences
+        eng.set_option('persistent', int(os.environ['CASV_OPT_PERSISTENT']))
     eng.train_begin()
     facade = None
     if args.facade:
@@ -229,8 +231,9 @@ def train_bench(args):
         facade.close()
         os.unlink(tmp.name)
     pl, pg, ps = eng.profile_read('lstm_gemm'), eng.profile_read('gemm'), eng.profile_read('lstm_gemm_small')
+    pp = eng.profile_read('persist')
     eng.profile(False)
-    fl, ms = pl['flops'] + pg['flops'] + ps['flops'], pl['ms'] + pg['ms'] + ps['ms']
+    fl, ms = pl['flops'] + pg['flops'] + ps['flops'] + pp['flops'], pl['ms'] + pg['ms'] + ps['ms'] + pp['ms']
     emit(json.dumps({
         'metric': 'trained chars/sec (1 GPU), depth-4 width-512 teacher-forced train step, 100-char lines',
         'value': B * LENGTH * args.steps / elapsed, 'unit': 'chars/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
@@ -239,9 +242,9 @@ def train_bench(args):
         'config': {'workload': 'BASELINE configs[3]: depth=4 width=512 V=256 train step, batch 512 x 100 chars, dropout 0.2, Adam(clipnorm 5)',
                    'batches': 'read from a TSV file and vectorised by the worker thread of train() (training.prefetch)' if args.facade
                               else 'one synthetic batch, resident on the host', 'last_loss': loss, 'last_grad_norm': norm},
-        'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel (all GEMMs of the step)', 'achieved': fl / max(ms, 1e-9) / 1e9,
+        'roofline': {'bound': 'mfma', 'kernel': 'all GEMMs of the step (incl. the persistent recurrences: %.1f ms in %d launches)' % (pp['ms'] / max(args.steps, 1), pp['launches'] // max(args.steps, 1)), 'achieved': fl / max(ms, 1e-9) / 1e9,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / max(ms, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS,
-                     'traffic': None, 'launches': pl['launches'] + pg['launches'] + ps['launches'],
+                     'traffic': None, 'launches': pl['launches'] + pg['launches'] + ps['launches'] + pp['launches'],
                      # the whole step priced with SURVEY.md section 8(d)'s ~133 MFLOP per trained character
                      'whole_path': {'flop_per_char': 133e6,
                                     'frac': B * LENGTH * args.steps / elapsed * 133e6 / 1e12 / PEAK_F32_MFMA_TFLOPS}}}))

@@ -40,6 +40,7 @@ struct TrainState {
     DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, CTX, RecIn, prev, logits, dG, d_enc, du, DWQ, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
     std::vector<DevBuf> O, DO;             // masked layer outputs (encoder O[n], decoder DO[n])
     DevBuf loss, normsq;
+    DevBuf rec_cnt; int rec_launches = 0, rec_skip = 0, rec_penalty = 0;   // persistent recurrences: counters per launch, back-off
     int find(const std::string& n) const { for (size_t i = 0; i < tens.size(); ++i) if (tens[i].name == n) return (int)i; return -1; }
     float* W_(int i) { return tens[i].w.as<float>(); }
     float* G_(int i) { return tens[i].g.as<float>(); }
@@ -108,7 +109,7 @@ int casv_train_release(casv_model* m) {
     DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
         &ts->m_cell, &ts->X0, &ts->H1, &ts->u, &ts->Y0, &ts->Ym, &ts->WQ, &ts->Ast, &ts->WIN, &ts->CTX, &ts->RecIn, &ts->prev,
         &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl, &ts->dYl, &ts->dOin, &ts->dcbuf2, &ts->dvaP, &ts->dbvP,
-        &ts->loss, &ts->normsq};
+        &ts->loss, &ts->normsq, &ts->rec_cnt};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : ts->O) b.release();
     for (auto& b : ts->DO) b.release();
@@ -339,6 +340,44 @@ static int layers_backward(casv_model* m, const LayerBwd* a, int count) {
     return 0;
 }
 
+// Forward recurrence of up to two independent plain layers: ONE persistent launch (train_persist.hip) where the shape has
+// one and the device is ours, else one launch per step for both (the two are interchangeable bit for bit).
+struct LayerFwd { TLayer* l; const float* h0; const float* c0; };
+static int layers_forward(casv_model* m, const LayerFwd* a, int count) {
+    TrainState* ts = m->train;
+    const int W = m->W, B = ts->B;
+    int maxlen = 0;
+    for (int j = 0; j < count; ++j) maxlen = std::max(maxlen, a[j].l->len);
+    if (m->persist_mode != 0 && ts->rec_skip == 0 && ts->rec_launches < 16 && m->ncu >= 64) {
+        RecArgs ra{};
+        ra.njobs = count; ra.B = B; ra.W = W;
+        for (int j = 0; j < count; ++j) {
+            TLayer& l = *a[j].l;
+            ra.job[j] = RecJob{ts->W_(l.iwr), l.Z.as<float>(), l.hs, l.hs_ld, l.Cs.as<float>(), l.Gt.as<float>(), a[j].h0, a[j].c0, l.len,
+                               l.reverse ? 1 : 0};
+        }
+        const size_t cb = train_recurrence_counter_bytes(B);
+        ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
+        if (const int grid = train_recurrence_grid(ra, m->ncu)) {
+            hipEvent_t ev{};
+            double flops = 0;
+            for (int j = 0; j < count; ++j) flops += 2.0 * B * 4.0 * W * W * a[j].l->len;
+            m->prof_begin(PC_PERSIST, flops, 0.0, ev);
+            launch_train_recurrence(ra, grid, m->stream);
+            m->prof_end(PC_PERSIST, ev);
+            ++ts->rec_launches;
+            return 0;
+        }
+    }
+    for (int k = 0; k < maxlen; ++k) {
+        GemmBatch b{};
+        for (int j = 0; j < count; ++j)
+            if (k < a[j].l->len) b.g[b.count++] = layer_step_job(m, *a[j].l, k, a[j].h0, a[j].c0, nullptr);
+        run_gemm_batch(m, EPI_LSTM, b);
+    }
+    return 0;
+}
+
 extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T, int32_t U, int32_t A,
                                const int32_t* enc_idx, const float* enc_val, const int32_t* dec_in, const int32_t* dec_out,
                                const float* weights, const float* mask_enc, const float* mask_dec, const float* mask_cell,
@@ -377,6 +416,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         else if (l.name == "enc1_bw") { l.hs = ts->H1.as<float>() + W; l.hs_ld = 2 * W; }
         else { ENS(l.Hown, rows * W * 4) l.hs = l.Hown.as<float>(); l.hs_ld = W; }
     }
+    ENS(ts->rec_cnt, 16 * train_recurrence_counter_bytes(B))
     for (int n = 1; n <= D; ++n) ENS(ts->O[n], TB * (n == 1 ? 2 * W : W) * 4)
     for (int n = 1; n < D; ++n) ENS(ts->DO[n], UB * W * 4)
 #undef ENS
@@ -398,6 +438,9 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     const float inv_count = 1.0f / (float)std::max(cnt, 1L);
     HIPCHK(hipMemsetAsync(ts->loss.p, 0, 16, st));
     HIPCHK(hipMemsetAsync(ts->normsq.p, 0, 16, st));
+    HIPCHK(hipMemsetAsync(ts->rec_cnt.p, 0, 16 * train_recurrence_counter_bytes(B), st));
+    ts->rec_launches = 0;
+    if (ts->rec_skip > 0) --ts->rec_skip;
     if (training) for (auto& t : ts->tens) HIPCHK(hipMemsetAsync(t.g.p, 0, t.n * 4, st));
 
     TLayer* Lfw = &ts->layers[0]; TLayer* Lbw = &ts->layers[1];
@@ -412,13 +455,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     launch_embed_tm(ts->W_(ts->iE), ts->e_idx.as<int>(), enc_val ? ts->e_val.as<float>() : nullptr, ts->X0.as<float>(), B, T, A, V, W, st);
     layer_input_gemm(m, *Lfw, ts->X0.as<float>(), W);
     layer_input_gemm(m, *Lbw, ts->X0.as<float>(), W);
-    for (int k = 0; k < T; ++k) {
-        GemmBatch b{};
-        b.g[0] = layer_step_job(m, *Lfw, k, nullptr, nullptr, nullptr);
-        b.g[1] = layer_step_job(m, *Lbw, k, nullptr, nullptr, nullptr);
-        b.count = 2;
-        run_gemm_batch(m, EPI_LSTM, b);
-    }
+    { const LayerFwd f[2] = {{Lfw, nullptr, nullptr}, {Lbw, nullptr, nullptr}}; if (int rc = layers_forward(m, f, 2)) return rc; }
     // final states handed to the decoder: layer 1 = backward direction after t = 0 (seq2seq.py:280)
     HIPCHK(hipMemcpy2DAsync(hfin, (size_t)W * 4, Lbw->hs, (size_t)2 * W * 4, (size_t)W * 4, B, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(cfin, Lbw->Cs.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
@@ -433,12 +470,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         layer_input_gemm(m, le, ts->O[n - 1].as<float>(), le.kx);
         layer_input_gemm(m, ld, y, W);
         const float* h0 = hfin + (size_t)(n - 2) * B * W; const float* c0 = cfin + (size_t)(n - 2) * B * W;
-        for (int k = 0; k < L; ++k) {
-            GemmBatch b{};
-            if (k < T) b.g[b.count++] = layer_step_job(m, le, k, nullptr, nullptr, nullptr);
-            if (k < U) b.g[b.count++] = layer_step_job(m, ld, k, h0, c0, nullptr);
-            run_gemm_batch(m, EPI_LSTM, b);
-        }
+        { const LayerFwd f[2] = {{&le, nullptr, nullptr}, {&ld, h0, c0}}; if (int rc = layers_forward(m, f, 2)) return rc; }
         HIPCHK(hipMemcpyAsync(hfin + (size_t)(n - 1) * B * W, le.hs + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(cfin + (size_t)(n - 1) * B * W, le.Cs.as<float>() + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
         launch_mul_mask(le.hs, W, menc_n(n), ts->O[n].as<float>(), W, TB, W, st);
@@ -477,6 +509,26 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     { GemmArgs g = plain_gemm(top.hs, W, (int)UB, W, ts->W_(ts->iE), V, nullptr, ts->logits.as<float>(), Vp); run_gemm(m, EPI_PLAIN, g); }
     launch_softmax_ce(ts->logits.as<float>(), ts->d_out.as<int>(), ts->d_w.as<float>(), B, U, V, Vp, inv_count, ts->loss.as<double>(),
                       training ? 1 : 0, st);
+    if (ts->rec_launches) {
+        // Did every persistent recurrence run to its end?  (A launch gives up when its workgroups wait too long for each other --
+        // a GPU shared with another process: handoff.h.)  Nothing has been updated yet: start over with per-step launches, and
+        // keep to them for the next 16, 32, ... steps.
+        unsigned gave_up[16] = {0};
+        const size_t cb = train_recurrence_counter_bytes(B);
+        for (int i = 0; i < ts->rec_launches; ++i)
+            HIPCHK(hipMemcpyAsync(&gave_up[i], static_cast<char*>(ts->rec_cnt.p) + cb * (i + 1) - 32 * sizeof(unsigned), 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        bool any = false;
+        for (int i = 0; i < ts->rec_launches; ++i) any |= gave_up[i] != 0;
+        if (any) {
+            ts->rec_penalty = ts->rec_penalty ? std::min(2 * ts->rec_penalty, 1 << 20) : 16;
+            ts->rec_skip = ts->rec_penalty + 1;
+            fprintf(stderr, "cor_asv_ann_hip: a persistent recurrence of the train step gave up waiting (is the GPU shared?); "
+                            "per-step launches for the next %d steps\n", ts->rec_penalty);
+            return casv_train_step(m, mode, B, T, U, A, enc_idx, enc_val, dec_in, dec_out, weights, mask_enc, mask_dec, mask_cell, loss_out, norm_out);
+        }
+        ts->rec_penalty = 0;
+    }
     if (!training) {                       // K.in_train_phase: the regulariser counts only in the train phase
         HIPCHK(hipMemcpyAsync(loss_out, ts->loss.p, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

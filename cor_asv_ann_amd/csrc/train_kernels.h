@@ -17,6 +17,20 @@ void launch_mul_rowmask(const float* in, long long ld_in, const float* mask, lon
 void launch_softmax_ce(float* logits, const int* target, const float* weight, int B, int U, int V, int Vp, float inv_count,
                        double* loss, int want_grad, hipStream_t st);
 
+// The forward recurrence of up to two independent plain LSTM layers over all their time steps as ONE launch (train_persist.hip).
+struct RecJob {
+    const float* Wr;                 // [4W][W] recurrent weights, rows gate-interleaved in groups of 32 units (train.hip)
+    const float* Z;                  // [len][B][4W]  x.Wx + b of every step
+    float* hs; long long hs_ld;      // [len][B][hs_ld] outputs
+    float* Cs; float* Gt;            // [len][B][W] cell states, [len][B][4W] gate activations (kept for the backward pass)
+    const float* h0; const float* c0;   // [B][W] initial state or nullptr (zeros)
+    int len, reverse;
+};
+struct RecArgs { RecJob job[2]; int njobs, B, W; unsigned* counters; };
+size_t train_recurrence_counter_bytes(int B);
+int train_recurrence_grid(const RecArgs& ra, int ncu);      // 0: no persistent form for this shape on this device
+void launch_train_recurrence(const RecArgs& ra, int grid, hipStream_t stream);
+
 struct LstmBwdArgs {
     const float* a; long long lda; const float* mask_a;     // gradient from the layer above (x dropout mask)
     const float* b; long long ldb;                           // recurrent gradient

@@ -18,7 +18,9 @@ def _idx(a):
                                                      (3, 64, 96, 8, 12, 6.0, True), (4, 64, 96, 6, 10, 8.0, False),
                                                      # widths that are no multiple of 32 (dead-unit padding, engine.py)
                                                      (1, 20, 24, 3, 7, 3.0, True), (2, 50, 40, 4, 9, 4.0, True)])
-def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks):
+@pytest.mark.parametrize('persistent', [-1, 0])
+def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks, persistent):
+    """persistent -1: the forward recurrences as one launch per pair of layers (train_persist.hip); 0: one launch per step."""
     from cor_asv_ann_amd.engine import HipEngine
     cfg = ModelConfig(depth=d, width=W, voc_size=V)
     w = make_weights(cfg, emb_scale=es)
@@ -40,6 +42,7 @@ def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks):
     loss, grads, aux = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, masks)
     eng = HipEngine(d, W, V)
     eng.set_weights(w)
+    eng.set_option('persistent', persistent)
     eng.train_begin()
     gl, gn = eng.train_step(sidx, None, _idx(dec_in), _idx(dec_out), wts, masks, mode=2)
     onorm = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values()))
@@ -290,5 +293,14 @@ def test_c4_full_size_step_equals_oracle(golden_dir):
     # a second evaluation of the same step: float atomics may reorder sums, nothing else may move
     loss2, norm2 = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
     assert abs(loss2 - loss) < 1e-6 * abs(loss) and abs(norm2 - norm) < 1e-5 * norm
+    # ... and with one launch per time step in the forward recurrences instead of the persistent launches: the same forward
+    # pass bit for bit (the loss is an fp64 sum of the same fp32 terms), the same gradients up to the order of atomic sums
+    eng.set_option('persistent', 0)
+    loss3, norm3 = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
+    assert abs(loss3 - loss) < 1e-12 * abs(loss) and abs(norm3 - norm) < 1e-5 * norm
+    eval_a, _ = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=0)
+    eng.set_option('persistent', -1)
+    eval_b, _ = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=0)
+    assert abs(eval_a - eval_b) < 1e-12 * abs(eval_a)
     eng.train_end()
     eng.close()
