@@ -186,8 +186,9 @@ def train_bench(args):
     keep = lambda shape: ((rng.random(shape) >= 0.2) / 0.8).astype(np.float32)
     masks = {'enc': [keep(2 * WIDTH if n == 0 else WIDTH) for n in range(DEPTH)], 'dec': [keep(WIDTH) for _ in range(DEPTH - 1)],
              'cell': keep((B, 2 * WIDTH))}
-    if os.environ.get('CASV_OPT_PERSISTENT'):       # A/B switch: 0 = one launch per time step in the recurrences
-        eng.set_option('persistent', int(os.environ['CASV_OPT_PERSISTENT']))
+    for opt in ('persistent', 'fused_backward'):    # A/B switches: 0 = one launch per time step and operation
+        if os.environ.get('CASV_OPT_' + opt.upper()):
+            eng.set_option(opt, int(os.environ['CASV_OPT_' + opt.upper()]))
     eng.train_begin()
     facade = None
     if args.facade:
@@ -198,7 +199,7 @@ def train_bench(args):
         from cor_asv_ann_amd.seq2seq import Sequence2Sequence
         from cor_asv_ann_amd.synthetic import make_vocabulary
         i_c = make_vocabulary(VOC)[1]
-        n_batches = args.warmup + args.steps
+        n_batches = args.warmup + 2 * args.steps          # (the timed steps, and again for the per-kernel pass)
         src_lines, sidx_all = make_lines(B * n_batches, LENGTH, 104, voc_size=VOC)
         tgt_idx = sidx_all[:, :LENGTH].copy()
         sub2 = rng.random(tgt_idx.shape) < 0.05
@@ -220,13 +221,18 @@ def train_bench(args):
         return eng.train_step(idx_, val_, din_, dout_, w_, masks_, mode=1)
     for _ in range(args.warmup):
         one_step()
-    eng.profile(True)
     eng.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, norm = one_step()
     eng.synchronize()
     elapsed = time.perf_counter() - t0
+    # the GEMMs' own time: a second pass over the same steps with HIP events around every launch (kept out of the timed
+    # region: ~1300 event pairs per step keep consecutive kernels from overlapping and cost 6.5 ms of a 75 ms step)
+    eng.profile(True)
+    for _ in range(args.steps):
+        one_step()
+    eng.synchronize()
     if facade is not None:
         facade.close()
         os.unlink(tmp.name)
@@ -430,7 +436,10 @@ def decode_bench(args):
     for _ in range(args.warmup):
         step()
     if eng:
-        eng.profile(2)      # HIP events around the launches of the dominant kernel, on the library's stream
+        # HIP events around launches of the dominant kernel, on the library's stream: around every 13th of them (level 3) --
+        # an event pair keeps the next launch from overlapping the kernel's tail, which costs ~8 us per pair: around every
+        # launch (level 2) the timed region of c3 is 2 % slower than without events
+        eng.profile(int(os.environ.get('CASV_BENCH_PROFILE', '2' if dom == 'persist' else '3')))
     t_gather[0] = 0.0
     t_realign[0] = 0.0
     sync()

@@ -60,6 +60,8 @@ inline const char* kProfNames[PC_COUNT] = {"lstm_gemm", "gemm", "attention", "so
 struct Prof {
     bool on = false;
     bool only_lstm = false;          // level 2: events only around the dominant kernel (cheaper inside a timed region)
+    int sample = 1; long long seen = 0;   // level 3: ... and only around every `sample`-th of its launches (an event pair keeps
+                                     // the next launch from overlapping the kernel's tail: ~8 us each, 2 % of a decode step)
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     struct Rec { hipEvent_t a, b; int cls; };
@@ -127,6 +129,7 @@ struct casv_model {
     // options
     int eos = 1;                                          // vocabulary index of '\n' (seq2seq.py:1255,1344,1402)
     bool use_graph = false;
+    bool fused_backward = true;                           // train step: cell backward fused into the step's data GEMM (gemm_bwd.hip)
     const int* skip_nact = nullptr;                       // beam decode: live rows per line, handed to the step's kernels when
     int skip_group = 0;                                   // skipping can pay (wide beams, or a line has finished); rows per line
     // the captured step graph of the last decode configuration (option "graph"): kept across calls, rebuilt when the
@@ -140,12 +143,14 @@ struct casv_model {
     Prof prof;
 
     void prof_begin(int cls, double fl, double by, hipEvent_t& a) {
+        a = nullptr;
         if (!prof.on || (prof.only_lstm && cls != PC_LSTM && cls != PC_PERSIST)) return;
+        if (prof.sample > 1 && (prof.seen++ % prof.sample)) return;
         a = prof.get(); (void)hipEventRecord(a, stream);
         prof.flops[cls] += fl; prof.bytes[cls] += by; prof.launches[cls] += 1;
     }
     void prof_end(int cls, hipEvent_t a) {
-        if (!prof.on || (prof.only_lstm && cls != PC_LSTM && cls != PC_PERSIST)) return;
+        if (!a) return;
         hipEvent_t b = prof.get(); (void)hipEventRecord(b, stream);
         prof.recs.push_back({a, b, cls});
     }

@@ -1110,7 +1110,9 @@ extern "C" int casv_profile(casv_model* m, int32_t enable) {
     HIPCHK(hipStreamSynchronize(m->stream));
     m->prof.reset();
     m->prof.on = enable != 0;
-    m->prof.only_lstm = enable == 2;
+    m->prof.only_lstm = enable == 2 || enable == 3;
+    m->prof.sample = enable == 3 ? 13 : 1;       // (13: coprime to the layers of a step, every layer is sampled equally often)
+    m->prof.seen = 0;
     return CASV_OK;
 }
 
@@ -1184,6 +1186,7 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
         if (value < 0 || value >= m->V) return fail(CASV_ERR_ARG, "eos index %lld outside the vocabulary", (long long)value);
         m->eos = (int)value; return CASV_OK;
     }
+    if (!strcmp(key, "fused_backward")) { m->fused_backward = value != 0; return CASV_OK; }
     if (!strcmp(key, "skinny") || !strcmp(key, "tile")) {   // process-wide: tile shape of the GEMM launches (results identical)
         if (value < -1 || value > 1) return fail(CASV_ERR_ARG, "tile must be -1 (by size), 0 (128x128) or 1 (32x128)");
         set_gemm_tile_mode((int)value); return CASV_OK;

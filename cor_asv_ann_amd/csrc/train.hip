@@ -40,6 +40,7 @@ struct TrainState {
     DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, CTX, RecIn, prev, logits, dG, d_enc, du, DWQ, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
     std::vector<DevBuf> O, DO;             // masked layer outputs (encoder O[n], decoder DO[n])
     DevBuf loss, normsq;
+    DevBuf dcalt;                          // second dL/dc buffers of the fused backward steps (two layers)
     DevBuf rec_cnt; int rec_launches = 0, rec_skip = 0, rec_penalty = 0;   // persistent recurrences: counters per launch, back-off
     int find(const std::string& n) const { for (size_t i = 0; i < tens.size(); ++i) if (tens[i].name == n) return (int)i; return -1; }
     float* W_(int i) { return tens[i].w.as<float>(); }
@@ -109,7 +110,7 @@ int casv_train_release(casv_model* m) {
     DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
         &ts->m_cell, &ts->X0, &ts->H1, &ts->u, &ts->Y0, &ts->Ym, &ts->WQ, &ts->Ast, &ts->WIN, &ts->CTX, &ts->RecIn, &ts->prev,
         &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl, &ts->dYl, &ts->dOin, &ts->dcbuf2, &ts->dvaP, &ts->dbvP,
-        &ts->loss, &ts->normsq, &ts->rec_cnt};
+        &ts->loss, &ts->normsq, &ts->rec_cnt, &ts->dcalt};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : ts->O) b.release();
     for (auto& b : ts->DO) b.release();
@@ -323,6 +324,33 @@ static int layers_backward(casv_model* m, const LayerBwd* a, int count) {
         else HIPCHK(hipMemsetAsync(a[j].dc, 0, (size_t)B * W * 4, m->stream));
         maxlen = std::max(maxlen, a[j].l->len);
     }
+    if (m->fused_backward) {
+        // one launch per step for both layers: the cells' backward inside the data GEMM (gemm_bwd.hip); dL/dc ping-pongs
+        float* dcb[2][2];
+        int done[2] = {0, 0};
+        for (int j = 0; j < count; ++j) { dcb[j][0] = a[j].dc; dcb[j][1] = ts->dcalt.as<float>() + (size_t)j * B * W; }
+        for (int i = 0; i < maxlen; ++i) {
+            BwdStepBatch fb{};
+            double flops = 0, bytes = 0;
+            for (int j = 0; j < count; ++j) {
+                const int k = a[j].l->len - 1 - i;
+                if (k < 0) continue;
+                BwdStepJob& q = fb.j[fb.count++];
+                q.p = layer_backward_pointwise(m, a[j], k);
+                q.dc_in = dcb[j][done[j] & 1]; q.p.dc = dcb[j][(done[j] + 1) & 1];
+                ++done[j];
+                const GemmArgs g = layer_backward_gemm(m, a[j], k);
+                q.Bt = g.Bt; q.out = g.out.base; q.ld_out = g.out.ld; q.N = g.N;
+                flops += 2.0 * B * (double)g.N * 4.0 * W; bytes += 4.0 * ((double)B * 4 * W + (double)g.N * 4 * W + (double)B * g.N);
+            }
+            hipEvent_t ev{};
+            m->prof_begin(PC_GEMM, flops, bytes, ev);
+            launch_lstm_bwd_gemm(fb, m->stream);
+            m->prof_end(PC_GEMM, ev);
+        }
+        for (int j = 0; j < count; ++j)
+            if (done[j] & 1) HIPCHK(hipMemcpyAsync(a[j].dc, dcb[j][1], (size_t)B * W * 4, hipMemcpyDeviceToDevice, m->stream));
+    } else
     for (int i = 0; i < maxlen; ++i) {
         GemmBatch b{};
         LstmBwdBatch pw{};
@@ -416,7 +444,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         else if (l.name == "enc1_bw") { l.hs = ts->H1.as<float>() + W; l.hs_ld = 2 * W; }
         else { ENS(l.Hown, rows * W * 4) l.hs = l.Hown.as<float>(); l.hs_ld = W; }
     }
-    ENS(ts->rec_cnt, 16 * train_recurrence_counter_bytes(B))
+    ENS(ts->rec_cnt, 16 * train_recurrence_counter_bytes(B)) ENS(ts->dcalt, (size_t)2 * B * W * 4)
     for (int n = 1; n <= D; ++n) ENS(ts->O[n], TB * (n == 1 ? 2 * W : W) * 4)
     for (int n = 1; n < D; ++n) ENS(ts->DO[n], UB * W * 4)
 #undef ENS
@@ -569,9 +597,22 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             p.cell = top.Cs.as<float>() + (long long)t * B * W;
             p.c_prev = t > 0 ? top.Cs.as<float>() + (long long)(t - 1) * B * W : c0t; p.ld_cprev = W;
             p.dc = dc; p.dz = top.Z.as<float>() + (long long)t * B * 4 * W; p.rows = B; p.W = W;
-            launch_lstm_bwd(p, st);
             float* drec = top.dRec.as<float>() + (long long)t * B * kr;
-            { GemmArgs g = plain_gemm(p.dz, 4 * W, B, 4 * W, top.wrT.as<float>(), kr, nullptr, drec, kr); g.out_zeroed = 1; run_gemm(m, EPI_PLAIN, g); }
+            if (m->fused_backward) {
+                BwdStepBatch fb{};
+                fb.count = 1;
+                BwdStepJob& q = fb.j[0];
+                q.p = p;
+                q.dc_in = ((U - 1 - t) & 1) ? ts->dcalt.as<float>() : dc; q.p.dc = ((U - 1 - t) & 1) ? dc : ts->dcalt.as<float>();
+                q.Bt = top.wrT.as<float>(); q.out = drec; q.ld_out = kr; q.N = kr;
+                hipEvent_t ev{};
+                m->prof_begin(PC_GEMM, 2.0 * B * (double)kr * 4.0 * W, 4.0 * ((double)B * 4 * W + (double)kr * 4 * W + (double)B * kr), ev);
+                launch_lstm_bwd_gemm(fb, st);
+                m->prof_end(PC_GEMM, ev);
+            } else {
+                launch_lstm_bwd(p, st);
+                GemmArgs g = plain_gemm(p.dz, 4 * W, B, 4 * W, top.wrT.as<float>(), kr, nullptr, drec, kr); g.out_zeroed = 1; run_gemm(m, EPI_PLAIN, g);
+            }
             AttnBwdArgs ab{};
             ab.dxh = drec; ab.ld_dxh = kr; ab.ctx_off = 0; ab.mcell = mcell; ab.ld_mcell = W + C; ab.mc_off = W;
             ab.a = ts->Ast.as<float>() + (long long)(t + 1) * B * T; ab.win = ts->WIN.as<int>() + (long long)t * B;
@@ -585,6 +626,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             g.out_zeroed = 1;
             run_gemm(m, EPI_PLAIN, g);
         }
+        if (m->fused_backward && (U & 1)) HIPCHK(hipMemcpyAsync(dc, ts->dcalt.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));   // dL/dc0 of the cell
         launch_colsum(ts->dvaP.as<float>(), B, W, W, ts->G_(ts->iva), st);
         launch_colsum(ts->dbvP.as<float>(), B, 1, 1, ts->G_(ts->ibv), st);
         // dL/dh0 of the cell = recurrent part of step 0 + the query path of step 0

@@ -45,6 +45,12 @@ struct LstmBwdBatch { LstmBwdArgs a[2]; int count; };     // independent layers 
 void launch_lstm_bwd(const LstmBwdArgs& p, hipStream_t st);
 void launch_lstm_bwd_batch(const LstmBwdBatch& b, hipStream_t st);
 
+// ... and the same with the data GEMM out[rows][N] (+)= dz[rows][4W] . Bt[N][4W]^T of that step behind it, as one launch
+// (gemm_bwd.hip).  p.dc is written (dL/dc of the previous step), dc_in is read: two different buffers.  `out` is zeroed.
+struct BwdStepJob { LstmBwdArgs p; const float* dc_in; const float* Bt; float* out; long long ld_out; int N; };
+struct BwdStepBatch { BwdStepJob j[2]; int count; };
+void launch_lstm_bwd_gemm(const BwdStepBatch& b, hipStream_t st);
+
 struct AttnBwdArgs {
     const float* dxh; long long ld_dxh; int ctx_off;         // dL/dx of the cell input; context part at ctx_off
     const float* mcell; long long ld_mcell; int mc_off;      // per-sample input mask (context part at mc_off) or nullptr

@@ -207,7 +207,9 @@ int casv_comm_all_gather_records(casv_model* m, int32_t* recv);
 
 /* Measurement support for bench.py: per-kernel HIP-event timing on the library's stream.
  * casv_profile(m, 1) starts recording for all kernel classes, casv_profile(m, 2) only for "lstm_gemm" (fewer
- * event records inside a timed region), casv_profile(m, 0) stops; casv_profile_read returns, for kernel class `name`
+ * event records inside a timed region), casv_profile(m, 3) only for every 13th launch of it (an event pair keeps the next
+ * launch from overlapping the kernel's tail, ~8 us each: level 2 costs a beamed decode 2 %, level 3 0.2 %),
+ * casv_profile(m, 0) stops; casv_profile_read returns, for kernel class `name`
  * ("lstm_gemm", "lstm_gemm_small", "gemm", "attention", "softmax", "beam", "embed", "persist"), the number of launches, their
  * summed duration (ms) and their summed algorithmic FLOPs and bytes. */
 int casv_profile(casv_model* m, int32_t enable);

@@ -17,10 +17,13 @@ def _idx(a):
 @pytest.mark.parametrize('d,W,V,B,L,es,with_masks', [(1, 32, 40, 4, 9, 3.0, False), (2, 32, 40, 4, 9, 3.0, True),
                                                      (3, 64, 96, 8, 12, 6.0, True), (4, 64, 96, 6, 10, 8.0, False),
                                                      # widths that are no multiple of 32 (dead-unit padding, engine.py)
-                                                     (1, 20, 24, 3, 7, 3.0, True), (2, 50, 40, 4, 9, 4.0, True)])
-@pytest.mark.parametrize('persistent', [-1, 0])
-def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks, persistent):
-    """persistent -1: the forward recurrences as one launch per pair of layers (train_persist.hip); 0: one launch per step."""
+                                                     (1, 20, 24, 3, 7, 3.0, True), (2, 50, 40, 4, 9, 4.0, True),
+                                                     # three / five unit groups per K share of the fused backward step
+                                                     (2, 96, 40, 5, 8, 4.0, True), (3, 160, 40, 3, 6, 4.0, False)])
+@pytest.mark.parametrize('path', ['fused', 'stepwise'])
+def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks, path):
+    """fused: the forward recurrences as one launch per pair of layers (train_persist.hip), the cell's backward inside the
+    backward steps' data GEMM (gemm_bwd.hip); stepwise: one launch per time step and per operation."""
     from cor_asv_ann_amd.engine import HipEngine
     cfg = ModelConfig(depth=d, width=W, voc_size=V)
     w = make_weights(cfg, emb_scale=es)
@@ -42,7 +45,8 @@ def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks, persistent):
     loss, grads, aux = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, masks)
     eng = HipEngine(d, W, V)
     eng.set_weights(w)
-    eng.set_option('persistent', persistent)
+    eng.set_option('persistent', -1 if path == 'fused' else 0)
+    eng.set_option('fused_backward', 1 if path == 'fused' else 0)
     eng.train_begin()
     gl, gn = eng.train_step(sidx, None, _idx(dec_in), _idx(dec_out), wts, masks, mode=2)
     onorm = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values()))
@@ -298,9 +302,39 @@ def test_c4_full_size_step_equals_oracle(golden_dir):
     eng.set_option('persistent', 0)
     loss3, norm3 = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
     assert abs(loss3 - loss) < 1e-12 * abs(loss) and abs(norm3 - norm) < 1e-5 * norm
+    # ... and with the cell's backward as a launch of its own in front of every backward step's data GEMM
+    eng.set_option('fused_backward', 0)
+    loss4, norm4 = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
+    assert abs(loss4 - loss) < 1e-12 * abs(loss) and abs(norm4 - norm) < 2e-5 * norm
+    grads4 = eng.train_gradients()
+    for k, got in grads.items():
+        scale = max(float(g['max/' + k]), 1e-6 * onorm)
+        assert np.abs(grads4[k] - got).max() < 1e-4 * scale + 1e-7, k
+    eng.set_option('fused_backward', 1)
     eval_a, _ = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=0)
     eng.set_option('persistent', -1)
     eval_b, _ = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=0)
     assert abs(eval_a - eval_b) < 1e-12 * abs(eval_a)
     eng.train_end()
     eng.close()
+
+
+def test_fused_backward_step_against_the_host(tmp_path):
+    """One fused backward step (cell backward + data GEMM, gemm_bwd.hip) on random data against a double-precision host
+    computation of the same step: every path of the kernel's software pipeline (1, 2, 3 and more unit groups per K share,
+    partial row blocks and column tiles, split-K atomics at the train step's full size)."""
+    import os, re, shutil, subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'bwd_step_check')
+    subprocess.check_call([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-I', os.path.join(root, 'include'),
+                           os.path.join(root, 'tests', 'native', 'bwd_step_check.hip'),
+                           os.path.join(root, 'cor_asv_ann_amd', 'csrc', 'gemm_bwd.hip'), '-o', exe])
+    for rows, width, n in [(4, 32, 32), (4, 32, 96), (40, 64, 64), (33, 96, 96), (7, 160, 160), (100, 256, 256),
+                           (512, 512, 512), (512, 512, 1024)]:
+        out = subprocess.run([exe, str(rows), str(width), str(n)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        m = re.search(r'dz err (\S+)\s+dc err (\S+)\s+out err (\S+) \(scale (\S+)\)', out.stdout)
+        assert m, out.stdout
+        dz, dc, err, scale = map(float, m.groups())
+        assert dz < 2e-6 and dc < 2e-6 and err < 2e-6 * max(scale, 1.0) * (4 * width) ** 0.5, out.stdout

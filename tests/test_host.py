@@ -257,3 +257,17 @@ def test_batch_prefetch_runs_ahead_keeps_order_and_hands_errors_over():
     gen.close()
     time.sleep(0.3)
     assert not any(t.name == 'casv-batch-prefetch' and t.is_alive() for t in threading.enumerate())
+
+
+def test_no_kernel_reads_a_register_whose_hidden_load_is_in_flight():
+    """The GEMM kernels hide their tile loads from the compiler's wait bookkeeping (asm loads + counted s_waitcnt); a register
+    copy the compiler inserts between such a load and its wait would move stale data.  csrc/check_asm_loads.py compiles the
+    kernels to ISA and walks every path."""
+    import os, subprocess, sys
+    import pytest
+    if not os.path.exists('/opt/rocm/bin/hipcc'):
+        pytest.skip('no hipcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'cor_asv_ann_amd', 'csrc', 'check_asm_loads.py')],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
