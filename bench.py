@@ -432,9 +432,40 @@ def decode_bench(args):
             if backend == 'nccl':
                 torch.cuda.synchronize()
 
+    # One GPU: the steps are independent of each other, and they run the way `Sequence2Sequence.predict()` runs its batches --
+    # through `correct_batches`, where batch k + 1 is vectorised while batch k is on the device and the strings of batch k - 1
+    # are built (--pipeline 0: one `correct_lines` call after the other).  All K steps lie inside the timed region either way.
+    pipelined = bool(args.pipeline) and eng is not None and not dist_on and not dry
+
+    def run_steps(n):
+        if not pipelined:
+            last = None
+            for _ in range(n):
+                last = step()
+            return last
+        confmat = bool(wl.get('confmat'))
+        fast = False if confmat else wl['fast']
+
+        def batches():
+            for _ in range(n):
+                for chunk in chunks:
+                    yield (chunk, chunk) if confmat else chunk
+        out_lines, last = [], None
+        for k, (o, p, sc, al) in enumerate(s2s.correct_batches(batches(), fast=fast, greedy=fast, alignments=want_align)):
+            if confmat and want_align:
+                from cor_asv_ann_amd.realign import alignment2path
+                t1 = time.perf_counter()
+                for line, text, a in zip(chunks[k % len(chunks)], o, al):
+                    if len(a):
+                        alignment2path(a, sum(max((len(x[0]) for x in c), default=0) for c in line), len(text), 1. / V)
+                t_realign[0] += time.perf_counter() - t1
+            out_lines += o
+            if (k + 1) % len(chunks) == 0:
+                last, out_lines = out_lines, []
+        return last
+
     dom = 'lstm_gemm' if args.workload != 'c2' else 'persist'
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     if eng:
         # HIP events around launches of the dominant kernel, on the library's stream: around every 13th of them (level 3) --
         # an event pair keeps the next launch from overlapping the kernel's tail, which costs ~8 us per pair: around every
@@ -444,8 +475,7 @@ def decode_bench(args):
     t_realign[0] = 0.0
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
+    last = run_steps(args.steps)
     sync_dev()
     mine = time.perf_counter() - t0                       # this rank's own time, before it waits for the others
     sync()
@@ -455,7 +485,7 @@ def decode_bench(args):
     if eng:
         prof = eng.profile_read(dom)
         eng.profile(1)                 # one extra, untimed step with events around every kernel class
-        step()
+        run_steps(1)
         sync()
         others = {k: eng.profile_read(k) for k in ('lstm_gemm', 'lstm_gemm_small', 'gemm', 'attention', 'softmax', 'beam', 'embed', 'persist')}
         eng.profile(False)
@@ -491,6 +521,8 @@ def decode_bench(args):
                        'gather': 'casv_comm (RCCL, C ABI)' if comm else ('torch.distributed/' + backend if dist_on else 'none'),
                        'records': (records + '-packed') if dist_on else 'none',
                        'graph': bool(args.graph), 'alignments': want_align,
+                       'steps_run': 'through correct_batches, as predict() does: host work of neighbouring steps overlaps the device'
+                                    if pipelined else 'one correct_lines call after the other',
                        'launcher': 'bench.py' if os.environ.get('CASV_BENCH_CHILD') else
                                    ('torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ else 'direct')},
             'ms_per_step_by_rank': [1e3 * x / args.steps for x in per_rank_s],
@@ -611,6 +643,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-others', action='store_true', help='do not time c2 / c4 / page after the default c3 run')
+    ap.add_argument('--pipeline', type=int, default=1, help='1 GPU: 1 = the steps run through correct_batches (vectorising, device and '
+                    'string building of neighbouring steps overlap, as in predict()), 0 = one correct_lines call after the other')
     ap.add_argument('--graph', type=int, default=0, help='replay the decode step from a hipGraph')
     ap.add_argument('--workload', default=None, choices=['c2', 'c3', 'c4', 'c5', 'page'],
                     help='c3 = beamed decode (the BASELINE metric; default on one GPU); c5 = 8192 lines per GPU per step '

@@ -386,9 +386,9 @@ static int count_ktiles(const GemmArgs& g) {
 
 // Tile shape and split-K factor of a launch.  Launches that would occupy at most half the CUs as 128x128 tiles (even
 // after split-K) run as 32x128 tiles: 4x the workgroups, same values ...
-struct GemmPlan { int blocks, sblocks, ksplit; bool skinny; };
+struct GemmPlan { int blocks, sblocks, ksplit; bool skinny; int srows; };
 static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
-    GemmPlan p{0, 0, 1, false};
+    GemmPlan p{0, 0, 1, false, 32};
     for (int j = 0; j < b.count; ++j) {
         const int nbn = (b.g[j].N + BN - 1) / BN;
         const int nb = ((b.g[j].M + BM - 1) / BM) * nbn, ns = ((b.g[j].M + 31) / 32) * nbn;
@@ -427,6 +427,15 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
         p.skinny = true;
         p.ksplit = choose_ksplit(p.sblocks * b.count, 512);
     }
+    // 64 x 128 tiles (gemm_skinny.hip, two row blocks per workgroup) for launches without split-K that leave at most one 128x128
+    // workgroup per CU, or go as 32-row tiles, while 64-row tiles still put two on every CU: the encoder at 1024 lines -- layer 1's
+    // two directions (256 tiles of 128x128) and the anti-diagonals of the layers above (384)
+    if (!splittable && p.ksplit == 1) {
+        int blocks64 = 0;
+        for (int j = 0; j < b.count; ++j) blocks64 = std::max(blocks64, ((b.g[j].M + 63) / 64) * ((b.g[j].N + BN - 1) / BN));
+        const bool fits = blocks64 * b.count >= 2 * ncu;
+        if (g_tile_mode == 2 || (g_tile_mode < 0 && fits && (p.skinny || grid < 2 * ncu))) { p.skinny = true; p.srows = 64; }
+    }
     return p;
 }
 bool gemm_is_skinny(int epi, const GemmBatch& b) { return plan_gemm(epi, b).skinny; }
@@ -460,7 +469,7 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
         if (g.out.ld == g.N) (void)hipMemsetAsync(cbase, 0, (size_t)g.M * g.N * sizeof(float), stream);
         else (void)hipMemset2DAsync(cbase, (size_t)g.out.ld * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream);
     }
-    if (skinny) { launch_gemm_skinny(epi, bb, ksplit, stream); return; }
+    if (skinny) { launch_gemm_skinny(epi, bb, ksplit, plan.srows, stream); return; }
     // wave-group split-K (train step only, GemmArgs.kgroups): worth it while the grid leaves CUs idle
     bool two = true;
     for (int j = 0; j < b.count; ++j)

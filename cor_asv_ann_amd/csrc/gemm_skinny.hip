@@ -21,13 +21,17 @@ namespace casv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SBM = 32, SBN = 128;
+constexpr int SBN = 128;
 constexpr int SK2 = 32, SLD = SK2 + 4;                       // k per LDS stage, padded row stride (floats)
-constexpr int STAGE_FLOATS = (SBM + SBN) * SLD;              // A rows, then B rows      // prefetch depth 4 = 6 = 8 K-tiles (measured; in round 2 again: 8 gains 2 % on the train step, nothing on decode)
 
-template <int EPI>
+// RB = row blocks of 32 per workgroup: 32 x 128 tiles, or 64 x 128 (round 3: every wave carries two accumulators on one B
+// fragment -- half the B traffic and LDS reads per FLOP; for launches whose 128x128 grid leaves one workgroup per CU or less
+// while 64-row tiles still give every CU two: the encoder at 1024 lines).  Same k order and MFMA sequence per element.
+template <int EPI, int RB>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch batch) {
-    __shared__ __attribute__((aligned(16))) float s_stage[2 * STAGE_FLOATS];      // 46 KB; the epilogue's gate exchange reuses it
+    constexpr int SBM = 32 * RB;
+    constexpr int STAGE_FLOATS = (SBM + SBN) * SLD;          // A rows, then B rows
+    __shared__ __attribute__((aligned(16))) float s_stage[2 * STAGE_FLOATS];      // 46 / 55 KB; the epilogue's gate exchange reuses it
     float (*s_gate)[16][64] = reinterpret_cast<float (*)[16][64]>(s_stage);
     const GemmArgs& g = batch.g[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,9 +51,11 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
 
     // staging role of this thread: A row tid >> 3 (of 32), B rows (tid >> 3) + 32 i, 16 bytes at k = 4 * (tid & 7) of every stage
     const int srow = tid >> 3, sk = 4 * (tid & 7);
+    // (segment pointers of A row srow of row block 0; row block r adds its own row's offset: drow[r][segment])
     const float* ap0; const float* ap1; const float* ap2;
     int tiles0 = 0, tiles1 = 0, tiles2 = 0;                      // in stages of 32 k
     int mrow = m0 + srow; mrow = mrow < g.M ? mrow : g.M - 1;
+    long long drow[RB][3];
 #define CASV_SETUP_SEG(S, AP, TILES)                                                             \
     if (g.nseg > S && !(g.a[S].skip_first && step == 0 && !g.a[S].first_base)) {                 \
         const Seg& sg = g.a[S];                                                                  \
@@ -59,8 +65,14 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         const int rid = (sg.rows && !first) ? sg.rows[mrow] : mrow;                              \
         AP = base + (long long)rid * sg.ld + sk;                                                 \
         TILES = sg.width / SK2;                                                                  \
+        _Pragma("unroll") for (int r = 0; r < RB; ++r) {                                         \
+            int mr = m0 + srow + 32 * r; mr = mr < g.M ? mr : g.M - 1;                           \
+            const int rr = (sg.rows && !first) ? sg.rows[mr] : mr;                               \
+            drow[r][S] = (long long)(rr - rid) * sg.ld * 4;                                      \
+        }                                                                                        \
     } else {                                                                                     \
         AP = nullptr;                                                                            \
+        _Pragma("unroll") for (int r = 0; r < RB; ++r) drow[r][S] = 0;                           \
     }
     CASV_SETUP_SEG(0, ap0, tiles0)
     CASV_SETUP_SEG(1, ap1, tiles1)
@@ -82,19 +94,22 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         bp[i] = g.Bt + (long long)ncol * g.Ktot + sk;
     }
 
-    struct GStage { f32x4 a, b[4]; };
+    struct GStage { f32x4 a[RB], b[4]; };
     auto load_stage = [&](GStage& gs, int kt_rel) {
         const int kt = kt_rel + kt_begin;
         const long long m1 = (kt >= c0 && kt < c1) ? -1LL : 0LL, m2 = (kt >= c1) ? -1LL : 0LL;
         const int ko = kt - ((int)m1 & c0) - ((int)m2 & c1);
         const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * SK2;
         const char* pa = (const char*)ap0 + (d1 & m1) + (d2 & m2) + (long long)ko * (SK2 * 4);
-        gs.a = *reinterpret_cast<const f32x4*>(pa);
+        gs.a[0] = *reinterpret_cast<const f32x4*>(pa);
+#pragma unroll
+        for (int r = 1; r < RB; ++r)
+            gs.a[r] = *reinterpret_cast<const f32x4*>(pa + ((drow[r][0] & ~(m1 | m2)) | (drow[r][1] & m1) | (drow[r][2] & m2)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs.b[i] = *reinterpret_cast<const f32x4*>(bp[i] + kb);
     };
-    // The same loads hidden from the compiler's wait bookkeeping (steady state): two register sets alternate, a stage's five
-    // loads have TWO stage times to arrive, and the wait in front of its LDS store is a counted vmcnt(5) that leaves the next
+    // The same loads hidden from the compiler's wait bookkeeping (steady state): two register sets alternate, a stage's 4 + RB
+    // loads have TWO stage times to arrive, and the wait in front of its LDS store is a counted vmcnt(4 + RB) that leaves the next
     // stage's loads in flight (hipcc's own wait there is a vmcnt(0): round 2's loop kept one stage in registers and paid what
     // was left of the L2 latency after one stage of 16 MFMAs -- 1024 cycles -- in every iteration).
     auto load_stage_asm = [&](GStage& gs, int kt_rel) {
@@ -103,7 +118,12 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         const int ko = kt - ((int)m1 & c0) - ((int)m2 & c1);
         const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * SK2;
         const char* pa = (const char*)ap0 + (d1 & m1) + (d2 & m2) + (long long)ko * (SK2 * 4);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gs.a) : "v"(pa));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gs.a[0]) : "v"(pa));
+#pragma unroll
+        for (int r = 1; r < RB; ++r) {
+            const char* par = pa + ((drow[r][0] & ~(m1 | m2)) | (drow[r][1] & m1) | (drow[r][2] & m2));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gs.a[r]) : "v"(par));
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float* pb = bp[i] + kb;
@@ -112,32 +132,38 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
     };
     auto store_stage = [&](const GStage& gs, int buf) {
         float* sa = s_stage + buf * STAGE_FLOATS + srow * SLD + sk;
-        *reinterpret_cast<f32x4*>(sa) = gs.a;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) *reinterpret_cast<f32x4*>(sa + 32 * r * SLD) = gs.a[r];
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(sa + (SBM + 32 * i) * SLD) = gs.b[i];
     };
-    f32x16 acc;
+    f32x16 acc[RB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.0f;
     // fragments of one stage: two 16-k halves, in each lane half lh contracts k = 4 lh + 8 j + i in instruction (j, i) --
     // the k order of gemm.hip
     const int a_off = l31 * SLD + 4 * lh, b_off = (SBM + wave * 32 + l31) * SLD + 4 * lh;
     auto compute = [&](int buf) {
         const float* base = s_stage + buf * STAGE_FLOATS;
-        f32x4 fa[4], fb[4];
+        f32x4 fa[RB][4], fb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            fa[q] = *reinterpret_cast<const f32x4*>(base + a_off + 8 * q);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) fa[r][q] = *reinterpret_cast<const f32x4*>(base + a_off + 32 * r * SLD + 8 * q);
             fb[q] = *reinterpret_cast<const f32x4*>(base + b_off + 8 * q);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][i], fb[q][i], acc, 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[r][q][i], fb[q][i], acc[r], 0, 0, 0);
     };
 
-    // LSTM: wave w finishes rows (r & 3, r >> 2 == w) of the tile; fetch their previous cell state under the K loop
-    float cpv[4];
+    // LSTM: wave w finishes rows (r & 3, r >> 2 == w) of every row block; fetch their previous cell state under the K loop
+    float cpv[RB][4];
     if (EPI == EPI_LSTM && !g.epi_plain) {
         const bool cfirst = g.c_in.first_base && step == 0;
         const bool czero = g.c_in.skip_first && step == 0 && !cfirst;
@@ -145,29 +171,33 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
             : g.c_in.base + (long long)(step * g.c_in.step_mul + g.c_in.step_add) * g.c_in.slot_stride;
         const int u = bn * 32 + l31;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int m = m0 + q + 8 * wave + 4 * lh;
-            m = m < g.M ? m : g.M - 1;
-            cpv[q] = 0.0f;
-            if (!czero) {
-                const int rid = (g.c_in.rows && !cfirst) ? g.c_in.rows[m] : m;
-                cpv[q] = cin[(long long)rid * g.c_in.ld + u];
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int m = m0 + 32 * r + q + 8 * wave + 4 * lh;
+                m = m < g.M ? m : g.M - 1;
+                cpv[r][q] = 0.0f;
+                if (!czero) {
+                    const int rid = (g.c_in.rows && !cfirst) ? g.c_in.rows[m] : m;
+                    cpv[r][q] = cin[(long long)rid * g.c_in.ld + u];
+                }
             }
-        }
     }
 
     // ... and (train step) the precomputed input pre-activations x.K + b of its (row, unit) elements: requested here, under the
     // K loop, instead of as a dependent round trip between the K loop and the cell
-    float zpre[4][4];
+    float zpre[RB][4][4];
     const bool has_zin = EPI == EPI_LSTM && !g.epi_plain && g.zinit.base != nullptr;
     if (has_zin) {
         const float* zin0 = g.zinit.base + (long long)(step * g.zinit.step_mul + g.zinit.step_add) * g.zinit.slot_stride;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m0 + q + 8 * wave + 4 * lh;
-            const float* zr = zin0 + (long long)(m < g.M ? m : g.M - 1) * g.zinit.ld + n0 + l31;
-            zpre[q][0] = zr[0]; zpre[q][1] = zr[32]; zpre[q][2] = zr[64]; zpre[q][3] = zr[96];
-        }
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + 32 * r + q + 8 * wave + 4 * lh;
+                const float* zr = zin0 + (long long)(m < g.M ? m : g.M - 1) * g.zinit.ld + n0 + l31;
+                zpre[r][q][0] = zr[0]; zpre[r][q][1] = zr[32]; zpre[r][q][2] = zr[64]; zpre[r][q][3] = zr[96];
+            }
     }
 
     if (ntiles > 0) {
@@ -177,9 +207,13 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         load_stage(g0, 0);
         store_stage(g0, 0);
         int kt = 0;
+        // (the waits name every register of the stage: its loads must have landed before the LDS store reads them)
+#define CASV_SK_WAIT(CNT, G)                                                                                       \
+        if constexpr (RB == 1) asm volatile("s_waitcnt vmcnt(" CNT ")" : "+v"(G.a[0]), "+v"(G.b[0]), "+v"(G.b[1]), "+v"(G.b[2]), "+v"(G.b[3])); \
+        else asm volatile("s_waitcnt vmcnt(" CNT ")" : "+v"(G.a[0]), "+v"(G.a[RB - 1]), "+v"(G.b[0]), "+v"(G.b[1]), "+v"(G.b[2]), "+v"(G.b[3]));
 #define CASV_SK_FULL(G, J)                                                                                         \
         {                                                                                                          \
-            asm volatile("s_waitcnt vmcnt(5)" : "+v"(G.a), "+v"(G.b[0]), "+v"(G.b[1]), "+v"(G.b[2]), "+v"(G.b[3]));  \
+            if constexpr (RB == 1) { CASV_SK_WAIT("5", G) } else { CASV_SK_WAIT("6", G) }                          \
             store_stage(G, ((J) + 1) & 1);                                                                         \
             load_stage_asm(G, (J) + 3);                                                                            \
             compute((J) & 1);                                                                                      \
@@ -200,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
                 CASV_SK_FULL(g1, kt)
                 CASV_SK_FULL(g0, kt + 1)
             }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0.a), "+v"(g0.b[0]), "+v"(g0.b[1]), "+v"(g0.b[2]), "+v"(g0.b[3]),
-                                                "+v"(g1.a), "+v"(g1.b[0]), "+v"(g1.b[1]), "+v"(g1.b[2]), "+v"(g1.b[3]));
+            CASV_SK_WAIT("0", g0)
+            CASV_SK_WAIT("0", g1)
         } else {
             if (ntiles > 1) load_stage(g1, 1);
             if (ntiles > 2) load_stage(g0, 2);
@@ -214,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         if (kt < ntiles) CASV_SK_STEP(g1, kt)
 #undef CASV_SK_STEP
 #undef CASV_SK_FULL
+#undef CASV_SK_WAIT
     }
 
     // ---- epilogue ----
@@ -223,20 +258,18 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         if (n < g.N) {
             const float b = g.bias ? g.bias[n] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < g.M) {
-                    float* dst = cbase + (long long)m * g.out.ld + n;
-                    if (nsplit > 1) atomicAdd(dst, acc[r] + (blockIdx.z == 0 ? b : 0.0f));
-                    else *dst = g.accumulate ? (*dst + acc[r] + b) : (acc[r] + b);
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < g.M) {
+                        float* dst = cbase + (long long)m * g.out.ld + n;
+                        if (nsplit > 1) atomicAdd(dst, acc[rb][r] + (blockIdx.z == 0 ? b : 0.0f));
+                        else *dst = g.accumulate ? (*dst + acc[rb][r] + b) : (acc[rb][r] + b);
+                    }
                 }
-            }
         }
     } else {
-        // gate w of every (row, unit) of the tile -> LDS; then wave w takes accumulator rows r = 4w .. 4w+3 of all four gates
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s_gate[wave][r][lane] = acc[r];      // (every wave is past the K loop's last barrier)
-        __syncthreads();
         const int u = bn * 32 + l31;
         const float bi = g.bias ? g.bias[n0 + l31] : 0.f, bf_ = g.bias ? g.bias[n0 + 32 + l31] : 0.f;
         const float bg = g.bias ? g.bias[n0 + 64 + l31] : 0.f, bo = g.bias ? g.bias[n0 + 96 + l31] : 0.f;
@@ -245,39 +278,54 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         float* gout = g.gates_out.base
             ? g.gates_out.base + (long long)(step * g.gates_out.step_mul + g.gates_out.step_add) * g.gates_out.slot_stride
             : nullptr;
-        float z[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int rb = 0; rb < RB; ++rb) {
+            // gate w of every (row, unit) of the row block -> LDS; then wave w takes accumulator rows r = 4w .. 4w+3 of all four gates
+            if (rb) __syncthreads();                                          // (the exchange buffer is read out)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) z[q][c] = s_gate[c][4 * wave + q][lane];
-        if (has_zin) {
+            for (int r = 0; r < 16; ++r) s_gate[wave][r][lane] = acc[rb][r];  // (every wave is past the K loop's last barrier)
+            __syncthreads();
+            float z[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { z[q][0] += zpre[q][0]; z[q][1] += zpre[q][1]; z[q][2] += zpre[q][2]; z[q][3] += zpre[q][3]; }
-        }
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m0 + q + 8 * wave + 4 * lh;
-            if (m < g.M) {
-                const LstmCellOut cell = lstm_cell(z[q][0] + bi, z[q][1] + bf_, z[q][2] + bg, z[q][3] + bo, cpv[q]);
-                cout[(long long)m * g.c_out.ld + u] = cell.c;
-                hout[(long long)m * g.out.ld + u] = cell.h;
-                if (gout) {
-                    float* gr = gout + (long long)m * g.gates_out.ld + n0 + l31;
-                    gr[0] = cell.i; gr[32] = cell.f; gr[64] = cell.g; gr[96] = cell.o;
+                for (int c = 0; c < 4; ++c) z[q][c] = s_gate[c][4 * wave + q][lane];
+            if (has_zin) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { z[q][0] += zpre[rb][q][0]; z[q][1] += zpre[rb][q][1]; z[q][2] += zpre[rb][q][2]; z[q][3] += zpre[rb][q][3]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + 32 * rb + q + 8 * wave + 4 * lh;
+                if (m < g.M) {
+                    const LstmCellOut cell = lstm_cell(z[q][0] + bi, z[q][1] + bf_, z[q][2] + bg, z[q][3] + bo, cpv[rb][q]);
+                    cout[(long long)m * g.c_out.ld + u] = cell.c;
+                    hout[(long long)m * g.out.ld + u] = cell.h;
+                    if (gout) {
+                        float* gr = gout + (long long)m * g.gates_out.ld + n0 + l31;
+                        gr[0] = cell.i; gr[32] = cell.f; gr[64] = cell.g; gr[96] = cell.o;
+                    }
                 }
             }
         }
     }
 }
 
-void launch_gemm_skinny(int epi, const GemmBatch& b, int ksplit, hipStream_t stream) {
+// rows = 32 or 64 per tile (gemm.hip's plan)
+void launch_gemm_skinny(int epi, const GemmBatch& b, int ksplit, int rows, hipStream_t stream) {
     int blocks = 0;
     for (int j = 0; j < b.count; ++j) {
-        const int nb = ((b.g[j].M + SBM - 1) / SBM) * ((b.g[j].N + SBN - 1) / SBN);
+        const int nb = ((b.g[j].M + rows - 1) / rows) * ((b.g[j].N + SBN - 1) / SBN);
         blocks = nb > blocks ? nb : blocks;
     }
-    if (epi == EPI_LSTM) hipLaunchKernelGGL((gemm_skinny_kernel<EPI_LSTM>), dim3(blocks, b.count, ksplit), dim3(256), 0, stream, b);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<EPI_PLAIN>), dim3(blocks, b.count, ksplit), dim3(256), 0, stream, b);
+    const dim3 grid(blocks, b.count, ksplit);
+    if (rows == 64) {
+        if (epi == EPI_LSTM) hipLaunchKernelGGL((gemm_skinny_kernel<EPI_LSTM, 2>), grid, dim3(256), 0, stream, b);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<EPI_PLAIN, 2>), grid, dim3(256), 0, stream, b);
+    } else {
+        if (epi == EPI_LSTM) hipLaunchKernelGGL((gemm_skinny_kernel<EPI_LSTM, 1>), grid, dim3(256), 0, stream, b);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<EPI_PLAIN, 1>), grid, dim3(256), 0, stream, b);
+    }
 }
 
 }  // namespace casv

@@ -364,7 +364,7 @@ def test_model_loaded_from_the_reference_container(golden_dir, tmp_path):
 
 
 def test_tile_shape_does_not_change_results():
-    """GEMM launches run as 32x128 or 128x128 tiles (the launcher picks by size): both contract k in the same order
+    """GEMM launches run as 32x128, 64x128 or 128x128 tiles (the launcher picks by size): all contract k in the same order
     with the same instruction sequence per element, so the choice -- which depends on the batch size -- must not
     change a single bit (the batch-independence of a row's result rests on it)."""
     cfg = ModelConfig(depth=2, width=96, voc_size=70)
@@ -373,7 +373,7 @@ def test_tile_shape_does_not_change_results():
     eng = _engine(cfg, weights)
     outs = []
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             eng.set_option('tile', mode)
             eng.encode(idx)
             enc, states = eng.encoder_outputs()

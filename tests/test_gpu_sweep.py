@@ -14,9 +14,9 @@ from oracle import ModelConfig, make_weights, make_lines
 from oracle.decode import OracleModel, correct_lines
 
 
-@pytest.mark.parametrize('seed,ncase,tile', [(1, 40, -1), (7, 40, 0)])
+@pytest.mark.parametrize('seed,ncase,tile', [(1, 40, -1), (7, 40, 0), (11, 30, 2)])
 def test_random_beam_configurations(seed, ncase, tile):
-    """tile: -1 = the launcher's choice (32x128 tiles at these sizes), 0 = 128x128 tiles forced, so that both GEMM
+    """tile: -1 = the launcher's choice (32x128 tiles at these sizes), 0 = 128x128 tiles forced, 2 = 64x128, so that every GEMM
     kernels see the odd shapes of the sweep."""
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
     rng = np.random.default_rng(seed)
