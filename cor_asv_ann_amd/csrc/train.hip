@@ -41,7 +41,8 @@ struct TrainState {
     std::vector<DevBuf> O, DO;             // masked layer outputs (encoder O[n], decoder DO[n])
     DevBuf loss, normsq;
     DevBuf dcalt;                          // second dL/dc buffers of the fused backward steps (two layers)
-    DevBuf rec_cnt; int rec_launches = 0, rec_skip = 0, rec_penalty = 0;   // persistent recurrences: counters per launch, back-off
+    DevBuf rec_cnt; int rec_launches = 0, rec_checked = 0, rec_skip = 0, rec_penalty = 0;   // persistent recurrences: counters per launch, back-off
+    const unsigned* rec_abort[16] = {nullptr};    // ... and where each launch leaves its "gave up" word
     int find(const std::string& n) const { for (size_t i = 0; i < tens.size(); ++i) if (tens[i].name == n) return (int)i; return -1; }
     float* W_(int i) { return tens[i].w.as<float>(); }
     float* G_(int i) { return tens[i].g.as<float>(); }
@@ -324,7 +325,33 @@ static int layers_backward(casv_model* m, const LayerBwd* a, int count) {
         else HIPCHK(hipMemsetAsync(a[j].dc, 0, (size_t)B * W * 4, m->stream));
         maxlen = std::max(maxlen, a[j].l->len);
     }
-    if (m->fused_backward) {
+    bool persistent = false;
+    if (m->persist_mode != 0 && ts->rec_skip == 0 && ts->rec_launches < 16 && m->ncu >= 64) {
+        RecBwdArgs ra{};
+        ra.njobs = count; ra.B = B; ra.W = W;
+        bool plain = true;
+        for (int j = 0; j < count; ++j) {
+            TLayer& l = *a[j].l;
+            plain = plain && l.kr == W;
+            ra.job[j] = RecBwdJob{l.wrT.as<float>(), a[j].dOut, a[j].ld_out, a[j].mask, a[j].dh_fin, a[j].dc_fin, l.Gt.as<float>(), l.Cs.as<float>(), a[j].c0,
+                                  l.Z.as<float>(), l.dRec.as<float>(), a[j].dc, l.len, l.reverse ? 1 : 0};
+        }
+        const size_t cb = train_recurrence_bwd_counter_bytes(B);
+        ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
+        const int grid = plain ? train_recurrence_bwd_grid(ra, m->ncu) : 0;
+        if (grid) {
+            hipEvent_t ev{};
+            double flops = 0;
+            for (int j = 0; j < count; ++j) flops += 2.0 * B * 4.0 * W * W * a[j].l->len;
+            m->prof_begin(PC_PERSIST, flops, 0.0, ev);
+            launch_train_recurrence_bwd(ra, grid, m->stream);
+            m->prof_end(PC_PERSIST, ev);
+            ts->rec_abort[ts->rec_launches++] = ra.counters + (cb / sizeof(unsigned) - 32);
+            persistent = true;
+        }
+    }
+    if (persistent) {
+    } else if (m->fused_backward) {
         // one launch per step for both layers: the cells' backward inside the data GEMM (gemm_bwd.hip); dL/dc ping-pongs
         float* dcb[2][2];
         int done[2] = {0, 0};
@@ -384,7 +411,7 @@ static int layers_forward(casv_model* m, const LayerFwd* a, int count) {
             ra.job[j] = RecJob{ts->W_(l.iwr), l.Z.as<float>(), l.hs, l.hs_ld, l.Cs.as<float>(), l.Gt.as<float>(), a[j].h0, a[j].c0, l.len,
                                l.reverse ? 1 : 0};
         }
-        const size_t cb = train_recurrence_counter_bytes(B);
+        const size_t cb = train_recurrence_bwd_counter_bytes(B);        // (one slot size for both kinds of launch)
         ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
         if (const int grid = train_recurrence_grid(ra, m->ncu)) {
             hipEvent_t ev{};
@@ -393,7 +420,7 @@ static int layers_forward(casv_model* m, const LayerFwd* a, int count) {
             m->prof_begin(PC_PERSIST, flops, 0.0, ev);
             launch_train_recurrence(ra, grid, m->stream);
             m->prof_end(PC_PERSIST, ev);
-            ++ts->rec_launches;
+            ts->rec_abort[ts->rec_launches++] = ra.counters + (train_recurrence_counter_bytes(B) / sizeof(unsigned) - 32);
             return 0;
         }
     }
@@ -444,7 +471,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         else if (l.name == "enc1_bw") { l.hs = ts->H1.as<float>() + W; l.hs_ld = 2 * W; }
         else { ENS(l.Hown, rows * W * 4) l.hs = l.Hown.as<float>(); l.hs_ld = W; }
     }
-    ENS(ts->rec_cnt, 16 * train_recurrence_counter_bytes(B)) ENS(ts->dcalt, (size_t)2 * B * W * 4)
+    ENS(ts->rec_cnt, 16 * train_recurrence_bwd_counter_bytes(B)) ENS(ts->dcalt, (size_t)2 * B * W * 4)
     for (int n = 1; n <= D; ++n) ENS(ts->O[n], TB * (n == 1 ? 2 * W : W) * 4)
     for (int n = 1; n < D; ++n) ENS(ts->DO[n], UB * W * 4)
 #undef ENS
@@ -466,8 +493,8 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     const float inv_count = 1.0f / (float)std::max(cnt, 1L);
     HIPCHK(hipMemsetAsync(ts->loss.p, 0, 16, st));
     HIPCHK(hipMemsetAsync(ts->normsq.p, 0, 16, st));
-    HIPCHK(hipMemsetAsync(ts->rec_cnt.p, 0, 16 * train_recurrence_counter_bytes(B), st));
-    ts->rec_launches = 0;
+    HIPCHK(hipMemsetAsync(ts->rec_cnt.p, 0, 16 * train_recurrence_bwd_counter_bytes(B), st));
+    ts->rec_launches = ts->rec_checked = 0;
     if (ts->rec_skip > 0) --ts->rec_skip;
     if (training) for (auto& t : ts->tens) HIPCHK(hipMemsetAsync(t.g.p, 0, t.n * 4, st));
 
@@ -537,25 +564,30 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     { GemmArgs g = plain_gemm(top.hs, W, (int)UB, W, ts->W_(ts->iE), V, nullptr, ts->logits.as<float>(), Vp); run_gemm(m, EPI_PLAIN, g); }
     launch_softmax_ce(ts->logits.as<float>(), ts->d_out.as<int>(), ts->d_w.as<float>(), B, U, V, Vp, inv_count, ts->loss.as<double>(),
                       training ? 1 : 0, st);
-    if (ts->rec_launches) {
-        // Did every persistent recurrence run to its end?  (A launch gives up when its workgroups wait too long for each other --
-        // a GPU shared with another process: handoff.h.)  Nothing has been updated yet: start over with per-step launches, and
-        // keep to them for the next 16, 32, ... steps.
+    // Did every persistent recurrence so far run to its end?  (A launch gives up when its workgroups wait too long for each
+    // other -- a GPU shared with another process: handoff.h.)  Nothing has been updated yet: start over with per-step launches,
+    // and keep to them for the next 16, 32, ... steps.  Asked after the forward pass and again in front of the update.
+    auto recurrences_gave_up = [&](bool& any) -> int {
+        any = false;
+        if (ts->rec_launches == ts->rec_checked) return 0;
         unsigned gave_up[16] = {0};
-        const size_t cb = train_recurrence_counter_bytes(B);
-        for (int i = 0; i < ts->rec_launches; ++i)
-            HIPCHK(hipMemcpyAsync(&gave_up[i], static_cast<char*>(ts->rec_cnt.p) + cb * (i + 1) - 32 * sizeof(unsigned), 4, hipMemcpyDeviceToHost, st));
+        for (int i = ts->rec_checked; i < ts->rec_launches; ++i)
+            HIPCHK(hipMemcpyAsync(&gave_up[i], ts->rec_abort[i], 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        bool any = false;
-        for (int i = 0; i < ts->rec_launches; ++i) any |= gave_up[i] != 0;
+        for (int i = ts->rec_checked; i < ts->rec_launches; ++i) any |= gave_up[i] != 0;
+        ts->rec_checked = ts->rec_launches;
         if (any) {
             ts->rec_penalty = ts->rec_penalty ? std::min(2 * ts->rec_penalty, 1 << 20) : 16;
             ts->rec_skip = ts->rec_penalty + 1;
             fprintf(stderr, "cor_asv_ann_hip: a persistent recurrence of the train step gave up waiting (is the GPU shared?); "
                             "per-step launches for the next %d steps\n", ts->rec_penalty);
-            return casv_train_step(m, mode, B, T, U, A, enc_idx, enc_val, dec_in, dec_out, weights, mask_enc, mask_dec, mask_cell, loss_out, norm_out);
         }
-        ts->rec_penalty = 0;
+        return 0;
+    };
+    {
+        bool any = false;
+        if (int rc = recurrences_gave_up(any)) return rc;
+        if (any) return casv_train_step(m, mode, B, T, U, A, enc_idx, enc_val, dec_in, dec_out, weights, mask_enc, mask_dec, mask_cell, loss_out, norm_out);
     }
     if (!training) {                       // K.in_train_phase: the regulariser counts only in the train phase
         HIPCHK(hipMemcpyAsync(loss_out, ts->loss.p, 8, hipMemcpyDeviceToHost, st));
@@ -682,6 +714,12 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     }
     launch_embed_scatter(ts->G_(ts->iE), ts->e_idx.as<int>(), enc_val ? ts->e_val.as<float>() : nullptr, ts->dX0.as<float>(), W, B, T, A, V, W, st);
 
+    {
+        bool any = false;
+        if (int rc = recurrences_gave_up(any)) return rc;
+        if (any) return casv_train_step(m, mode, B, T, U, A, enc_idx, enc_val, dec_in, dec_out, weights, mask_enc, mask_dec, mask_cell, loss_out, norm_out);
+        if (ts->rec_launches) ts->rec_penalty = 0;
+    }
     // ---- regulariser, clip, update ----
     launch_reg(ts->W_(ts->iE), ts->G_(ts->iE), V, W, ts->loss.as<double>(), 1, st);
     for (auto& t : ts->tens) if (!t.frozen) launch_sumsq(t.g.as<float>(), (long long)t.n, ts->normsq.as<double>(), st);

@@ -31,6 +31,22 @@ size_t train_recurrence_counter_bytes(int B);
 int train_recurrence_grid(const RecArgs& ra, int ncu);      // 0: no persistent form for this shape on this device
 void launch_train_recurrence(const RecArgs& ra, int grid, hipStream_t stream);
 
+// ... and the backward recurrence of up to two plain layers (train_persist_bwd.hip): cell backward + data GEMM of every step.
+struct RecBwdJob {
+    const float* WrT;                                         // [W][4W] recurrent weights, transposed (the data GEMM's operand)
+    const float* dOut; long long ld_out; const float* mask;   // [len][B][ld_out] gradient w.r.t. the outputs (x feature mask [W]) or nullptr
+    const float* dh_fin; const float* dc_fin;                 // [B][W] gradient w.r.t. the final state or nullptr
+    const float* Gt; const float* Cs; const float* c0;        // what the forward pass kept; initial cell state or nullptr
+    float* dZ;                                                // [len][B][4W] out: gate derivatives (over the forward pass's Z)
+    float* dRec;                                              // [len][B][W] out, zeroed: dL/dh of the step before (slot of the first = dL/dh0)
+    float* dc_out;                                            // [B][W] out: dL/dc0
+    int len, reverse;
+};
+struct RecBwdArgs { RecBwdJob job[2]; int njobs, B, W; unsigned* counters; };
+size_t train_recurrence_bwd_counter_bytes(int B);
+int train_recurrence_bwd_grid(const RecBwdArgs& ra, int ncu);
+void launch_train_recurrence_bwd(const RecBwdArgs& ra, int grid, hipStream_t stream);
+
 struct LstmBwdArgs {
     const float* a; long long lda; const float* mask_a;     // gradient from the layer above (x dropout mask)
     const float* b; long long ldb;                           // recurrent gradient

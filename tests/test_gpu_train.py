@@ -19,11 +19,14 @@ def _idx(a):
                                                      # widths that are no multiple of 32 (dead-unit padding, engine.py)
                                                      (1, 20, 24, 3, 7, 3.0, True), (2, 50, 40, 4, 9, 4.0, True),
                                                      # three / five unit groups per K share of the fused backward step
-                                                     (2, 96, 40, 5, 8, 4.0, True), (3, 160, 40, 3, 6, 4.0, False)])
+                                                     (2, 96, 40, 5, 8, 4.0, True), (3, 160, 40, 3, 6, 4.0, False),
+                                                     # whole column tiles of 128 units: the backward recurrences are persistent too
+                                                     (3, 128, 40, 37, 7, 4.0, True), (2, 256, 48, 5, 6, 4.0, False)])
 @pytest.mark.parametrize('path', ['fused', 'stepwise'])
 def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks, path):
-    """fused: the forward recurrences as one launch per pair of layers (train_persist.hip), the cell's backward inside the
-    backward steps' data GEMM (gemm_bwd.hip); stepwise: one launch per time step and per operation."""
+    """fused: the recurrences as one launch per pair of layers (train_persist.hip; backward: train_persist_bwd.hip at widths of
+    whole 128-unit column tiles, else the cell's backward inside each step's data GEMM, gemm_bwd.hip); stepwise: one launch per
+    time step and per operation."""
     from cor_asv_ann_amd.engine import HipEngine
     cfg = ModelConfig(depth=d, width=W, voc_size=V)
     w = make_weights(cfg, emb_scale=es)
