@@ -341,3 +341,71 @@ def test_fused_backward_step_against_the_host(tmp_path):
         assert m, out.stdout
         dz, dc, err, scale = map(float, m.groups())
         assert dz < 2e-6 and dc < 2e-6 and err < 2e-6 * max(scale, 1.0) * (4 * width) ** 0.5, out.stdout
+
+
+def test_persistent_recurrences_under_uneven_load():
+    """The hand-offs inside the persistent forward / backward recurrences must not depend on timing: train steps of random
+    shapes while a second model handle keeps the CUs busy with beamed decodes on another stream, each step evaluated with the
+    persistent launches and with one launch per time step, and twice.  Loss and gradient norm agree up to the order of float
+    atomic sums (at these sizes the whole-sequence input GEMMs of the forward pass split K three or four ways, so even two
+    identical evaluations may differ in the last bit of a row's loss; at configs[3]'s size they do not and
+    test_c4_full_size_step_equals_oracle compares the forward passes exactly) -- a stale or early read would show as garbage.
+    A persistent launch that cannot become resident beside the foreign kernels gives up and the step is redone stepwise: the
+    results must not show which of the two happened."""
+    import threading
+    import time
+    from cor_asv_ann_amd.engine import HipEngine
+    stop = []
+
+    def background():
+        cfg = ModelConfig(depth=2, width=256, voc_size=64)
+        e = HipEngine(2, 256, 64)
+        e.set_weights(make_weights(cfg, emb_scale=32.0))
+        _, bidx = make_lines(96, 30, 1, voc_size=64)
+        while not stop:
+            e.encode(bidx)
+            e.decode_beam(batch_size=8)
+        e.close()
+
+    th = threading.Thread(target=background)
+    th.start()
+    try:
+        rng = np.random.default_rng(11)
+        t0, cases = time.time(), 0
+        while time.time() - t0 < 10.0 or cases < 8:
+            d = int(rng.integers(2, 5)); W = int(rng.choice([128, 256, 512])); V = int(rng.choice([40, 96]))
+            B = int(rng.integers(1, 300)); L = int(rng.integers(3, 24))
+            cfg = ModelConfig(depth=d, width=W, voc_size=V)
+            w = make_weights(cfg, seed=int(rng.integers(1, 1 << 30)), emb_scale=float(rng.choice([3., 8.])))
+            _, sidx = make_lines(B, L, int(rng.integers(1, 1 << 30)), voc_size=V)
+            _, tidx = make_lines(B, L, int(rng.integers(1, 1 << 30)), voc_size=V)
+            U = L + 2
+            dec_in = np.full((B, U), -1, np.int32); dec_out = np.full((B, U), -1, np.int32)
+            dec_in[:, 1:L + 2] = tidx; dec_out[:, :L + 1] = tidx
+            wts = (dec_out >= 0).astype(np.float32)
+            eng = HipEngine(d, W, V)
+            eng.set_weights(w)
+            eng.train_begin()
+            # two different batches take turns, so that a value left over from the evaluation before is a wrong value
+            _, sidx2 = make_lines(B, L, int(rng.integers(1, 1 << 30)), voc_size=V)
+            seen = {}
+            for rep in range(2):
+                for p in (-1, 0):
+                    eng.set_option('persistent', p)
+                    for which, src in enumerate((sidx, sidx2)):
+                        loss, norm = eng.train_step(src, None, dec_in, dec_out, wts, None, mode=2)
+                        assert np.isfinite(loss) and np.isfinite(norm)
+                        if (p, which) in seen:
+                            assert abs(loss - seen[p, which][0]) < 1e-8 * abs(loss) and abs(norm - seen[p, which][1]) < 2e-5 * norm, \
+                                ('not reproducible', p, d, W, V, B, L)
+                        seen[p, which] = (loss, norm)
+            for which in (0, 1):
+                assert abs(seen[-1, which][0] - seen[0, which][0]) < 1e-8 * abs(seen[0, which][0]), ('persistent != stepwise (forward)', d, W, V, B, L)
+                assert abs(seen[-1, which][1] - seen[0, which][1]) < 2e-5 * seen[0, which][1], ('persistent != stepwise (gradients)', d, W, V, B, L)
+            assert seen[0, 0][0] != seen[0, 1][0]
+            eng.train_end()
+            eng.close()
+            cases += 1
+    finally:
+        stop.append(1)
+        th.join()
