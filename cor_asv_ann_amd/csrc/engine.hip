@@ -1179,7 +1179,9 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
     if (!m || !key) return fail(CASV_ERR_ARG, "null argument");
     if (!strcmp(key, "graph")) { m->use_graph = value != 0; return CASV_OK; }
     if (!strcmp(key, "persistent")) {
-        if (value < -1 || value > 1) return fail(CASV_ERR_ARG, "persistent must be -1 (by batch size), 0 (per-step kernels) or 1 (always)");
+        // (2: as -1, and in the train step's first persistent recurrence one workgroup leaves without handing on: its peers give up
+        // after their bounded wait and the step falls back to per-step launches -- a test of that path)
+        if (value < -1 || value > 2) return fail(CASV_ERR_ARG, "persistent must be -1 (by batch size), 0 (per-step kernels) or 1 (always)");
         m->persist_mode = (int)value; return CASV_OK;
     }
     if (!strcmp(key, "eos")) {

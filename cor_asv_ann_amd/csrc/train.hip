@@ -413,6 +413,7 @@ static int layers_forward(casv_model* m, const LayerFwd* a, int count) {
         }
         const size_t cb = train_recurrence_bwd_counter_bytes(B);        // (one slot size for both kinds of launch)
         ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
+        ra.fault = m->persist_mode == 2;       // (test of the give-up path)
         if (const int grid = train_recurrence_grid(ra, m->ncu)) {
             hipEvent_t ev{};
             double flops = 0;

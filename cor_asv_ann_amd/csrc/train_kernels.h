@@ -26,7 +26,7 @@ struct RecJob {
     const float* h0; const float* c0;   // [B][W] initial state or nullptr (zeros)
     int len, reverse;
 };
-struct RecArgs { RecJob job[2]; int njobs, B, W; unsigned* counters; };
+struct RecArgs { RecJob job[2]; int njobs, B, W; unsigned* counters; int fault; };   // fault: test of the give-up path (one workgroup leaves early)
 size_t train_recurrence_counter_bytes(int B);
 int train_recurrence_grid(const RecArgs& ra, int ncu);      // 0: no persistent form for this shape on this device
 void launch_train_recurrence(const RecArgs& ra, int grid, hipStream_t stream);

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void train_recurrence_kernel(const RecArgs 
     }
 
     for (int k = 0; k < len; ++k) {
+        if (ra.fault && blockIdx.x == 0 && k == 1) return;      // (test: a workgroup that never hands on -- its peers must give up)
         const int t = job.reverse ? len - 1 - k : k, tp = job.reverse ? t + 1 : t - 1;
         const float* arow = k == 0 ? (job.h0 ? job.h0 + (long long)mrow * W + sk : nullptr)
                                    : job.hs + ((long long)tp * B + mrow) * job.hs_ld + sk;

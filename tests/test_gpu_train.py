@@ -409,3 +409,80 @@ def test_persistent_recurrences_under_uneven_load():
     finally:
         stop.append(1)
         th.join()
+
+
+def test_two_train_sessions_share_the_gpu(capfd):
+    """Two model handles run train steps at the same time, each with persistent recurrences that want every CU: whichever way the
+    hardware interleaves their workgroups -- one launch after the other, or both partly resident, waiting for workgroups that cannot
+    start (then both give up after their bounded wait and redo the step with per-step launches) -- every step must return what
+    the same step returns alone."""
+    import threading
+    from cor_asv_ann_amd.engine import HipEngine
+    d, W, V, B, L = 2, 512, 64, 512, 16
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    w = make_weights(cfg, emb_scale=4.0)
+    jobs = []
+    for k in range(2):
+        _, sidx = make_lines(B, L, 31 + k, voc_size=V)
+        _, tidx = make_lines(B, L, 41 + k, voc_size=V)
+        U = L + 2
+        dec_in = np.full((B, U), -1, np.int32); dec_out = np.full((B, U), -1, np.int32)
+        dec_in[:, 1:L + 2] = tidx; dec_out[:, :L + 1] = tidx
+        jobs.append((sidx, dec_in, dec_out, (dec_out >= 0).astype(np.float32)))
+    engs = [HipEngine(d, W, V) for _ in range(2)]
+    for e in engs:
+        e.set_weights(w)
+        e.train_begin()
+    alone = [engs[k].train_step(jobs[k][0], None, jobs[k][1], jobs[k][2], jobs[k][3], None, mode=2) for k in range(2)]
+    got = [[], []]
+    start = threading.Barrier(2)
+
+    def work(k):
+        start.wait()
+        for _ in range(8):
+            got[k].append(engs[k].train_step(jobs[k][0], None, jobs[k][1], jobs[k][2], jobs[k][3], None, mode=2))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(2):
+        for loss, norm in got[k]:
+            assert abs(loss - alone[k][0]) < 1e-8 * abs(alone[k][0]) and abs(norm - alone[k][1]) < 2e-5 * alone[k][1]
+    for e in engs:
+        e.train_end()
+        e.close()
+    print(capfd.readouterr().err[-400:])
+
+
+def test_a_recurrence_that_loses_a_workgroup_gives_up_and_the_step_falls_back(capfd):
+    """What a GPU shared with another process's persistent kernel can do to a persistent recurrence: a workgroup its peers wait for
+    does not run.  Option "persistent" = 2 makes one workgroup of the forward recurrences leave without handing on; the others
+    give up after their bounded wait (50 ms), the launch drains, the host sees the abort word before anything is updated and
+    redoes the step with per-step launches: same results, a message, and no second attempt for the next steps."""
+    from cor_asv_ann_amd.engine import HipEngine
+    d, W, V, B, L = 2, 256, 64, 70, 5
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    w = make_weights(cfg, emb_scale=4.0)
+    _, sidx = make_lines(B, L, 3, voc_size=V)
+    _, tidx = make_lines(B, L, 4, voc_size=V)
+    U = L + 2
+    dec_in = np.full((B, U), -1, np.int32); dec_out = np.full((B, U), -1, np.int32)
+    dec_in[:, 1:L + 2] = tidx; dec_out[:, :L + 1] = tidx
+    wts = (dec_out >= 0).astype(np.float32)
+    eng = HipEngine(d, W, V)
+    eng.set_weights(w)
+    eng.train_begin()
+    eng.set_option('persistent', 0)
+    want = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=2)
+    capfd.readouterr()
+    eng.set_option('persistent', 2)
+    got = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=2)
+    assert 'gave up waiting' in capfd.readouterr().err
+    assert abs(got[0] - want[0]) < 1e-8 * abs(want[0]) and abs(got[1] - want[1]) < 2e-5 * want[1]
+    again = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=2)         # backed off: no launch, no message
+    assert 'gave up waiting' not in capfd.readouterr().err
+    assert abs(again[0] - want[0]) < 1e-8 * abs(want[0]) and abs(again[1] - want[1]) < 2e-5 * want[1]
+    eng.train_end()
+    eng.close()
