@@ -222,10 +222,16 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
 /* Options: "graph" = replay the decode step through a captured hipGraph (1) or launch kernels eagerly (0);
  * "persistent" = greedy decoding through the persistent decoder (all steps in ONE launch, workgroups hand rows to each
  * other through memory: small batches, where a step is too short for a launch per kernel): -1 by batch size (default:
- * up to 512 lines), 0 never, 1 always -- the results are the same bit for bit;
+ * up to 512 lines), 0 never, 1 always -- the results are the same bit for bit; the same option governs the train step's
+ * recurrences (every pair of plain layers walks its sequence in ONE launch forward and ONE backward unless 0; 2 = as -1, and
+ * one workgroup of the first forward recurrence leaves without handing on -- a test of the give-up path: the step is redone
+ * with per-step launches);
+ * "fused_backward" = 1 (default): a backward time step without a persistent form is ONE launch (cell backward inside the data
+ * GEMM), 0: two;
  * "eos" = vocabulary index of the end-of-line character '\n' (default 1: '' and '\n' sort first, seq2seq.py:580);
  * "tile" (process-wide; alias "skinny") = tile shape of the GEMM launches: -1 by size (default), 0 always 128x128,
- * 1 always 32x128 -- a measurement/test switch, the values computed are the same bit for bit. */
+ * 1 always 32x128, 2 = 64x128 wherever there is no split-K -- a measurement/test switch, the values computed are the same bit
+ * for bit. */
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 /* Statistics of the last call (tests): "beam_max_new_keys" = most child hypotheses one line created in one search
  * iteration of the last casv_decode_beam; "beam_sort_capacity" = how many of them are sorted in LDS at once (more are
