@@ -106,6 +106,7 @@ struct GemmArgs {
     SlotPtr c_out;
     SlotPtr zinit;        // LSTM: pre-activation term added to the contraction, [M][4U] interleaved (x.K + b of all steps, precomputed)
     SlotPtr gates_out;    // training: activated gates i,f,g,o, [M][4U] in the interleaved column order (or null)
+    SlotPtr out2;         // training: a second copy of h (the next step's cell input rows [ctx | h]) (or null)
     const int* nact;      // beam decode: live rows per line (0 = search finished); a tile without a live row is skipped --
     int nact_group;       // rows per line                                   its rows are never read
     int epi_plain;        // job of an EPI_LSTM launch that takes the PLAIN epilogue (lets independent GEMMs of both kinds share a launch)
@@ -158,7 +159,9 @@ struct AttnArgs {
     const int* prev;        // [R] global row id of the parent expansion
     const int* line;        // [R] or nullptr (then line = r / rows_per_line)
     int rows_per_line;
-    float* ctx;             // [R][C]
+    float* ctx;             // [R][C] (row stride ctx_ld if set)
+    long long ctx_ld;       // 0 = C; train step: the context goes straight into the cell's input rows [ctx | h]
+    const float* ctx_mask; long long ctx_mask_ld;   // optional per-row keep-mask of the context (train step: dropout on the cell input)
     int R, T, W, C, window;
     int step_imm; const int* step_ptr;   // output slot = step + 1
     double* apos;           // [R] sum_s a'[s]*s

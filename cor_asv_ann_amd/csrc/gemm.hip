@@ -315,6 +315,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         float* gout = g.gates_out.base
             ? g.gates_out.base + (long long)(step * g.gates_out.step_mul + g.gates_out.step_add) * g.gates_out.slot_stride
             : nullptr;
+        float* hout2 = g.out2.base ? g.out2.base + (long long)(step * g.out2.step_mul + g.out2.step_add) * g.out2.slot_stride : nullptr;
         if (zin) {      // precomputed input term (train step): all loads issue before the first store of the loop below
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -332,6 +333,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
                 const LstmCellOut cell = lstm_cell(zi, zf, zg, zo, cprev);
                 cout[(long long)m * g.c_out.ld + u] = cell.c;
                 hout[(long long)m * g.out.ld + u] = cell.h;
+                if (hout2) hout2[(long long)m * g.out2.ld + u] = cell.h;
                 if (gout) {
                     float* gr = gout + (long long)m * g.gates_out.ld + n0 + l31;
                     gr[0] = cell.i; gr[32] = cell.f; gr[64] = cell.g; gr[96] = cell.o;

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         float* gout = g.gates_out.base
             ? g.gates_out.base + (long long)(step * g.gates_out.step_mul + g.gates_out.step_add) * g.gates_out.slot_stride
             : nullptr;
+        float* hout2 = g.out2.base ? g.out2.base + (long long)(step * g.out2.step_mul + g.out2.step_add) * g.out2.slot_stride : nullptr;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             // gate w of every (row, unit) of the row block -> LDS; then wave w takes accumulator rows r = 4w .. 4w+3 of all four gates
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
                     const LstmCellOut cell = lstm_cell(z[q][0] + bi, z[q][1] + bf_, z[q][2] + bg, z[q][3] + bo, cpv[rb][q]);
                     cout[(long long)m * g.c_out.ld + u] = cell.c;
                     hout[(long long)m * g.out.ld + u] = cell.h;
+                    if (hout2) hout2[(long long)m * g.out2.ld + u] = cell.h;
                     if (gout) {
                         float* gr = gout + (long long)m * g.gates_out.ld + n0 + l31;
                         gr[0] = cell.i; gr[32] = cell.f; gr[64] = cell.g; gr[96] = cell.o;

@@ -140,7 +140,8 @@ __device__ __forceinline__ void att_context(const AttnArgs& a, const int r, cons
                                             const float (&e)[MAXWIN]) {
     const int C = a.C, s_lo = w.s_lo, cnt = w.cnt;
     const float nanv = __builtin_nanf("");
-    float4* ctx4 = reinterpret_cast<float4*>(a.ctx + (long long)r * C);
+    float4* ctx4 = reinterpret_cast<float4*>(a.ctx + (long long)r * (a.ctx_ld ? a.ctx_ld : C));
+    const float4* mk4 = a.ctx_mask ? reinterpret_cast<const float4*>(a.ctx_mask + (long long)r * a.ctx_mask_ld) : nullptr;
     const int C4 = C >> 2;
     for (int c = lane; c < C4; c += 64) {
         float4 v = cnt <= 0 ? make_float4(nanv, nanv, nanv, nanv) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -154,6 +155,7 @@ __device__ __forceinline__ void att_context(const AttnArgs& a, const int r, cons
                 if (i0 + i < MAXWIN && i0 + i < cnt) { v.x += e[i0 + i] * x[i].x; v.y += e[i0 + i] * x[i].y; v.z += e[i0 + i] * x[i].z; v.w += e[i0 + i] * x[i].w; }
             if (WB < MAXWIN) __builtin_amdgcn_sched_barrier(0);
         }
+        if (mk4) { const float4 k = mk4[c]; v.x *= k.x; v.y *= k.y; v.z *= k.z; v.w *= k.w; }
         if (HANDOFF) {
             float* dst = reinterpret_cast<float*>(ctx4 + c);
             store_sc1(dst, v.x); store_sc1(dst + 1, v.y); store_sc1(dst + 2, v.z); store_sc1(dst + 3, v.w);

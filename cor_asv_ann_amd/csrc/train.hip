@@ -37,7 +37,7 @@ struct TrainState {
     DevBuf ETp, WaN, UaN;                  // derived: E^T padded [W][Vp], W_a [W][W], U_a [C][W]
     int B = 0, T = 0, U = 0, A = 0;
     DevBuf e_idx, e_val, d_in, d_out, d_w, m_enc, m_dec, m_cell;
-    DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, CTX, RecIn, prev, logits, dG, d_enc, du, DWQ, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
+    DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, RecIn, prev, logits, dG, d_enc, du, DWQ, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
     std::vector<DevBuf> O, DO;             // masked layer outputs (encoder O[n], decoder DO[n])
     DevBuf loss, normsq;
     DevBuf dcalt;                          // second dL/dc buffers of the fused backward steps (two layers)
@@ -109,7 +109,7 @@ int casv_train_release(casv_model* m) {
     for (auto& t : ts->tens) { t.w.release(); t.g.release(); t.m.release(); t.v.release(); }
     for (auto& l : ts->layers) { l.wxT.release(); l.wrT.release(); l.Hown.release(); l.Cs.release(); l.Gt.release(); l.Z.release(); l.dRec.release(); }
     DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
-        &ts->m_cell, &ts->X0, &ts->H1, &ts->u, &ts->Y0, &ts->Ym, &ts->WQ, &ts->Ast, &ts->WIN, &ts->CTX, &ts->RecIn, &ts->prev,
+        &ts->m_cell, &ts->X0, &ts->H1, &ts->u, &ts->Y0, &ts->Ym, &ts->WQ, &ts->Ast, &ts->WIN, &ts->RecIn, &ts->prev,
         &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl, &ts->dYl, &ts->dOin, &ts->dcbuf2, &ts->dvaP, &ts->dbvP,
         &ts->loss, &ts->normsq, &ts->rec_cnt, &ts->dcalt};
     for (DevBuf* b : bufs) b->release();
@@ -457,7 +457,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     ENS(ts->e_idx, TB * A * 4) ENS(ts->e_val, TB * A * 4) ENS(ts->d_in, UB * 4) ENS(ts->d_out, UB * 4) ENS(ts->d_w, UB * 4)
     ENS(ts->m_enc, (size_t)(D + 1) * W * 4) ENS(ts->m_dec, (size_t)D * W * 4) ENS(ts->m_cell, (size_t)B * (W + C) * 4)
     ENS(ts->X0, TB * W * 4) ENS(ts->H1, TB * 2 * W * 4) ENS(ts->u, TB * W * 4) ENS(ts->Y0, UB * W * 4) ENS(ts->Ym, UB * W * 4)
-    ENS(ts->WQ, UB * W * 4) ENS(ts->Ast, (size_t)(U + 1) * B * T * 4) ENS(ts->WIN, UB * 4) ENS(ts->CTX, (size_t)B * C * 4)
+    ENS(ts->WQ, UB * W * 4) ENS(ts->Ast, (size_t)(U + 1) * B * T * 4) ENS(ts->WIN, UB * 4)
     ENS(ts->RecIn, UB * (C + W) * 4) ENS(ts->prev, (size_t)B * 4) ENS(ts->logits, UB * Vp * 4)
     ENS(ts->dG, UB * W * 4) ENS(ts->d_enc, TB * C * 4) ENS(ts->du, TB * W * 4) ENS(ts->DWQ, UB * W * 4) ENS(ts->dhatt, UB * W * 4)
     ENS(ts->dfin, (size_t)2 * D * B * W * 4) ENS(ts->dcbuf, (size_t)B * W * 4) ENS(ts->HP, LB * W * 4)
@@ -543,6 +543,10 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     const float* h0t = hfin + (size_t)(D - 1) * B * W; const float* c0t = cfin + (size_t)(D - 1) * B * W;
     HIPCHK(hipMemsetAsync(ts->Ast.p, 0, (size_t)B * T * 4, st));
     HIPCHK(hipMemsetAsync(ts->WQ.p, 0, UB * W * 4, st));        // split-K partial sums land here
+    // The cell's input rows [ctx * mask | h(t-1)] (LSTMCell(dropout) masks the cell input [y | ctx] per sample, seq2seq.py:345; the y
+    // part is masked where it is precomputed) are filled where their parts are produced: the attention rows write the masked
+    // context straight into them, the cell of the step before stores its h a second time.
+    HIPCHK(hipMemcpy2DAsync(ts->RecIn.as<float>() + C, (size_t)(C + W) * 4, h0t, (size_t)W * 4, (size_t)W * 4, B, hipMemcpyDeviceToDevice, st));
     for (int t = 0; t < U; ++t) {
         const float* hprev = t == 0 ? h0t : top.hs + (long long)(t - 1) * B * W;
         float* wq = ts->WQ.as<float>() + (long long)t * B * W;
@@ -550,15 +554,16 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         AttnArgs a{};
         a.wq = wq; a.u = ts->u.as<float>(); a.enc = enc_out; a.va = ts->W_(ts->iva); a.bv = ts->W_(ts->ibv);
         a.a_base = ts->Ast.as<float>(); a.prev = nullptr; a.line = nullptr; a.rows_per_line = 1;
-        a.ctx = ts->CTX.as<float>(); a.R = B; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
+        float* rec = ts->RecIn.as<float>() + (long long)t * B * (C + W);
+        a.ctx = rec; a.ctx_ld = C + W; a.ctx_mask = mcell ? mcell + W : nullptr; a.ctx_mask_ld = W + C;
+        a.R = B; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
         a.step_imm = t; a.step_ptr = nullptr; a.apos = nullptr; a.amax1 = nullptr; a.nrows = nullptr;
         a.u_line = W; a.u_time = (long long)B * W; a.enc_line = C; a.enc_time = (long long)B * C;
         a.win_out = ts->WIN.as<int>() + (long long)t * B;
         launch_attention(a, st);
-        float* rec = ts->RecIn.as<float>() + (long long)t * B * (C + W);
-        launch_build_recin(ts->CTX.as<float>(), mcell, W + C, W, hprev, W, rec, B, C, W, st);
         GemmArgs g = layer_step_job(m, top, t, nullptr, c0t, ts->RecIn.as<float>());
         g.c_in.skip_first = 0;
+        if (t + 1 < U) g.out2 = mkslot(rec + (long long)B * (C + W) + C, C + W);
         run_gemm(m, EPI_LSTM, g);
     }
     // ================= loss =================

@@ -10,8 +10,6 @@ void launch_embed_tm(const float* E, const int* idx, const float* val, float* ou
 void launch_embed_scatter(float* dE, const int* idx, const float* val, const float* dX, long long ld_dx, int B, int T, int A,
                           int V, int W, hipStream_t st);
 void launch_mul_mask(const float* in, long long ld_in, const float* mask, float* out, long long ld_out, long long rows, int F, hipStream_t st);
-void launch_build_recin(const float* ctx, const float* mcell, long long ld_mc, int mc_off, const float* hprev, long long ld_h,
-                        float* out, int B, int C, int W, hipStream_t st);
 void launch_mul_rowmask(const float* in, long long ld_in, const float* mask, long long ld_mask, float* out, long long ld_out,
                         long long rows, int B, int F, hipStream_t st);
 void launch_softmax_ce(float* logits, const int* target, const float* weight, int B, int U, int V, int Vp, float inv_count,

@@ -83,23 +83,6 @@ void launch_mul_mask(const float* in, long long ld_in, const float* mask, float*
     hipLaunchKernelGGL(mul_mask_kernel, dim3(blocks), dim3(256), 0, st, in, ld_in, mask, out, ld_out, rows, F);
 }
 
-// ---- recurrent-side input of the attention cell: [ctx * mask | h_prev] (LSTMCell(dropout) masks the
-// cell input [y | ctx] per sample, seq2seq.py:345; the y part is masked where it is precomputed) ----
-__global__ void build_recin_kernel(const float* __restrict__ ctx, const float* __restrict__ mcell, long long ld_mc, int mc_off,
-                                   const float* __restrict__ hprev, long long ld_h, float* __restrict__ out, int B, int C, int W) {
-    const int b = blockIdx.x, F = C + W;
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-        float v;
-        if (f < C) v = ctx[(long long)b * C + f] * (mcell ? mcell[(long long)b * ld_mc + mc_off + f] : 1.0f);
-        else v = hprev ? hprev[(long long)b * ld_h + (f - C)] : 0.0f;
-        out[(long long)b * F + f] = v;
-    }
-}
-void launch_build_recin(const float* ctx, const float* mcell, long long ld_mc, int mc_off, const float* hprev, long long ld_h,
-                        float* out, int B, int C, int W, hipStream_t st) {
-    hipLaunchKernelGGL(build_recin_kernel, dim3(B), dim3(256), 0, st, ctx, mcell, ld_mc, mc_off, hprev, ld_h, out, B, C, W);
-}
-
 // ---- out[(t*B+b)][f] = in[(t*B+b)][f] * mask[b][f]: per-sample, time-constant mask ----
 __global__ void mul_rowmask_kernel(const float* __restrict__ in, long long ld_in, const float* __restrict__ mask, long long ld_mask,
                                    float* __restrict__ out, long long ld_out, long long rows, int B, int F) {
