@@ -547,18 +547,38 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     // part is masked where it is precomputed) are filled where their parts are produced: the attention rows write the masked
     // context straight into them, the cell of the step before stores its h a second time.
     HIPCHK(hipMemcpy2DAsync(ts->RecIn.as<float>() + C, (size_t)(C + W) * 4, h0t, (size_t)W * 4, (size_t)W * 4, B, hipMemcpyDeviceToDevice, st));
-    for (int t = 0; t < U; ++t) {
+    AttnArgs att{};         // what every step's attention rows share
+    att.u = ts->u.as<float>(); att.enc = enc_out; att.va = ts->W_(ts->iva); att.bv = ts->W_(ts->ibv);
+    att.a_base = ts->Ast.as<float>(); att.prev = nullptr; att.line = nullptr; att.rows_per_line = 1;
+    att.ctx_ld = C + W; att.ctx_mask = mcell ? mcell + W : nullptr; att.ctx_mask_ld = W + C;
+    att.R = B; att.T = T; att.W = W; att.C = C; att.window = m->cfg.window_width;
+    att.apos = nullptr; att.amax1 = nullptr; att.nrows = nullptr;
+    att.u_line = W; att.u_time = (long long)B * W; att.enc_line = C; att.enc_time = (long long)B * C;
+    bool top_persistent = false;
+    if (m->persist_mode != 0 && ts->rec_skip == 0 && ts->rec_launches < 16 && m->ncu >= 64) {
+        // ONE launch for the whole recurrence of the cell (train_persist_top.hip)
+        TopRecArgs ra{};
+        ra.Wr = ts->W_(top.iwr); ra.WaT = ts->W_(ts->iWaT); ra.bUW = ts->W_(ts->ibUW); ra.Z = top.Z.as<float>();
+        ra.RecIn = ts->RecIn.as<float>(); ra.WQ = ts->WQ.as<float>(); ra.hs = top.hs; ra.Cs = top.Cs.as<float>(); ra.Gt = top.Gt.as<float>();
+        ra.c0 = c0t; ra.WIN = ts->WIN.as<int>(); ra.att = att; ra.B = B; ra.U = U; ra.W = W; ra.C = C;
+        const size_t cb = train_recurrence_bwd_counter_bytes(B);
+        ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
+        if (const int grid = top.hs_ld == W ? train_attention_cell_grid(ra, m->ncu) : 0) {
+            hipEvent_t ev{};
+            m->prof_begin(PC_PERSIST, 2.0 * B * U * ((double)4 * W * (C + W) + (double)W * W), 0.0, ev);
+            launch_train_attention_cell(ra, grid, st);
+            m->prof_end(PC_PERSIST, ev);
+            ts->rec_abort[ts->rec_launches++] = ra.counters + (train_attention_cell_counter_bytes(B) / sizeof(unsigned) - 32);
+            top_persistent = true;
+        }
+    }
+    for (int t = 0; t < U && !top_persistent; ++t) {
         const float* hprev = t == 0 ? h0t : top.hs + (long long)(t - 1) * B * W;
         float* wq = ts->WQ.as<float>() + (long long)t * B * W;
         { GemmArgs g = plain_gemm(hprev, W, B, W, ts->W_(ts->iWaT), W, ts->W_(ts->ibUW), wq, W); g.out_zeroed = 1; run_gemm(m, EPI_PLAIN, g); }
-        AttnArgs a{};
-        a.wq = wq; a.u = ts->u.as<float>(); a.enc = enc_out; a.va = ts->W_(ts->iva); a.bv = ts->W_(ts->ibv);
-        a.a_base = ts->Ast.as<float>(); a.prev = nullptr; a.line = nullptr; a.rows_per_line = 1;
+        AttnArgs a = att;
         float* rec = ts->RecIn.as<float>() + (long long)t * B * (C + W);
-        a.ctx = rec; a.ctx_ld = C + W; a.ctx_mask = mcell ? mcell + W : nullptr; a.ctx_mask_ld = W + C;
-        a.R = B; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
-        a.step_imm = t; a.step_ptr = nullptr; a.apos = nullptr; a.amax1 = nullptr; a.nrows = nullptr;
-        a.u_line = W; a.u_time = (long long)B * W; a.enc_line = C; a.enc_time = (long long)B * C;
+        a.wq = wq; a.ctx = rec; a.step_imm = t; a.step_ptr = nullptr;
         a.win_out = ts->WIN.as<int>() + (long long)t * B;
         launch_attention(a, st);
         GemmArgs g = layer_step_job(m, top, t, nullptr, c0t, ts->RecIn.as<float>());

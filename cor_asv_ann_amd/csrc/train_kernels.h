@@ -45,6 +45,26 @@ size_t train_recurrence_bwd_counter_bytes(int B);
 int train_recurrence_bwd_grid(const RecBwdArgs& ra, int ncu);
 void launch_train_recurrence_bwd(const RecBwdArgs& ra, int grid, hipStream_t stream);
 
+// ... and the attention cell's forward recurrence (train_persist_top.hip): query, attention rows, cell input rows and LSTM step of
+// every time step in one launch.
+struct TopRecArgs {
+    const float* Wr;             // [4W][C + W] the cell's recurrent-side weights, columns [ctx | h], rows gate-interleaved
+    const float* WaT;            // [W][W] attention query weights (row = query column), bias bUW [W]
+    const float* bUW;
+    const float* Z;              // [U][B][4W]  y.Wx + b of every step
+    float* RecIn;                // [U][B][C + W] the cell's input rows [ctx * mask | h(t-1)]; slot 0's h part = the initial state
+    float* WQ;                   // [U][B][W] attention queries (kept for the backward pass)
+    float* hs; float* Cs; float* Gt;   // [U][B][W], [U][B][W], [U][B][4W]
+    const float* c0;             // [B][W] initial cell state
+    int* WIN;                    // [U][B] attention windows (kept for the backward pass)
+    AttnArgs att;                // u, enc, v_a, b_v, alignment store, strides, context mask (wq / ctx / step / win_out are set per step)
+    int B, U, W, C;
+    unsigned* counters;
+};
+size_t train_attention_cell_counter_bytes(int B);
+int train_attention_cell_grid(const TopRecArgs& ra, int ncu);
+void launch_train_attention_cell(const TopRecArgs& ra, int grid, hipStream_t stream);
+
 struct LstmBwdArgs {
     const float* a; long long lda; const float* mask_a;     // gradient from the layer above (x dropout mask)
     const float* b; long long ldb;                           // recurrent gradient

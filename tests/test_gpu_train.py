@@ -300,15 +300,16 @@ def test_c4_full_size_step_equals_oracle(golden_dir):
     # a second evaluation of the same step: float atomics may reorder sums, nothing else may move
     loss2, norm2 = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
     assert abs(loss2 - loss) < 1e-6 * abs(loss) and abs(norm2 - norm) < 1e-5 * norm
-    # ... and with one launch per time step in the forward recurrences instead of the persistent launches: the same forward
-    # pass bit for bit (the loss is an fp64 sum of the same fp32 terms), the same gradients up to the order of atomic sums
+    # ... and with one launch per time step instead of the persistent launches: the recurrences of the plain layers give the same
+    # bits either way; the attention cell's persistent form sums its gate pre-activations over [h | ctx] instead of [ctx | h] and
+    # the attention query in four k quarters instead of two split-K shares: the same forward pass to fp32 rounding
     eng.set_option('persistent', 0)
     loss3, norm3 = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
-    assert abs(loss3 - loss) < 1e-12 * abs(loss) and abs(norm3 - norm) < 1e-5 * norm
+    assert abs(loss3 - loss) < 1e-6 * abs(loss) and abs(norm3 - norm) < 1e-5 * norm
     # ... and with the cell's backward as a launch of its own in front of every backward step's data GEMM
     eng.set_option('fused_backward', 0)
     loss4, norm4 = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
-    assert abs(loss4 - loss) < 1e-12 * abs(loss) and abs(norm4 - norm) < 2e-5 * norm
+    assert abs(loss4 - loss) < 1e-6 * abs(loss) and abs(norm4 - norm) < 2e-5 * norm
     grads4 = eng.train_gradients()
     for k, got in grads.items():
         scale = max(float(g['max/' + k]), 1e-6 * onorm)
@@ -317,7 +318,7 @@ def test_c4_full_size_step_equals_oracle(golden_dir):
     eval_a, _ = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=0)
     eng.set_option('persistent', -1)
     eval_b, _ = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=0)
-    assert abs(eval_a - eval_b) < 1e-12 * abs(eval_a)
+    assert abs(eval_a - eval_b) < 1e-6 * abs(eval_a)
     eng.train_end()
     eng.close()
 
