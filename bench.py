@@ -186,7 +186,7 @@ def train_bench(args):
     keep = lambda shape: ((rng.random(shape) >= 0.2) / 0.8).astype(np.float32)
     masks = {'enc': [keep(2 * WIDTH if n == 0 else WIDTH) for n in range(DEPTH)], 'dec': [keep(WIDTH) for _ in range(DEPTH - 1)],
              'cell': keep((B, 2 * WIDTH))}
-    for opt in ('persistent', 'fused_backward'):    # A/B switches: 0 = one launch per time step and operation
+    for opt in ('persistent', 'fused_backward', 'vendor_gemm'):    # A/B switches: 0 = one launch per time step and operation
         if os.environ.get('CASV_OPT_' + opt.upper()):
             eng.set_option(opt, int(os.environ['CASV_OPT_' + opt.upper()]))
     eng.train_begin()

@@ -144,6 +144,9 @@ void launch_gemm_tn(const TnArgs& g, hipStream_t stream);
 void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream);
 void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream);
 void launch_gemm_skinny(int epi, const GemmBatch& b, int ksplit, int rows, hipStream_t stream);
+// optional vendor path for plain contractions C[M][N] (+)= A[M][K] . Bt[N][K]^T (+ bias) (vendor_gemm.hip); false = not taken
+bool vendor_gemm_nt(const float* A, long long lda, long long M, int K, const float* Bt, int N, const float* bias, float* C, long long ldc,
+                    int accumulate, hipStream_t stream);
 bool gemm_is_skinny(int epi, const GemmBatch& b);     // which tile shape launch_gemm_batch will pick
 // tile shape of the GEMM launches: -1 = by size (default), 0 = always 128x128, 1 = always 32x128 (same results)
 void set_gemm_tile_mode(int mode);

@@ -1189,6 +1189,7 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
         m->eos = (int)value; return CASV_OK;
     }
     if (!strcmp(key, "fused_backward")) { m->fused_backward = value != 0; return CASV_OK; }
+    if (!strcmp(key, "vendor_gemm")) { m->vendor_gemm = value != 0; return CASV_OK; }
     if (!strcmp(key, "skinny") || !strcmp(key, "tile")) {   // process-wide: tile shape of the GEMM launches (results identical)
         if (value < -1 || value > 2) return fail(CASV_ERR_ARG, "tile must be -1 (by size), 0 (128x128), 1 (32x128) or 2 (64x128 where there is no split-K)");
         set_gemm_tile_mode((int)value); return CASV_OK;

@@ -195,6 +195,19 @@ static GemmArgs plain_gemm(const float* A, long long lda, int M, int K, const fl
     return g;
 }
 
+// A plain contraction over the whole sequence (thousands of rows, nothing fused): through the vendor library when that is switched
+// on and has a solution for the shape (vendor_gemm.hip), else gemm.hip.
+static void run_plain(casv_model* m, GemmArgs& g) {
+    if (m->vendor_gemm && g.nseg == 1 && !g.a[0].rows && !g.step_ptr && g.M >= 4096 && g.a[0].width == g.Ktot && g.a[0].koff == 0) {
+        hipEvent_t ev{};
+        m->prof_begin(PC_GEMM, 2.0 * g.M * (double)g.N * g.Ktot, 4.0 * ((double)g.M * g.Ktot + (double)g.N * g.Ktot + (double)g.M * g.N), ev);
+        const bool done = vendor_gemm_nt(g.a[0].base, g.a[0].ld, g.M, g.Ktot, g.Bt, g.N, g.bias, g.out.base, g.out.ld, g.accumulate, m->stream);
+        m->prof_end(PC_GEMM, ev);
+        if (done) return;
+    }
+    run_gemm(m, EPI_PLAIN, g);
+}
+
 // C[M][N] += A^T . B for operands as the forward / backward passes left them: A [K][lda], B [K][ldb] (gemm_tn.hip)
 static void run_gemm_tn(casv_model* m, const float* A, long long lda, int M, int Mstore, const float* B, long long ldb, int N, long long K,
                         float* C, long long ldc, float* colsum = nullptr) {
@@ -236,7 +249,7 @@ static int time_of(const TLayer& l, int k) { return l.reverse ? l.len - 1 - k : 
 static void layer_input_gemm(casv_model* m, TLayer& l, const float* x, long long ldx) {
     TrainState* ts = m->train;
     GemmArgs g = plain_gemm(x, ldx, l.len * ts->B, l.kx, ts->W_(l.iwx), 4 * m->W, ts->W_(l.ib), l.Z.as<float>(), 4 * m->W);
-    run_gemm(m, EPI_PLAIN, g);
+    run_plain(m, g);
 }
 
 // weight gradients of one layer from dZ (in l.Z), its inputs x and its recurrent-side inputs rec [len*B][kr]: both
@@ -297,7 +310,7 @@ static int layer_backward_finish(casv_model* m, const LayerBwd& a) {
     const long long rows = (long long)l.len * B;
     if (a.dX) {
         GemmArgs g = plain_gemm(l.Z.as<float>(), 4 * W, (int)rows, 4 * W, l.wxT.as<float>(), l.kx, nullptr, a.dX, a.ld_dx, a.dx_accumulate);
-        run_gemm(m, EPI_PLAIN, g);
+        run_plain(m, g);
     }
     // recurrent-side inputs of every step: HP[t] = h of the previously processed step (h0 / zero at the first)
     float* HP = ts->HP.as<float>();
@@ -534,7 +547,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         y = ts->DO[n - 1].as<float>();
     }
     const float* enc_out = ts->O[D].as<float>();
-    { GemmArgs g = plain_gemm(enc_out, C, (int)TB, C, ts->W_(ts->iUT), W, nullptr, ts->u.as<float>(), W); run_gemm(m, EPI_PLAIN, g); }
+    { GemmArgs g = plain_gemm(enc_out, C, (int)TB, C, ts->W_(ts->iUT), W, nullptr, ts->u.as<float>(), W); run_plain(m, g); }
 
     // ================= forward: attention cell =================
     TLayer& top = dec_layer(D);
@@ -587,7 +600,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         run_gemm(m, EPI_LSTM, g);
     }
     // ================= loss =================
-    { GemmArgs g = plain_gemm(top.hs, W, (int)UB, W, ts->W_(ts->iE), V, nullptr, ts->logits.as<float>(), Vp); run_gemm(m, EPI_PLAIN, g); }
+    { GemmArgs g = plain_gemm(top.hs, W, (int)UB, W, ts->W_(ts->iE), V, nullptr, ts->logits.as<float>(), Vp); run_plain(m, g); }
     launch_softmax_ce(ts->logits.as<float>(), ts->d_out.as<int>(), ts->d_w.as<float>(), B, U, V, Vp, inv_count, ts->loss.as<double>(),
                       training ? 1 : 0, st);
     // Did every persistent recurrence so far run to its end?  (A launch gives up when its workgroups wait too long for each
@@ -628,7 +641,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     {
         run_gemm_tn(m, dlog, Vp, Vp, V, top.hs, W, W, UB, ts->G_(ts->iE), W);      // (the padding columns of dlogits are zero)
         GemmArgs g2 = plain_gemm(dlog, Vp, (int)UB, Vp, ts->ETp.as<float>(), W, nullptr, ts->dG.as<float>(), W);
-        run_gemm(m, EPI_PLAIN, g2);
+        run_plain(m, g2);
     }
     HIPCHK(hipMemsetAsync(ts->d_enc.p, 0, TB * C * 4, st));
     HIPCHK(hipMemsetAsync(ts->du.p, 0, TB * W * 4, st));
@@ -692,7 +705,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         launch_axpy(dfin_h(D), ts->dhatt.as<float>(), (long long)B * W, st);       // slot of step 0
         // y-part gradient for all steps, weight grads
         GemmArgs g = plain_gemm(top.Z.as<float>(), 4 * W, (int)UB, 4 * W, top.wxT.as<float>(), W, nullptr, ts->dXtop.as<float>(), W);
-        run_gemm(m, EPI_PLAIN, g);
+        run_plain(m, g);
         launch_mul_rowmask(ts->dXtop.as<float>(), W, mcell, W + C, ts->dXtop.as<float>(), W, UB, B, W, st);
         if (int rc = layer_weight_grads(m, top, ts->Ym.as<float>(), W, ts->RecIn.as<float>(), kr)) return rc;
         // attention parameters: dWaT = DWQ^T . Hprev ; dbUW = colsum(DWQ) ; u path
@@ -703,7 +716,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         {
             run_gemm_tn(m, ts->du.as<float>(), W, W, W, enc_out, C, C, TB, ts->G_(ts->iUT), C);
             GemmArgs gd = plain_gemm(ts->du.as<float>(), W, (int)TB, W, ts->UaN.as<float>(), C, nullptr, ts->d_enc.as<float>(), C, 1);
-            run_gemm(m, EPI_PLAIN, gd);
+            run_plain(m, gd);
         }
     }
     // ---- decoder layer n with encoder layer n+1 (the mirror of the forward pairing) ----

@@ -315,6 +315,17 @@ def test_c4_full_size_step_equals_oracle(golden_dir):
         scale = max(float(g['max/' + k]), 1e-6 * onorm)
         assert np.abs(grads4[k] - got).max() < 1e-4 * scale + 1e-7, k
     eng.set_option('fused_backward', 1)
+    # ... and with this library's own GEMM kernel for the plain whole-sequence contractions instead of the vendor's (hipBLASLt,
+    # loaded at run time where present: input projections of all time steps and their data gradients)
+    eng.set_option('persistent', -1)
+    eng.set_option('vendor_gemm', 0)
+    loss5, norm5 = eng.train_step(sidx, None, dec_in, dec_out, wts, masks, mode=2)
+    assert abs(loss5 - loss) < 1e-6 * abs(loss) and abs(norm5 - norm) < 2e-5 * norm
+    grads5 = eng.train_gradients()
+    for k, got in grads.items():
+        scale = max(float(g['max/' + k]), 1e-6 * onorm)
+        assert np.abs(grads5[k] - got).max() < 1e-4 * scale + 1e-7, k
+    eng.set_option('vendor_gemm', 1)
     eval_a, _ = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=0)
     eng.set_option('persistent', -1)
     eval_b, _ = eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=0)
