@@ -432,7 +432,9 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
     // 64 x 128 tiles (gemm_skinny.hip, two row blocks per workgroup) for launches without split-K that leave at most one 128x128
     // workgroup per CU, or go as 32-row tiles, while 64-row tiles still put two on every CU: the encoder at 1024 lines -- layer 1's
     // two directions (256 tiles of 128x128) and the anti-diagonals of the layers above (384)
-    if (!splittable && p.ksplit == 1) {
+    // (fused-LSTM launches only: the plain-epilogue launch it would also catch, the page call's logits -- 10240 x 640 x 512 --, runs
+    // 67.6 us as 32-row tiles and 75.6 us as 64-row tiles)
+    if ((epi == EPI_LSTM || g_tile_mode == 2) && !splittable && p.ksplit == 1) {
         int blocks64 = 0;
         for (int j = 0; j < b.count; ++j) blocks64 = std::max(blocks64, ((b.g[j].M + 63) / 64) * ((b.g[j].N + BN - 1) / BN));
         const bool fits = blocks64 * b.count >= 2 * ncu;
