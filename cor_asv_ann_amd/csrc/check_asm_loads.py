@@ -16,7 +16,7 @@ import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT = ['gemm.hip', 'gemm_skinny.hip', 'gemm_tn.hip', 'gemm_bwd.hip', 'train_persist.hip', 'train_persist_bwd.hip', 'train_persist_top.hip']
+DEFAULT = ['gemm.hip', 'gemm_skinny.hip', 'gemm_tn.hip', 'gemm_bwd.hip', 'train_persist.hip', 'train_persist_bwd.hip', 'train_persist_top.hip', 'train_persist_topb.hip']
 LOAD = re.compile(r'global_load_dword(x2|x3|x4)? v(?:\[(\d+):(\d+)\]|(\d+))')
 REG = re.compile(r'v\[(\d+):(\d+)\]|\bv(\d+)\b')
 
@@ -46,30 +46,33 @@ def functions(lines):
 
 
 def blocks_of(body):
-    """basic blocks: label -> (instructions, successor labels); the entry block is '' """
-    blocks, order, cur = {'': []}, [''], ''
+    """basic blocks: label -> instructions, label -> successor labels; the entry block is ''.  A block ends at a label and at
+    every branch (the instructions behind a conditional branch form an anonymous block of their own: what is issued there must
+    not be charged to the path that took the branch)."""
+    blocks, order, cur, anon = {'': []}, [''], '', 0
+    ends = {}                                   # label -> (targets, falls through)
     for no, t in body:
         m = re.match(r'^(\.LBB\w+):', t)
         if m:
+            ends.setdefault(cur, ([], True))
             cur = m.group(1)
             blocks[cur] = []
             order.append(cur)
             continue
         blocks[cur].append((no, t))
+        m = re.match(r'^s_(c?branch)\w*\s+(\.LBB\w+)', t)
+        if m or t.startswith('s_endpgm'):
+            ends[cur] = ([m.group(2)] if m else [], bool(m) and m.group(1) == 'cbranch')
+            anon += 1
+            cur = '%s+%d' % (order[-1].split('+')[0], anon)
+            blocks[cur] = []
+            order.append(cur)
+    ends.setdefault(cur, ([], True))
     succ = {}
     for i, lab in enumerate(order):
         nxt = order[i + 1] if i + 1 < len(order) else None
-        targets, falls = [], True
-        for no, t in blocks[lab]:
-            m = re.match(r'^s_(c?branch)\w*\s+(\.LBB\w+)', t)
-            if m:
-                targets.append(m.group(2))
-                if m.group(1) == 'branch':
-                    falls = False
-            if t.startswith('s_endpgm'):
-                falls = False
-        # (an instruction after an unconditional branch inside a block does not occur in compiler output)
-        succ[lab] = targets + ([nxt] if falls and nxt else [])
+        targets, falls = ends.get(lab, ([], True))
+        succ[lab] = list(targets) + ([nxt] if falls and nxt else [])
     return blocks, succ
 
 

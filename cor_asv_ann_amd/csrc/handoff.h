@@ -18,7 +18,7 @@ struct Dep { const unsigned* c; unsigned target; };
 
 // One lane waits until every counter has reached its target.  No cache invalidation follows: the payload is read with loads
 // that go past the L2 (load_sc1) -- an agent-scope acquire would empty this XCD's L2 of the weights as well, and the K loops
-// would wait for memory instead of the L2.  false = aborted.
+// would wait for memory instead of the L2.  A wait that gives up does not return (see below).
 __device__ __forceinline__ bool wait_deps(const Dep d0, const Dep d1, const Dep d2, unsigned* abort_w, int* s_ok) {
     if (threadIdx.x == 0) {
         int good = 1;
@@ -44,9 +44,15 @@ __device__ __forceinline__ bool wait_deps(const Dep d0, const Dep d1, const Dep 
         *s_ok = good;
     }
     __syncthreads();
-    const int ok = *s_ok;
+    const int ok = __builtin_amdgcn_readfirstlane(*s_ok);      // (one word for the whole workgroup: a scalar, the branch on it uniform)
     __syncthreads();
-    return ok != 0;
+    // A wait that gave up ends the wave here and now -- every wave of the workgroup takes this turn together, with nothing left in
+    // flight.  The function therefore never returns false (the callers' `if (!wait_deps(..)) return;` folds away): a `return` out
+    // of their loops would be laid out as a structured exit that shares blocks with the loop body, i.e. code paths on which
+    // registers with hidden loads in flight meet instructions that use them -- never walked, but neither check_asm_loads.py nor a
+    // reader could tell.
+    if (!ok) asm volatile("s_waitcnt vmcnt(0)\n\ts_endpgm" ::: "memory");
+    return true;
 }
 
 // Every wave has stored its share write-through; one lane signals for the workgroup.

@@ -657,7 +657,32 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         float* dc = dfin_c(D);
         HIPCHK(hipMemsetAsync(dc, 0, (size_t)B * W * 4, st));
         const int kr = C + W;
-        for (int t = U - 1; t >= 0; --t) {
+        bool topb_persistent = false;
+        if (m->persist_mode != 0 && ts->rec_skip == 0 && ts->rec_launches < 16 && m->ncu >= 64) {
+            // ONE launch for the whole backward recurrence of the cell (train_persist_topb.hip)
+            TopBwdArgs ra{};
+            ra.WrT = top.wrT.as<float>(); ra.WaN = ts->WaN.as<float>(); ra.dG = ts->dG.as<float>();
+            ra.Gt = top.Gt.as<float>(); ra.Cs = top.Cs.as<float>(); ra.c0 = c0t; ra.dZ = top.Z.as<float>(); ra.dRec = top.dRec.as<float>();
+            ra.dhatt = ts->dhatt.as<float>(); ra.DWQ = ts->DWQ.as<float>(); ra.WQ = ts->WQ.as<float>(); ra.Ast = ts->Ast.as<float>();
+            ra.WIN = ts->WIN.as<int>(); ra.dc_out = dc; ra.B = B; ra.U = U; ra.W = W; ra.C = C;
+            AttnBwdArgs& ab = ra.ab;
+            ab.mcell = mcell; ab.ld_mcell = W + C; ab.mc_off = W; ab.va = ts->W_(ts->iva);
+            ab.u = ts->u.as<float>(); ab.u_line = W; ab.u_time = (long long)B * W;
+            ab.enc = enc_out; ab.enc_line = C; ab.enc_time = (long long)B * C;
+            ab.d_enc = ts->d_enc.as<float>(); ab.du = ts->du.as<float>();
+            ab.dva_part = ts->dvaP.as<float>(); ab.dbv_part = ts->dbvP.as<float>(); ab.B = B; ab.T = T; ab.W = W; ab.C = C;
+            const size_t cb = train_recurrence_bwd_counter_bytes(B);
+            ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
+            if (const int grid = train_attention_cell_bwd_grid(ra, m->ncu)) {
+                hipEvent_t ev{};
+                m->prof_begin(PC_PERSIST, 2.0 * B * U * ((double)4 * W * (C + W) + (double)W * W), 0.0, ev);
+                launch_train_attention_cell_bwd(ra, grid, st);
+                m->prof_end(PC_PERSIST, ev);
+                ts->rec_abort[ts->rec_launches++] = ra.counters + (train_attention_cell_bwd_counter_bytes(B) / sizeof(unsigned) - 32);
+                topb_persistent = true;
+            }
+        }
+        for (int t = U - 1; t >= 0 && !topb_persistent; --t) {
             LstmBwdArgs p{};
             p.a = ts->dG.as<float>() + (long long)t * B * W; p.lda = W;
             if (t < U - 1) {
@@ -697,7 +722,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             g.out_zeroed = 1;
             run_gemm(m, EPI_PLAIN, g);
         }
-        if (m->fused_backward && (U & 1)) HIPCHK(hipMemcpyAsync(dc, ts->dcalt.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));   // dL/dc0 of the cell
+        if (!topb_persistent && m->fused_backward && (U & 1)) HIPCHK(hipMemcpyAsync(dc, ts->dcalt.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));   // dL/dc0 of the cell
         launch_colsum(ts->dvaP.as<float>(), B, W, W, ts->G_(ts->iva), st);
         launch_colsum(ts->dbvP.as<float>(), B, 1, 1, ts->G_(ts->ibv), st);
         // dL/dh0 of the cell = recurrent part of step 0 + the query path of step 0

@@ -98,6 +98,27 @@ struct AttnBwdArgs {
 };
 void launch_attention_bwd(const AttnBwdArgs& p, hipStream_t st);
 
+// ... and the attention cell's backward recurrence (train_persist_topb.hip): cell backward, data GEMM, attention backward and
+// query-path GEMM of every time step in one launch.
+struct TopBwdArgs {
+    const float* WrT;            // [C + W][4W] the cell's recurrent-side weights transposed (rows: ctx columns, then h columns)
+    const float* WaN;            // [W][W] attention query weights as the query-path GEMM takes them
+    const float* dG;             // [U][B][W] gradient w.r.t. the cell's outputs
+    const float* Gt; const float* Cs; const float* c0;     // what the forward pass kept; initial cell state
+    float* dZ;                   // [U][B][4W] out (over the forward pass's Z)
+    float* dRec;                 // [U][B][C + W] out, zeroed: gradient w.r.t. the cell's input rows [ctx | h(t-1)]
+    float* dhatt;                // [U][B][W] out: gradient w.r.t. h(t-1) through the attention query
+    float* DWQ;                  // [U][B][W] out: gradient w.r.t. the attention queries
+    const float* WQ; const float* Ast; const int* WIN;     // [U][B][W], [U+1][B][T], [U][B] kept by the forward pass
+    float* dc_out;               // [B][W] out: dL/dc0
+    AttnBwdArgs ab;              // mask, v_a, u, enc, d_enc, du, dva / dbv partial sums, sizes (dxh / a / win / wq / dwq are set per step)
+    int B, U, W, C;
+    unsigned* counters;
+};
+size_t train_attention_cell_bwd_counter_bytes(int B);
+int train_attention_cell_bwd_grid(const TopBwdArgs& ra, int ncu);
+void launch_train_attention_cell_bwd(const TopBwdArgs& ra, int grid, hipStream_t stream);
+
 void launch_axpy(float* y, const float* x, long long n, hipStream_t st);
 void launch_colsum(const float* in, long long rows, int cols, long long ld, float* out, hipStream_t st);
 void launch_reg(const float* E, float* dE, int V, int W, double* loss, int want_grad, hipStream_t st);

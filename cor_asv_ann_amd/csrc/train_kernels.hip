@@ -3,6 +3,7 @@
 // [t][b][feature], so that one time step is a contiguous [B][F] slab (a GEMM operand) and a whole
 // sequence is a [T*B][F] matrix (operand of the batched weight-gradient GEMMs).
 #include "train_kernels.h"
+#include "attn_bwd.h"
 #include <math.h>
 
 namespace casv {
@@ -198,62 +199,7 @@ void launch_lstm_bwd(const LstmBwdArgs& p, hipStream_t st) {
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdArgs p) {
     __shared__ float s_dx[2048];
     __shared__ float s_da[16], s_ds[16], s_av[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const int W = p.W, C = p.C, T = p.T;
-    const int wv = p.win[b];
-    const int s_lo = wv & 0xffff, cnt = wv >> 16;
-    const float* dx = p.dxh + (long long)b * p.ld_dxh + p.ctx_off;
-    const float* mc = p.mcell ? p.mcell + (long long)b * p.ld_mcell + p.mc_off : nullptr;
-    for (int c = tid; c < C; c += 256) s_dx[c] = dx[c] * (mc ? mc[c] : 1.0f);
-    if (tid < 16) s_av[tid] = tid < cnt ? p.a[(long long)b * T + s_lo + tid] : 0.0f;
-    __syncthreads();
-    // da_s = dctx . enc_s
-    for (int i = wave; i < cnt; i += 4) {
-        const float* es = p.enc + (long long)b * p.enc_line + (long long)(s_lo + i) * p.enc_time;
-        float part = 0.f;
-        for (int c = lane; c < C; c += 64) part += s_dx[c] * es[c];
-        part = wsum(part);
-        if (lane == 0) s_da[i] = part;
-    }
-    __syncthreads();
-    if (tid < 16) {
-        float dot = 0.f;
-        for (int i = 0; i < cnt; ++i) dot += s_av[i] * s_da[i];
-        s_ds[tid] = tid < cnt ? s_av[tid] * (s_da[tid] - dot) : 0.0f;          // dL/dscore
-    }
-    __syncthreads();
-    // d enc_out[s] += a_s * dctx
-    float* de = p.d_enc + (long long)b * p.enc_line + (long long)s_lo * p.enc_time;
-    for (int i = 0; i < cnt; ++i) {
-        const float av = s_av[i];
-        for (int c = tid; c < C; c += 256) atomicAdd(de + (long long)i * p.enc_time + c, av * s_dx[c]);
-    }
-    // energies: th = tanh(wq + u_s); dva += dscore*th ; dpre = dscore*va*(1-th^2) -> du_s, dwq
-    for (int j = tid; j < W; j += 256) {
-        const float q = p.wq[(long long)b * W + j], v = p.va[j];
-        const long long off0 = (long long)b * p.u_line + (long long)s_lo * p.u_time + j;
-        float uu[11];
-#pragma unroll
-        for (int i = 0; i < 11; ++i) uu[i] = p.u[off0 + (long long)(i < cnt ? i : 0) * p.u_time];
-        float dwq = 0.f, dva = 0.f;
-#pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            const float th = fast_tanh(q + uu[i]);
-            const float ds = s_ds[i];
-            dva += ds * th;
-            const float dpre = ds * v * (1.0f - th * th);
-            if (i < cnt) atomicAdd(p.du + off0 + (long long)i * p.u_time, dpre);
-            dwq += dpre;
-        }
-        p.dwq[(long long)b * W + j] = dwq;
-        p.dva_part[(long long)b * W + j] += dva;
-    }
-    if (tid == 0) {
-        float dbv = 0.f;
-        for (int i = 0; i < cnt; ++i) dbv += s_ds[i];
-        p.dbv_part[b] += dbv;
-    }
+    attention_bwd_sample<false>(p, blockIdx.x, true, threadIdx.x, 256, s_dx, s_da, s_ds, s_av);
 }
 void launch_attention_bwd(const AttnBwdArgs& p, hipStream_t st) {
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(p.B), dim3(256), 0, st, p);
