@@ -147,6 +147,7 @@ void launch_gemm_skinny(int epi, const GemmBatch& b, int ksplit, int rows, hipSt
 // optional vendor path for plain contractions C[M][N] (+)= A[M][K] . Bt[N][K]^T (+ bias) (vendor_gemm.hip); false = not taken
 bool vendor_gemm_nt(const float* A, long long lda, long long M, int K, const float* Bt, int N, const float* bias, float* C, long long ldc,
                     int accumulate, hipStream_t stream);
+void vendor_gemm_release(hipStream_t stream);         // frees the vendor path's workspace of a stream (model destruction)
 bool gemm_is_skinny(int epi, const GemmBatch& b);     // which tile shape launch_gemm_batch will pick
 // tile shape of the GEMM launches: -1 = by size (default), 0 = always 128x128, 1 = always 32x128 (same results)
 void set_gemm_tile_mode(int mode);
@@ -261,6 +262,9 @@ struct BeamState {
 };
 void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t stream);
 void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream);
+#ifdef CASV_GEMM_PROF
+void gemm_prof_dump();               // diagnostic build: in-kernel cycle stamps of the 128x128 LSTM GEMM (gemm.hip)
+#endif
 #ifdef CASV_BEAM_PROF
 void beam_prof_dump(int steps);      // diagnostic build: phase times of the beam step kernel (beam_kernels.hip)
 #endif

@@ -129,7 +129,7 @@ struct casv_model {
     // options
     int eos = 1;                                          // vocabulary index of '\n' (seq2seq.py:1255,1344,1402)
     bool use_graph = false;
-    bool vendor_gemm = true;                              // train step: plain whole-sequence contractions through hipBLASLt where it loads (vendor_gemm.hip)
+    bool vendor_gemm = false;                             // calibration only: the train step's plain whole-sequence contractions through hipBLASLt (vendor_gemm.hip)
     bool fused_backward = true;                           // train step: cell backward fused into the step's data GEMM (gemm_bwd.hip)
     const int* skip_nact = nullptr;                       // beam decode: live rows per line, handed to the step's kernels when
     int skip_group = 0;                                   // skipping can pay (wide beams, or a line has finished); rows per line

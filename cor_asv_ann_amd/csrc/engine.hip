@@ -78,6 +78,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     for (auto& b : m->st_h) b.release();
     for (auto& b : m->st_c) b.release();
     (void)casv_train_release(m);
+    vendor_gemm_release(m->stream);
     (void)casv_comm_destroy(m);
     if (m->pin_active) { (void)hipHostFree(m->pin_active); for (int k = 0; k < 2; ++k) (void)hipEventDestroy(m->ev_active[k]); }
     if (m->step_exec) (void)hipGraphExecDestroy(m->step_exec);
@@ -995,6 +996,9 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     HIPCHK(hipMemsetAsync(m->bo_rej.p, 0xff, OR * S * 4, m->stream));
 #ifdef CASV_BEAM_PROF
     { HIPCHK(hipStreamSynchronize(m->stream)); casv::beam_prof_dump(m->S); }
+#endif
+#ifdef CASV_GEMM_PROF
+    { HIPCHK(hipStreamSynchronize(m->stream)); casv::gemm_prof_dump(); }
 #endif
     launch_beam_extract(s, p, o, m->stream);
     HIPCHK(hipGetLastError());

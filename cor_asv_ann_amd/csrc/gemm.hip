@@ -25,9 +25,35 @@ namespace casv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build (-DCASV_GEMM_PROF): thread 0 of every workgroup of the 128x128 LSTM kernel adds its shader-clock cycles
+// in prologue / steady-state loop / epilogue, the loop's tile count and its wall-clock ticks (10 ns) to g_gemm_prof;
+// gemm_prof_dump() prints and clears them (engine.hip calls it after a beamed decode).
+#ifdef CASV_GEMM_PROF
+__device__ unsigned long long g_gemm_prof[16 + 64];
+#define CASV_STAMP(x) { asm volatile("" ::: "memory"); x = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); }
+void gemm_prof_dump() {
+    unsigned long long h[16 + 64];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_prof), sizeof(h));
+    if (h[5]) {
+        fprintf(stderr, "gemm_prof workgroup cycles, histogram in bins of 16384:");
+        for (int i = 0; i < 64; ++i) if (h[16 + i]) fprintf(stderr, " %d:%llu", i, h[16 + i]);
+        fprintf(stderr, "\n");
+    }
+    if (h[5]) fprintf(stderr, "gemm_prof prologue parts: setup %.0f, cell-state addresses %.0f, tiles 0/1 requested %.0f, landed+stored+tiles 2/3 requested+frags %.0f | tail tiles %.0f, epilogue %.0f cyc\n",
+                      (double)h[8] / h[5], (double)h[9] / h[5], (double)h[10] / h[5], (double)h[11] / h[5], (double)h[12] / h[5], (double)h[13] / h[5]);
+    if (h[5])
+        fprintf(stderr, "gemm_prof: %llu workgroups: prologue %.0f cyc, loop %.1f cyc/tile over %.1f tiles, tail+epilogue %.0f cyc, "
+                "whole workgroup %.0f cyc, loop clock %.3f GHz\n", h[5], (double)h[0] / h[5], (double)h[1] / (double)h[2], (double)h[2] / h[5],
+                (double)h[3] / h[5], (double)h[6] / h[5], (double)h[1] / (double)h[4] * 0.1);
+    unsigned long long z[16 + 64] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
+}
+#endif
+
 constexpr int BM = 128, BN = 128, BK = 16, LDW = BK + 4;   // 80-B LDS rows: ds_read_b128 conflict-free
 constexpr int TILE_FLOATS = 128 * LDW;               // one operand tile
 constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;
+constexpr int CELL_LDS_BYTES = 128 * 128;            // LSTM epilogue: the tile's previous cell state, [half][row][16 floats]
 
 // Software pipeline (per wave, so that ONE wave keeps its SIMD's matrix pipe busy and the two waves
 // of a SIMD do not have to be out of phase to cover each other):
@@ -44,6 +70,10 @@ constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;
 // Tile (bm, bn) of job g by the calling workgroup; split-K part zidx of nsplit.
 template <int EPI, int KS>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const int bn, const int zidx, const int nsplit, float* smem_all) {
+#ifdef CASV_GEMM_PROF
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pt1 = pt0, pt2 = pt0, pr1 = 0, pr2 = 0, pa = pt0, pb = pt0, pc = pt0, pe = pt0; int ptiles = 0;
+#endif
     const int grp = KS > 1 ? (threadIdx.x >> 8) : 0;
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     float* smem = smem_all + grp * (2 * 2 * TILE_FLOATS);
@@ -63,17 +93,53 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 
     const int r0 = tid >> 2, kc = tid & 3;     // staging: rows r0, r0+64; floats [4kc, 4kc+4)
 
+    // Operand rows of the (up to three) K segments.  The row indices of every gathered segment -- and of the cell state, below --
+    // are requested TOGETHER and without branches (a segment without an index array reads a dummy word): one memory round trip
+    // for all of them instead of one per segment, each behind its own branch and full wait (round 4, in-kernel stamps: 7 800
+    // cycles of set-up in front of the first tile request).
     const float* ap0[2]; const float* ap1[2]; const float* ap2[2];
     int tiles0 = 0, tiles1 = 0, tiles2 = 0;
+    int mrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int m = m0 + r0 + 64 * i; mrow[i] = m < g.M ? m : g.M - 1; }
+    const int* const no_rows = reinterpret_cast<const int*>(g.Bt);          // any readable word
+    // (the segment descriptors as local copies, fetched from the kernel-argument segment in ONE batch of scalar loads: read
+    // field by field behind the short-circuit conditions below they were two dozen dependent scalar round trips)
+    const Seg sg0 = g.a[0], sg1 = g.a[1], sg2 = g.a[2], sgc = g.c_in;
+    const int nseg = g.nseg;
+    asm volatile("" :: "s"(sg0.base), "s"(sg0.rows), "s"(sg0.first_base), "s"(sg1.base), "s"(sg1.rows), "s"(sg1.first_base),
+                 "s"(sg2.base), "s"(sg2.rows), "s"(sg2.first_base), "s"(sgc.base), "s"(sgc.rows), "s"(sgc.first_base));
+    const Seg* const sgs[3] = {&sg0, &sg1, &sg2};
+    int ridx[3][2];
+    bool act[3], gat[3];
+#pragma unroll
+    for (int S = 0; S < 3; ++S) {
+        const Seg& sg = *sgs[S];
+        act[S] = nseg > S && !(sg.skip_first && step == 0 && !sg.first_base);
+        gat[S] = act[S] && sg.rows && !(sg.first_base && step == 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ridx[S][i] = *(gat[S] ? sg.rows + mrow[i] : no_rows);
+    }
+    const bool cell_lane = EPI == EPI_LSTM && grp == 0 && !g.epi_plain;
+    const bool cfirst = cell_lane && sgc.first_base && step == 0;
+    const bool czero = cell_lane && sgc.skip_first && step == 0 && !cfirst;
+    const bool cstage = cell_lane && !czero;
+    int crow[2] = {0, 0};
+    const float* cin = !cstage ? nullptr : cfirst ? sgc.first_base
+        : sgc.base + (long long)(step * sgc.step_mul + sgc.step_add) * sgc.slot_stride;
+    {
+        const bool cgat = cstage && sgc.rows && !cfirst;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int ci = *(cgat ? sgc.rows + mrow[i] : no_rows); crow[i] = cgat ? ci : mrow[i]; }
+    }
 #define CASV_SETUP_SEG(S, AP, TILES)                                                             \
-    if (g.nseg > S && !(g.a[S].skip_first && step == 0 && !g.a[S].first_base)) {                 \
-        const Seg& sg = g.a[S];                                                                  \
+    if (act[S]) {                                                                                \
+        const Seg& sg = *sgs[S];                                                                 \
         const bool first = sg.first_base && step == 0;                                           \
         const float* base = first ? sg.first_base                                                \
             : sg.base + (long long)(step * sg.step_mul + sg.step_add) * sg.slot_stride;          \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                          \
-            int m = m0 + r0 + 64 * i; m = m < g.M ? m : g.M - 1;                                 \
-            const int rid = (sg.rows && !first) ? sg.rows[m] : m;                                \
+            const int rid = gat[S] ? ridx[S][i] : mrow[i];                                       \
             AP[i] = base + (long long)rid * sg.ld + 4 * kc;                                      \
         }                                                                                        \
         TILES = sg.width / BK;                                                                   \
@@ -92,7 +158,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     const int nt_blk = ntiles_all - kt_begin < per ? (ntiles_all - kt_begin > 0 ? ntiles_all - kt_begin : 0) : per;
     // this wave group's share: tiles kt_begin + KS*i + grp
     const int ntiles = (nt_blk - grp + KS - 1) / KS, nt_min = nt_blk / KS, nt_max = (nt_blk + KS - 1) / KS;
-    const int koff0 = g.a[0].koff, koff1 = g.a[1].koff, koff2 = g.a[2].koff;
+    const int koff0 = sg0.koff, koff1 = sg1.koff, koff2 = sg2.koff;
 
     const float* bp[2];
 #pragma unroll
@@ -129,6 +195,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     // the prefetch was one tile deep for every second tile.  Issued from asm statements the loads are invisible to that
     // bookkeeping; CASV_TILE_FULL waits with a counted vmcnt(4) instead -- the four loads of the tile about to be stored
     // have landed, the four of the next tile stay in flight -- so every tile's operands have two tile times to arrive.
+    auto issue_tile_asm = [&](GTile& gt, const char* pa0, const char* pa1, const float* pb0, const float* pb1) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[0]) : "v"(pa0));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[1]) : "v"(pa1));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[0]) : "v"(pb0));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[1]) : "v"(pb1));
+    };
     auto load_tile_asm = [&](GTile& gt, int kt_rel) {
         const int kt = kt_rel * KS + grp + kt_begin;
         const long long m1 = (kt >= c0 && kt < c1) ? -1LL : 0LL, m2 = (kt >= c1) ? -1LL : 0LL;
@@ -136,11 +208,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * BK;
         const char* pa0 = (const char*)ap0[0] + (d1_0 & m1) + (d2_0 & m2) + (long long)ko * (BK * 4);
         const char* pa1 = (const char*)ap0[1] + (d1_1 & m1) + (d2_1 & m2) + (long long)ko * (BK * 4);
-        const float* pb0 = bp[0] + kb; const float* pb1 = bp[1] + kb;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[0]) : "v"(pa0));
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[1]) : "v"(pa1));
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[0]) : "v"(pb0));
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[1]) : "v"(pb1));
+        issue_tile_asm(gt, pa0, pa1, bp[0] + kb, bp[1] + kb);
     };
     auto store_tile = [&](const GTile& gt, int buf) {
         float* sa = smem + buf * 2 * TILE_FLOATS + r0 * LDW + 4 * kc;
@@ -176,26 +244,30 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j][i], f.b[c][j][i], acc[c], 0, 0, 0);
     };
 
-    // LSTM: previous cell state of this lane's 16 (row, unit) elements, fetched under the main loop
-    float cpv[16];
-    if (EPI == EPI_LSTM && grp == 0 && !g.epi_plain) {
-        const bool cfirst = g.c_in.first_base && step == 0;
-        const bool czero = g.c_in.skip_first && step == 0 && !cfirst;
-        const float* cin = cfirst ? g.c_in.first_base
-            : g.c_in.base + (long long)(step * g.c_in.step_mul + g.c_in.step_add) * g.c_in.slot_stride;
-        const int u = bn * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            m = m < g.M ? m : g.M - 1;
-            cpv[r] = 0.0f;
-            if (!czero) {
-                const int rid = (g.c_in.rows && !cfirst) ? g.c_in.rows[m] : m;
-                cpv[r] = cin[(long long)rid * g.c_in.ld + u];
-            }
-        }
-    }
-
+#ifdef CASV_GEMM_PROF
+    CASV_STAMP(pa)
+#endif
+    // LSTM: the previous cell state of the tile -- 128 rows x 32 units, 128 bytes per (gathered) row -- is fetched like an operand
+    // tile: every thread 16-byte pieces of its two staging rows (chunks kc and kc + 4), parked in registers under the K loop and
+    // turned into the accumulator layout through LDS behind it.  Round 4, in-kernel stamps of the c3 decode
+    // (profiles/r04_gemm_stamps.txt): as 16 dependent 4-byte gathers per lane in the prologue the cell state took 26 000 cycles
+    // (11 us) to land -- in front of the first MFMA, because no compiler-tracked load may be pending on a path into the loop --
+    // and 23 000 when requested behind the loop instead; 4-byte-per-lane accesses are what the memory pipeline is slowest at.
+    auto cptr = [&](int i) { return cin + (long long)crow[i] * sgc.ld + bn * 32 + 4 * kc; };
+    // cell-state area behind the tile buffers: [half j of the 128-byte row][row][16 floats], the image a wave's LDS-DMA writes
+    // (lane L -> 16 bytes at base + 16 L: rows wave * 16 + L / 4, chunk L % 4)
+    float* const cs = smem_all + KS * (2 * 2 * TILE_FLOATS);
+    auto cell_dma = [&](int i, int j) {
+        const float* src = cstage ? cptr(i) + 16 * j : bp[0];         // (no cell state: any valid address, the image is not read)
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(size_t)(__attribute__((address_space(3))) float*)cs + (unsigned)((j * 128 + 64 * i + (tid >> 6) * 16) * 64));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+#ifdef CASV_GEMM_PROF
+    CASV_STAMP(pb)
+#endif
     Frag f0, f1;
     GTile g0, g1;
     // prologue: LDS[0] <- tile 0, LDS[1] <- tile 1, F0 <- LDS[0]; G0 <- tile 2, G1 <- tile 3
@@ -204,6 +276,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         if (ntiles > 0) load_tile(g0, 0);
         if (ntiles > 1) load_tile(g1, 1);
     }
+#ifdef CASV_GEMM_PROF
+    CASV_STAMP(pc)
+#endif
     if (ntiles > 0) store_tile(g0, 0);
     if (ntiles > 1) store_tile(g1, 1);
 
@@ -212,22 +287,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     //   G <- global tile kt+4 ;  FN <- LDS[(kt+1)&1]
     // with the issue order pinned: one memory instruction + a few address ops behind each of the first MFMAs,
     // so a wave has no memory-only phase in which its SIMD partner's MFMA stream starves its instruction issue.
-#define CASV_TILE_FULL(FC, FN, G, KT)                                                     \
+#define CASV_TILE_FULL_X(FC, FN, G, KT, NMEM, EXTRA_LOADS)                                \
     {                                                                                     \
         asm volatile("s_waitcnt vmcnt(4)" : "+v"(G.a[0]), "+v"(G.a[1]), "+v"(G.b[0]), "+v"(G.b[1]));  \
         store_tile(G, (KT) & 1);                                                          \
         load_tile_asm(G, (KT) + 4);                                                       \
+        EXTRA_LOADS                                                                       \
         read_frags(FN, ((KT) + 1) & 1);                                                   \
         mma(FC);                                                                          \
-        _Pragma("unroll") for (int q_ = 0; q_ < 18; ++q_) {                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < NMEM; ++q_) {                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
             __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                            \
             __builtin_amdgcn_sched_group_barrier(0x320, 1, 0);                            \
         }                                                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 32 - NMEM, 0);                        \
         __builtin_amdgcn_sched_barrier(0);   /* keep all 32 MFMAs in front of the barrier: by then the LDS ops have landed */ \
         __syncthreads();                                                                  \
     }
+#define CASV_TILE_FULL(FC, FN, G, KT) CASV_TILE_FULL_X(FC, FN, G, KT, 18, )
 #define CASV_TILE_STEP(FC, FN, G, KT)                                                     \
     {                                                                                     \
         if ((KT) + 2 < ntiles) store_tile(G, (KT) & 1);                                   \
@@ -237,29 +314,76 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         __syncthreads();                                                                  \
     }
     int kt = 0;
+    // (hidden transfers in flight across the tail below are older than anything the tail requests itself -- an odd tile count
+    // requests one more tile there --, so the compiler's counted waits for its own loads stay correct: they only wait longer)
+    const bool c_late = EPI == EPI_LSTM && KS == 1 && nt_min > 5;
     if (nt_min > 5) {
         // Tiles 2 and 3 are requested the hidden way already: a compiler-tracked load pending on ANY path into the loop would
         // put a full vmcnt(0) at the loop head, executed in every iteration.  (The cell-state loads above are older than
         // every tile load, so the counted waits cover them too.)
-        load_tile_asm(g0, 2); load_tile_asm(g1, 3);
+        // (c0 >= 4: tiles 2 and 3 lie in the layer input too -- their addresses do not wait for the gathered segments' row indices)
+        {
+            const char *qa0, *qa1, *ra0, *ra1; const float *qb0, *qb1, *rb0, *rb1;
+            if (kt_begin == 0 && c0 >= 4) {
+                qa0 = (const char*)(ap0[0] + 2 * BK); qa1 = (const char*)(ap0[1] + 2 * BK); qb0 = bp[0] + koff0 + 2 * BK; qb1 = bp[1] + koff0 + 2 * BK;
+                ra0 = (const char*)(ap0[0] + 3 * BK); ra1 = (const char*)(ap0[1] + 3 * BK); rb0 = bp[0] + koff0 + 3 * BK; rb1 = bp[1] + koff0 + 3 * BK;
+                asm volatile("" : "+v"(qa0), "+v"(ra0));           // (keeps the two paths apart: a select would wait for the indices)
+            } else {
+                auto addr = [&](int kt_rel, const char*& pa0, const char*& pa1, const float*& pb0, const float*& pb1) {
+                    const int ktt = kt_rel * KS + grp + kt_begin;
+                    const long long m1 = (ktt >= c0 && ktt < c1) ? -1LL : 0LL, m2 = (ktt >= c1) ? -1LL : 0LL;
+                    const int ko = ktt - ((int)m1 & c0) - ((int)m2 & c1);
+                    const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * BK;
+                    pa0 = (const char*)ap0[0] + (d1_0 & m1) + (d2_0 & m2) + (long long)ko * (BK * 4);
+                    pa1 = (const char*)ap0[1] + (d1_1 & m1) + (d2_1 & m2) + (long long)ko * (BK * 4);
+                    pb0 = bp[0] + kb; pb1 = bp[1] + kb;
+                };
+                addr(2, qa0, qa1, qb0, qb1); addr(3, ra0, ra1, rb0, rb1);
+            }
+            issue_tile_asm(g0, qa0, qa1, qb0, qb1); issue_tile_asm(g1, ra0, ra1, rb0, rb1);
+        }
         __syncthreads();
         read_frags(f0, 0);
         // The first steady-state step stores tile 2 into LDS buffer 0: every wave must have taken its fragments of tile 0
         // out of it first.  (Without this barrier only the latency of the tile-2 global loads kept a fast wave's store
         // behind a slow wave's read -- not enough once other kernels share the CU.)
         __syncthreads();
+#ifdef CASV_GEMM_PROF
+        pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (; kt + 5 < nt_min; kt += 2) {          // both wave groups have all the tiles of the steady state
             CASV_TILE_FULL(f0, f1, g0, kt)
             CASV_TILE_FULL(f1, f0, g1, kt + 1)
         }
-        // loads issued by the asm statements are still in flight: they land before the compiler-scheduled rest touches them
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0.a[0]), "+v"(g0.a[1]), "+v"(g0.b[0]), "+v"(g0.b[1]), "+v"(g1.a[0]), "+v"(g1.a[1]), "+v"(g1.b[0]), "+v"(g1.b[1]));
+#ifdef CASV_GEMM_PROF
+        pt2 = __builtin_amdgcn_s_memtime(); pr2 = __builtin_amdgcn_s_memrealtime(); ptiles = kt;
+#endif
+        // The cell state is requested behind the LAST tile loads, as LDS-DMA (no registers are held for it; hidden from the
+        // compiler's wait bookkeeping like the tile loads): nothing is queued behind it that a counted wait looks at, so however
+        // long the gathered rows take (rows of parents from many steps ago: HBM and page-table walks), no operand tile waits for
+        // them; they land under the tail tiles.  The tile loads themselves land before the compiler-scheduled rest touches them.
+        // (Every steady-state path of the LSTM kernel issues the four transfers -- jobs without a cell state from a valid dummy
+        // address -- so that ONE wait statement with ONE count follows the loop: two statements on two paths would meet in copies of
+        // registers whose loads are still in flight, csrc/check_asm_loads.py.)
+        if (EPI == EPI_LSTM && KS == 1) {
+            cell_dma(0, 0); cell_dma(0, 1); cell_dma(1, 0); cell_dma(1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(g0.a[0]), "+v"(g0.a[1]), "+v"(g0.b[0]), "+v"(g0.b[1]), "+v"(g1.a[0]), "+v"(g1.a[1]), "+v"(g1.b[0]), "+v"(g1.b[1]));
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0.a[0]), "+v"(g0.a[1]), "+v"(g0.b[0]), "+v"(g0.b[1]), "+v"(g1.a[0]), "+v"(g1.a[1]), "+v"(g1.b[0]), "+v"(g1.b[1]));
+        }
     } else {
         if (ntiles > 2) load_tile(g0, 2);
         if (ntiles > 3) load_tile(g1, 3);
         __syncthreads();
         if (ntiles > 0) read_frags(f0, 0);
         __syncthreads();
+    }
+    if (cstage && !c_late) {        // (short K, odd tile counts, wave-group split-K: through registers, stored into the same image)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<f32x4*>(cs + (j * 128 + r0 + 64 * i) * 16 + 4 * kc) = *reinterpret_cast<const f32x4*>(cptr(i) + 16 * j);
     }
     for (; kt + 1 < nt_max; kt += 2) {          // same barrier count for both groups
         CASV_TILE_STEP(f0, f1, g0, kt)
@@ -269,6 +393,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 #undef CASV_TILE_STEP
 #undef CASV_TILE_FULL
 
+#ifdef CASV_GEMM_PROF
+    pe = __builtin_amdgcn_s_memtime();
+#endif
     if (KS > 1) {       // acc(group 0) += acc(group 1), through LDS (all staging reads are behind the last barrier)
         float* red = smem_all + tid;
         if (grp == 1) {
@@ -285,9 +412,35 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
             for (int r = 0; r < 16; ++r) acc[c][r] += red[(c * 16 + r) * 256];
     }
 
+    // the cell state in the accumulator layout, out of its LDS image (every wave waits for its own transfers first -- also where
+    // the image is not read: an LDS-DMA must not outlive the workgroup whose LDS it writes)
+    if (c_late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float cpv[16];
+    float bi = 0.f, bf_ = 0.f, bg = 0.f, bo = 0.f;       // LSTM: gate biases of this lane's unit (ONE branch; they arrive under the barrier)
+    if (EPI == EPI_LSTM) {          // (uniform over the workgroup's remaining waves: group 1 of a KS = 2 launch has returned)
+        if (!g.epi_plain) {
+            if (g.bias) { bi = g.bias[n0 + l31]; bf_ = g.bias[n0 + 32 + l31]; bg = g.bias[n0 + 64 + l31]; bo = g.bias[n0 + 96 + l31]; }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                cpv[r] = czero ? 0.0f : cs[((l31 >> 4) * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 16 + (l31 & 15)];
+        }
+    }
+
     // ---- epilogue ----
     if (EPI == EPI_PLAIN || g.epi_plain) {
         float* cbase = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
+        if (nsplit == 1 && !g.accumulate && m0 + BM <= g.M && n0 + BN <= g.N) {
+            // full tile, plain stores: no control flow between the 64 stores (a branch per element makes the compiler wait for the
+            // element before -- see the LSTM epilogue below)
+            float* cb = cbase + (long long)(m0 + wave * 32 + 4 * lh) * g.out.ld + n0 + l31;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float b = g.bias ? g.bias[n0 + c * 32 + l31] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cb[(long long)((r & 3) + 8 * (r >> 2)) * g.out.ld + c * 32] = acc[c][r] + b;
+            }
+        } else
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int n = n0 + c * 32 + l31;
@@ -306,8 +459,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         }
     } else {
         const int u = bn * 32 + l31;     // hidden unit of this lane
-        const float bi = g.bias ? g.bias[n0 + l31] : 0.f, bf_ = g.bias ? g.bias[n0 + 32 + l31] : 0.f;
-        const float bg = g.bias ? g.bias[n0 + 64 + l31] : 0.f, bo = g.bias ? g.bias[n0 + 96 + l31] : 0.f;
         const float* zin = g.zinit.base
             ? g.zinit.base + (long long)(step * g.zinit.step_mul + g.zinit.step_add) * g.zinit.slot_stride : nullptr;
         float* cout = g.c_out.base + (long long)(step * g.c_out.step_mul + g.c_out.step_add) * g.c_out.slot_stride;
@@ -324,23 +475,55 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
                 acc[0][r] += zr[0]; acc[1][r] += zr[32]; acc[2][r] += zr[64]; acc[3][r] += zr[96];
             }
         }
+        if (m0 + BM <= g.M && !hout2 && !gout) {
+            // Full tile, inference outputs only: all cells first, then all stores, no control flow in between.  (With a branch per
+            // row the compiler's wait bookkeeping put an s_waitcnt vmcnt(0) in front of every row's cell -- stores count in
+            // vmcnt too, so each of the 16 rows waited for the stores of the row before: 16 serial store round trips, 44 000 cycles
+            // of epilogue in the c3 decode where the arithmetic needs 7 000.)
+            float hv[16], cv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m < g.M) {
-                const float cprev = cpv[r];
-                float zi = acc[0][r] + bi, zf = acc[1][r] + bf_, zg = acc[2][r] + bg, zo = acc[3][r] + bo;
-                const LstmCellOut cell = lstm_cell(zi, zf, zg, zo, cprev);
-                cout[(long long)m * g.c_out.ld + u] = cell.c;
-                hout[(long long)m * g.out.ld + u] = cell.h;
-                if (hout2) hout2[(long long)m * g.out2.ld + u] = cell.h;
-                if (gout) {
-                    float* gr = gout + (long long)m * g.gates_out.ld + n0 + l31;
-                    gr[0] = cell.i; gr[32] = cell.f; gr[64] = cell.g; gr[96] = cell.o;
+            for (int r = 0; r < 16; ++r) {
+                const LstmCellOut cell = lstm_cell(acc[0][r] + bi, acc[1][r] + bf_, acc[2][r] + bg, acc[3][r] + bo, cpv[r]);
+                hv[r] = cell.h; cv[r] = cell.c;
+            }
+            float* cb = cout + (long long)(m0 + wave * 32 + 4 * lh) * g.c_out.ld + u;
+            float* hb = hout + (long long)(m0 + wave * 32 + 4 * lh) * g.out.ld + u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = (r & 3) + 8 * (r >> 2);
+                cb[(long long)dm * g.c_out.ld] = cv[r];
+                hb[(long long)dm * g.out.ld] = hv[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < g.M) {
+                    const float cprev = cpv[r];
+                    float zi = acc[0][r] + bi, zf = acc[1][r] + bf_, zg = acc[2][r] + bg, zo = acc[3][r] + bo;
+                    const LstmCellOut cell = lstm_cell(zi, zf, zg, zo, cprev);
+                    cout[(long long)m * g.c_out.ld + u] = cell.c;
+                    hout[(long long)m * g.out.ld + u] = cell.h;
+                    if (hout2) hout2[(long long)m * g.out2.ld + u] = cell.h;
+                    if (gout) {
+                        float* gr = gout + (long long)m * g.gates_out.ld + n0 + l31;
+                        gr[0] = cell.i; gr[32] = cell.f; gr[64] = cell.g; gr[96] = cell.o;
+                    }
                 }
             }
         }
     }
+#ifdef CASV_GEMM_PROF
+    if (EPI == EPI_LSTM && KS == 1 && threadIdx.x == 0 && ptiles > 0) {
+        const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_gemm_prof[0], pt1 - pt0); atomicAdd(&g_gemm_prof[1], pt2 - pt1); atomicAdd(&g_gemm_prof[2], (unsigned long long)ptiles);
+        atomicAdd(&g_gemm_prof[3], pt3 - pt2); atomicAdd(&g_gemm_prof[4], pr2 - pr1); atomicAdd(&g_gemm_prof[5], 1ull);
+        atomicAdd(&g_gemm_prof[6], pt3 - pt0);
+        { unsigned long long bin = (pt3 - pt0) >> 14; atomicAdd(&g_gemm_prof[16 + (bin < 63 ? bin : 63)], 1ull); }
+        atomicAdd(&g_gemm_prof[8], pa - pt0); atomicAdd(&g_gemm_prof[9], pb - pa); atomicAdd(&g_gemm_prof[10], pc - pb); atomicAdd(&g_gemm_prof[11], pt1 - pc);
+        atomicAdd(&g_gemm_prof[12], pe - pt2); atomicAdd(&g_gemm_prof[13], pt3 - pe);
+    }
+#endif
 }
 
 template <int EPI, int KS>
@@ -371,10 +554,11 @@ static void launch_one(const GemmBatch& bb, int blocks, int ksplit, hipStream_t 
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GEMM_LDS_BYTES * KS);
+                                  GEMM_LDS_BYTES * KS + (EPI == EPI_LSTM ? CELL_LDS_BYTES : 0));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<EPI, KS>), dim3(blocks, bb.count, ksplit), dim3(256 * KS), GEMM_LDS_BYTES * KS, stream, bb);
+    hipLaunchKernelGGL((gemm_kernel<EPI, KS>), dim3(blocks, bb.count, ksplit), dim3(256 * KS),
+                       GEMM_LDS_BYTES * KS + (EPI == EPI_LSTM ? CELL_LDS_BYTES : 0), stream, bb);
 }
 
 static int g_tile_mode = -1;       // -1 by size, 0 = 128x128, 1 = 32x128

@@ -295,6 +295,22 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { z[q][0] += zpre[rb][q][0]; z[q][1] += zpre[rb][q][1]; z[q][2] += zpre[rb][q][2]; z[q][3] += zpre[rb][q][3]; }
             }
+            if (m0 + 32 * RB <= g.M && !hout2 && !gout) {
+                // full tile, inference outputs only: the four cells first, then the eight stores, no control flow in between (a branch
+                // per row makes the compiler wait for the stores of the row before: gemm.hip's epilogue, round 4)
+                float hv[4], cv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const LstmCellOut cell = lstm_cell(z[q][0] + bi, z[q][1] + bf_, z[q][2] + bg, z[q][3] + bo, cpv[rb][q]);
+                    hv[q] = cell.h; cv[q] = cell.c;
+                }
+                const long long mb = m0 + 32 * rb + 8 * wave + 4 * lh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cout[(mb + q) * g.c_out.ld + u] = cv[q];
+                    hout[(mb + q) * g.out.ld + u] = hv[q];
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = m0 + 32 * rb + q + 8 * wave + 4 * lh;

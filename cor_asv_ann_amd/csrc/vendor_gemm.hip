@@ -1,8 +1,12 @@
-// Optional vendor path for the train step's PLAIN whole-sequence contractions C[M][N] (+)= A[M][K] . Bt[N][K]^T (+ bias): the
-// input projections of all time steps and their data gradients -- nothing fused, ~2.2 TFLOP per train step.  hipBLASLt is loaded
-// at run time (dlopen: the library does not depend on it); a shape the heuristic has no solution for, a missing library or
-// CASV_VENDOR_GEMM=0 fall back to gemm.hip.  Host code only.
+// CALIBRATION path (off by default, option "vendor_gemm" = 1): the train step's PLAIN whole-sequence contractions
+// C[M][N] (+)= A[M][K] . Bt[N][K]^T (+ bias) -- the input projections of all time steps and their data gradients, nothing fused,
+// ~2.2 TFLOP per train step -- through hipBLASLt, so that this library's own kernel can be timed against the vendor's on the same
+// step.  hipBLASLt is loaded at run time (dlopen: no link-time dependency; its header is needed at build time only -- without it
+// this file compiles to a stub that takes no contraction); a shape the heuristic has no solution for, a missing library or
+// CASV_VENDOR_GEMM=0 fall back to gemm.hip.  One workspace per (device, stream): two models training on one GPU never share one.
+// Host code only.
 #include "common.h"
+#if __has_include(<hipblaslt/hipblaslt.h>)
 #include <dlfcn.h>
 #include <hipblaslt/hipblaslt.h>
 #include <map>
@@ -28,8 +32,8 @@ struct Api {
                               hipblasLtMatrixLayout_t, const void*, const void*, hipblasLtMatrixLayout_t, void*, hipblasLtMatrixLayout_t,
                               const hipblasLtMatmulAlgo_t*, void*, size_t, hipStream_t) = nullptr;
     hipblasLtHandle_t handle = nullptr;
-    void* workspace = nullptr;
     size_t workspace_bytes = 0;
+    std::map<hipStream_t, void*> workspace;               // per stream: solutions with a split K keep partial sums there
     bool ok = false;
 };
 
@@ -65,11 +69,23 @@ Api& api_for(int dev) {
 #undef CASV_SYM
     if (a.Create(&a.handle) != HIPBLAS_STATUS_SUCCESS) return a;
     a.workspace_bytes = 64u << 20;
-    if (hipMalloc(&a.workspace, a.workspace_bytes) != hipSuccess) { a.workspace = nullptr; a.workspace_bytes = 0; }
     a.ok = true;
     return a;
 }
 }  // namespace
+
+// the model that owned `stream` is being destroyed: its workspace goes with it
+void vendor_gemm_release(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_api.find(dev);
+    if (it == g_api.end()) return;
+    auto ws = it->second.workspace.find(stream);
+    if (ws == it->second.workspace.end()) return;
+    (void)hipFree(ws->second);
+    it->second.workspace.erase(ws);
+}
 
 // true = the contraction was enqueued on `stream`; false = not taken (the caller runs its own kernel)
 bool vendor_gemm_nt(const float* A, long long lda, long long M, int K, const float* Bt, int N, const float* bias, float* C, long long ldc,
@@ -79,6 +95,12 @@ bool vendor_gemm_nt(const float* A, long long lda, long long M, int K, const flo
     std::lock_guard<std::mutex> lock(g_mu);
     Api& a = api_for(dev);
     if (!a.ok) return false;
+    auto ws = a.workspace.find(stream);
+    if (ws == a.workspace.end()) {
+        void* w = nullptr;
+        if (hipMalloc(&w, a.workspace_bytes) != hipSuccess) return false;
+        ws = a.workspace.emplace(stream, w).first;
+    }
     const Key key{dev, M, N, K, lda, ldc, (long long)K, bias != nullptr, accumulate};
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
@@ -118,8 +140,14 @@ bool vendor_gemm_nt(const float* A, long long lda, long long M, int K, const flo
         if (a.MatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)) != HIPBLAS_STATUS_SUCCESS) return false;
     }
     const float alpha = 1.0f, beta = accumulate ? 1.0f : 0.0f;
-    return a.Matmul(a.handle, p.desc, &alpha, Bt, p.la, A, p.lb, &beta, C, p.lc, C, p.lc, &p.algo, a.workspace, a.workspace_bytes, stream) ==
+    return a.Matmul(a.handle, p.desc, &alpha, Bt, p.la, A, p.lb, &beta, C, p.lc, C, p.lc, &p.algo, ws->second, a.workspace_bytes, stream) ==
            HIPBLAS_STATUS_SUCCESS;
 }
 
 }  // namespace casv
+#else
+namespace casv {
+void vendor_gemm_release(hipStream_t) {}
+bool vendor_gemm_nt(const float*, long long, long long, int, const float*, int, const float*, float*, long long, int, hipStream_t) { return false; }
+}  // namespace casv
+#endif

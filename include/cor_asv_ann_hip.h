@@ -228,8 +228,9 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
  * with per-step launches);
  * "fused_backward" = 1 (default): a backward time step without a persistent form is ONE launch (cell backward inside the data
  * GEMM), 0: two;
- * "vendor_gemm" = 1 (default): the train step's plain whole-sequence contractions (input projections, their data gradients) go
- * through hipBLASLt where it can be loaded at run time, 0: through this library's own kernel (always the case for inference);
+ * "vendor_gemm" = 0 (default): every contraction runs in this library's own kernels; 1 = calibration: the train step's plain
+ * whole-sequence contractions (input projections, their data gradients) go through hipBLASLt where it can be loaded at run time
+ * (bench.py reports that time beside the own-kernel figure; inference never uses it);
  * "eos" = vocabulary index of the end-of-line character '\n' (default 1: '' and '\n' sort first, seq2seq.py:580);
  * "tile" (process-wide; alias "skinny") = tile shape of the GEMM launches: -1 by size (default), 0 always 128x128,
  * 1 always 32x128, 2 = 64x128 wherever there is no split-K -- a measurement/test switch, the values computed are the same bit

@@ -332,6 +332,36 @@ def test_c3_full_size_properties():
     eng.close()
 
 
+def test_c3_short_lines_equal_the_oracle(golden_dir):
+    """BASELINE configs[2]'s model and batch (depth 4, width 512, V 256, 1024 lines, N = 8, the bench's peaky weights) on
+    20-character lines, where the oracle's fp32 and fp64 searches agree on every line (tests/golden/make_c3_golden.py prints
+    that check): all 1024 lines end to end against the committed oracle fixture -- strings, lengths, numbers of finished
+    hypotheses and of search iterations exactly, line scores to 1e-4, character probabilities to rtol 2e-4
+    (seq2seq.py:1356-1544)."""
+    with np.load(os.path.join(golden_dir, 'c3_beam_short.npz')) as f:
+        g = {k: f[k] for k in f.files}
+    d, W, V, B, L, N, es, _ = (int(x) for x in g['meta'])
+    assert (d, W, V, B, N) == (4, 512, 256, 1024, 8)
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    weights = make_weights(cfg, emb_scale=float(es))
+    eng = _engine(cfg, weights)
+    eng.encode(g['idx'])
+    res = eng.decode_beam(batch_size=N)
+    i_c = OracleModel(cfg, weights).mapping[1]
+    assert np.array_equal(res['n_found'], g['beam_found'])
+    assert np.array_equal(res['n_steps'], g['beam_steps'])
+    bad = []
+    for j in range(B):
+        n = int(res['len'][j])
+        text = ''.join(i_c[int(c)] for c in res['idx'][j, :n])
+        if text != str(g['beam_text'][j]) or abs(res['score'][j] - g['beam_score'][j]) >= 1e-4 or \
+                not np.allclose(res['prob'][j, :n], g['beam_probs'][j, :n], rtol=RT, atol=AT):
+            bad.append(j)
+    assert not bad, 'lines that differ from the oracle fixture: %s' % bad[:20]
+    assert int((g['beam_found'] > 0).sum()) >= 50          # the fixture is not degenerate: searches do finish
+    eng.close()
+
+
 def test_model_loaded_from_the_reference_container(golden_dir, tmp_path):
     """A Keras-2.3 HDF5 model file (written by libhdf5, tests/golden/make_keras_h5.py) loads through
     load_config / configure / load_weights (scripts/proc.py:52-55) and decodes like the oracle with the same

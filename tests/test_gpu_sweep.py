@@ -20,7 +20,7 @@ def test_random_beam_configurations(seed, ncase, tile):
     kernels see the odd shapes of the sweep."""
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
     rng = np.random.default_rng(seed)
-    bad, total = [], 0
+    bad, total, excluded, skipped_cases = [], 0, 0, 0
     for case in range(ncase):
         d = int(rng.integers(1, 4)); W = int(rng.choice([32, 64, 96])); V = int(rng.choice([24, 64, 100, 257]))
         B = int(rng.integers(1, 7)); L = int(rng.integers(3, 20)); es = float(rng.choice([2., 6., 10., 14., 20.]))
@@ -42,6 +42,7 @@ def test_random_beam_configurations(seed, ncase, tile):
             except (IndexError, ValueError):      # the reference raises here; nothing to compare
                 res[dt] = None
         if res[np.float32] is None:
+            skipped_cases += 1
             continue
         w32 = make_weights(cfg, seed=wseed, emb_scale=es)
         s2s = Sequence2Sequence()
@@ -60,10 +61,15 @@ def test_random_beam_configurations(seed, ncase, tile):
             total += 1
             ok = got[0][j] == want[0][j] and abs(got[2][j] - want[2][j]) < 1e-4
             conditioned = res[np.float64] is not None and res[np.float64][0][j] == want[0][j]
+            excluded += not conditioned
             if not ok and conditioned:
                 bad.append((case, j, dict(d=d, W=W, V=V, B=B, L=L, es=es, seed=wseed, **kw)))
         s2s.engine.close()
+    # lines on which the oracle's own fp32 and fp64 searches disagree pin nothing: say how many there were and bound them
+    print('sweep seed %d: %d lines compared, %d of them excluded as ill-conditioned (oracle fp32 != fp64), %d cases skipped '
+          '(the reference raises)' % (seed, total, excluded, skipped_cases))
     assert total > 50 and not bad, bad
+    assert excluded <= 0.10 * total, 'too many lines excluded for fp32/fp64 disagreement: %d of %d' % (excluded, total)
 
 
 def test_random_train_steps():
