@@ -120,6 +120,21 @@ def survey_flop_per_char(d=DEPTH, W=WIDTH, N=BEAM_N, V=VOC, L=LENGTH):
     return (f_enc + N * 2 * T * f_row) / float(L)
 
 
+def executed_flop_per_char(d=DEPTH, W=WIDTH, N=BEAM_N, V=VOC, L=LENGTH):
+    """What the kernels execute per corrected character: as survey_flop_per_char, except that decoder layer 1 contracts the
+    fed-back distribution with the folded E.K (K = Vp + W instead of an embedding GEMV plus K = 2W)."""
+    K, T = 11, L + 1
+    C = 2 * W if d == 1 else W
+    Vp = -(-V // 32) * 32
+    if d == 1:
+        lstm = 8 * W * (Vp + C + W)
+    else:
+        lstm = 8 * W * (Vp + W) + (d - 2) * 16 * W * W + 8 * W * (2 * W + C)
+    f_row = lstm + 2 * W * W + K * (4 * W + 2 * C) + 2 * W * V
+    f_enc = T * (32 * W * W + (24 * W * W if d >= 2 else 0) + 16 * W * W * max(d - 2, 0) + 2 * C * W)
+    return (f_enc + N * 2 * T * f_row) / float(L)
+
+
 def survey_hbm_bytes_per_char(d=DEPTH, W=WIDTH, N=BEAM_N, V=VOC, L=LENGTH):
     """Q = Q_enc + N*S*Q_row per line (per-beam state in HBM, weights on chip), per corrected character."""
     K, T = 11, L + 1
@@ -137,7 +152,7 @@ def host_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(cfg, weights, lines, batch_size, fast, length=LENGTH, budget_s=22.0, repeats=5):
+def cpu_baseline(cfg, weights, lines, batch_size, fast, length=LENGTH, budget_s=22.0, repeats=5, min_lines=4):
     """The oracle in the reference's dataflow (per-character decoder call, dense-T attention, u recomputed
     every step, per-line best-first search / batched greedy loop) on the host cores: best of `repeats`
     samples of the same workload, each sized to a share of the time budget."""
@@ -149,6 +164,9 @@ def cpu_baseline(cfg, weights, lines, batch_size, fast, length=LENGTH, budget_s=
     correct_lines(om, lines[:n0], **kw)                      # warm-up (BLAS threads, page-in); also sizes the sample
     per_line = (time.perf_counter() - t0) / n0
     n = int(max(n0, min(len(lines), (budget_s / repeats) / max(per_line, 1e-6))))
+    if n < min_lines:                   # a sample of at least `min_lines` lines (a one- or two-line sample is noisy), fewer runs
+        n = min(min_lines, len(lines))
+        repeats = int(max(2, min(repeats, budget_s / max(n * per_line, 1e-6))))
     best = None
     for _ in range(repeats):
         t0 = time.perf_counter()
@@ -239,6 +257,22 @@ def train_bench(args):
     pl, pg, ps = eng.profile_read('lstm_gemm'), eng.profile_read('gemm'), eng.profile_read('lstm_gemm_small')
     pp = eng.profile_read('persist')
     eng.profile(False)
+    # calibration, outside the timed region: the same step with the plain whole-sequence contractions handed to the vendor's
+    # library (hipBLASLt, option "vendor_gemm"; never the default, never in `value`)
+    vendor_default = int(os.environ.get('CASV_OPT_VENDOR_GEMM', '0'))
+    calibration = None
+    if facade is None and not vendor_default:
+        eng.set_option('vendor_gemm', 1)
+        for _ in range(2):
+            one_step()
+        eng.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        eng.synchronize()
+        calibration = {'vendor_gemm_ms_per_step': 1e3 * (time.perf_counter() - t1) / args.steps,
+                       'note': 'plain whole-sequence contractions through hipBLASLt instead of csrc/gemm.hip; everything else unchanged'}
+        eng.set_option('vendor_gemm', 0)
     fl, ms = pl['flops'] + pg['flops'] + ps['flops'] + pp['flops'], pl['ms'] + pg['ms'] + ps['ms'] + pp['ms']
     emit(json.dumps({
         'metric': 'trained chars/sec (1 GPU), depth-4 width-512 teacher-forced train step, 100-char lines',
@@ -247,7 +281,9 @@ def train_bench(args):
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[3]: depth=4 width=512 V=256 train step, batch 512 x 100 chars, dropout 0.2, Adam(clipnorm 5)',
                    'batches': 'read from a TSV file and vectorised by the worker thread of train() (training.prefetch)' if args.facade
-                              else 'one synthetic batch, resident on the host', 'last_loss': loss, 'last_grad_norm': norm},
+                              else 'one synthetic batch, resident on the host', 'last_loss': loss, 'last_grad_norm': norm,
+                   'vendor_gemm': vendor_default},
+        'calibration': calibration,
         'roofline': {'bound': 'mfma', 'kernel': 'all GEMMs of the step (incl. the persistent recurrences: %.1f ms in %d launches)' % (pp['ms'] / max(args.steps, 1), pp['launches'] // max(args.steps, 1)), 'achieved': fl / max(ms, 1e-9) / 1e9,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / max(ms, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS,
                      'traffic': None, 'launches': pl['launches'] + pg['launches'] + ps['launches'] + pp['launches'],
@@ -508,6 +544,7 @@ def decode_bench(args):
         chars = len(all_lines) * L * args.steps
         fpc = survey_flop_per_char(wl['depth'], wl['width'], wl['n'], V, L)
         qpc = survey_hbm_bytes_per_char(wl['depth'], wl['width'], wl['n'], V, L)
+        xpc = executed_flop_per_char(wl['depth'], wl['width'], wl['n'], V, L)
         result = {
             'metric': METRIC if args.workload in ('c3', 'c5') else
                       ('corrected chars/sec (1 GPU) greedy, depth-2 width-256, 100-char lines' if args.workload == 'c2' else
@@ -557,13 +594,17 @@ def decode_bench(args):
                 'whole_path': {'flop_per_char': fpc,
                                'achieved': chars / elapsed * fpc / 1e12 / world,
                                'frac': chars / elapsed * fpc / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
+                               # ... and with the FLOP the kernels execute (embedding folded into decoder layer 1: fewer)
+                               'flop_per_char_executed': xpc,
+                               'frac_executed': chars / elapsed * xpc / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
                                # the other roofline of SURVEY 8(d): not the binding one at fp32
                                'hbm_bytes_per_char': qpc,
                                'hbm_frac': chars / elapsed * qpc / world / PEAK_HBM_BYTES_PER_S}}
         if others:
             result['kernel_ms_per_step'] = {k: v['ms'] for k, v in others.items()}     # from one extra untimed step
         if world == 1 and not args.no_cpu_baseline and not dry and not wl.get('confmat'):
-            result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64], wl['n'] if not wl['fast'] else 256, wl['fast'], L)
+            result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64], wl['n'] if not wl['fast'] else 256, wl['fast'], L,
+                                                  budget_s=args.cpu_budget)
     if comm:
         comm.close()
     elif dist_on:
@@ -574,19 +615,20 @@ def decode_bench(args):
         s2s.engine = None
     if rank == 0:
         if world == 1 and not dist_on and args.workload == 'c3' and not args.no_others and not dry:
-            result['other_workloads'] = other_workloads()
+            result['other_workloads'] = other_workloads(not args.no_cpu_baseline)
         emit(json.dumps(result))
     return 0
 
 
-def other_workloads():
+def other_workloads(with_cpu_baseline=True):
     """The other single-GPU workloads, each as a child process of this (finished) run so that the driver's one default
     invocation times them too: configs[1] (c2), configs[3] (c4) and the OCR-D processor's call (page).  Bounded: a few
     steps each, no CPU baseline; a workload that fails reports its error instead of failing the headline."""
     out = {}
     for name, extra in (('c2', ['--steps', '20', '--warmup', '3']), ('c4', ['--steps', '5', '--warmup', '2']),
                         ('page', ['--steps', '3', '--warmup', '1'])):
-        cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--no-cpu-baseline', '--no-others'] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--no-others'] + extra
+        cmd += ['--cpu-budget', '8'] if name == 'c2' and with_cpu_baseline else ['--no-cpu-baseline']
         env = {k: v for k, v in os.environ.items() if not k.startswith('CASV_BENCH_')}
         try:
             t0 = time.perf_counter()
@@ -603,9 +645,11 @@ def other_workloads():
                                     if k in r['roofline']}
                 if 'whole_path' in r['roofline']:
                     keep['roofline']['whole_path_frac'] = r['roofline']['whole_path']['frac']
-            for k in ('kernel_ms_per_step', 'realign_ms_per_step'):
+            for k in ('kernel_ms_per_step', 'realign_ms_per_step', 'cpu_baseline', 'calibration'):
                 if k in r:
                     keep[k] = r[k]
+            if name == 'c4':
+                keep['vendor_gemm'] = r['config'].get('vendor_gemm')
             keep['wall_s'] = time.perf_counter() - t0
             out[name] = keep
         except Exception as err:            # a measurement aid must not take the headline down
@@ -642,6 +686,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=22.0, help='seconds of host time for the cpu_baseline sample')
     ap.add_argument('--no-others', action='store_true', help='do not time c2 / c4 / page after the default c3 run')
     ap.add_argument('--pipeline', type=int, default=1, help='1 GPU: 1 = the steps run through correct_batches (vectorising, device and '
                     'string building of neighbouring steps overlap, as in predict()), 0 = one correct_lines call after the other')

@@ -242,3 +242,42 @@ def test_multi_gpu_launch_defaults_to_the_configs4_shape():
     out = lines[0]
     assert out['config']['lines_per_gpu'] == 8192 and out['gathered_records'] == 16384 and 'configs[4]' in out['config']['workload']
     assert out['config']['lines_per_decode_call'] == 1024
+
+
+def test_eight_ranks_of_configs4_rehearsed_without_a_device(tmp_path):
+    """BASELINE configs[4] with all EIGHT ranks on this host, dry (CASV_BENCH_DRY_RUN: every rank echoes its 8192 lines instead of
+    decoding them; gloo carries the gather): launcher, sharding, record packing, the all-gather of 65 536 records and the
+    reporting -- everything of `bench.py --gpus 8` but the device.  All records arrive, in line order; and eight ranks side by
+    side do not slow each other's host work down (what the first real 8-GPU run must not discover): the median rank's time
+    per step stays within 1.2x of one rank alone on the same host, the slowest within 2x."""
+    import numpy as np
+    from cor_asv_ann_amd import sharding
+    from cor_asv_ann_amd.synthetic import make_lines, make_vocabulary
+    import bench
+    env = {'CASV_BENCH_DRY_RUN': '1', 'CASV_BENCH_BACKEND': 'gloo'}
+    dump = str(tmp_path / 'rec8.npy')
+    code, lines, err = _run_bench(env, '--gpus', '8', '--steps', '2', '--warmup', '1', '--dump-records', dump)
+    assert code == 0, err
+    out = lines[0]
+    wl = bench.WORKLOADS['c5']
+    assert out['n_gpus'] == 8 and out['gathered_records'] == 65536 and out['config']['lines_per_gpu'] == 8192
+    assert len(out['ms_per_step_by_rank']) == 8
+    rec = np.load(dump)
+    S = 2 * (wl['length'] + 1)
+    assert rec.shape == (65536, 2 * S + 4)
+    idx, prob, length, score, found = sharding.unpack_records(rec)
+    _, want = make_lines(65536, wl['length'], wl['seed'], voc_size=wl['voc'])
+    assert (length == wl['length'] + 1).all()
+    assert np.array_equal(idx[:, :wl['length'] + 1], want)            # record j is line j of the global job, on every rank's view
+    # one rank alone through the same path (process group of one: packing, gather, reporting)
+    one = _run_bench(dict(env, CASV_BENCH_FORCE_DIST='1', MASTER_PORT='29641'), '--gpus', '1', '--workload', 'c5', '--steps', '2',
+                     '--warmup', '1', '--no-cpu-baseline')
+    assert one[0] == 0, one[2]
+    # a rank's own host work = its time per step without the collective (which moves 8x the bytes at 8 ranks and waits for the slowest)
+    alone = one[1][0]['ms_per_step_by_rank'][0] - one[1][0]['gather_ms_per_step']
+    packing8 = sorted(t - out['gather_ms_per_step'] for t in out['ms_per_step_by_rank'])
+    print('host ms per step without the gather: one rank alone %.1f; eight ranks side by side: median %.1f, slowest %.1f; '
+          'gather %.1f ms alone, %.1f ms at eight ranks (gloo, 107 MB per rank)'
+          % (alone, packing8[4], packing8[-1], one[1][0]['gather_ms_per_step'], out['gather_ms_per_step']))
+    assert packing8[4] <= 1.2 * alone + 20.0 and packing8[-1] <= 2.0 * alone + 50.0, (alone, packing8)
+
