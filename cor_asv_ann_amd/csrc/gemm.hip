@@ -54,6 +54,7 @@ constexpr int BM = 128, BN = 128, BK = 16, LDW = BK + 4;   // 80-B LDS rows: ds_
 constexpr int TILE_FLOATS = 128 * LDW;               // one operand tile
 constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;
 constexpr int CELL_LDS_BYTES = 128 * 128;            // LSTM epilogue: the tile's previous cell state, [half][row][16 floats]
+constexpr int STASH_LDS_BYTES = 256 * 6 * 8;         // per thread: row pointers that wait for their turn outside the register file
 
 // Software pipeline (per wave, so that ONE wave keeps its SIMD's matrix pipe busy and the two waves
 // of a SIMD do not have to be out of phase to cover each other):
@@ -132,6 +133,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 #pragma unroll
         for (int i = 0; i < 2; ++i) { const int ci = *(cgat ? sgc.rows + mrow[i] : no_rows); crow[i] = cgat ? ci : mrow[i]; }
     }
+    auto cptr = [&](int i) { return cin + (long long)crow[i] * sgc.ld + bn * 32 + 4 * kc; };
 #define CASV_SETUP_SEG(S, AP, TILES)                                                             \
     if (act[S]) {                                                                                \
         const Seg& sg = *sgs[S];                                                                 \
@@ -210,6 +212,53 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         const char* pa1 = (const char*)ap0[1] + (d1_1 & m1) + (d2_1 & m2) + (long long)ko * (BK * 4);
         issue_tile_asm(gt, pa0, pa1, bp[0] + kb, bp[1] + kb);
     };
+    // Steady state of the KS = 1 kernels: RUNNING operand pointers, advanced by one K tile per request (four 64-bit adds), and
+    // re-based where the request stream crosses into the next K segment -- a wave-uniform branch taken twice per K loop at most.
+    // The mask arithmetic above costs ~24 vector and ~20 scalar instructions per tile; a wave that has the matrix pipe to itself
+    // (its partner workgroup in prologue / epilogue: almost half of a decoder launch) issues them between its own MFMAs:
+    // 2317 instead of 2189 cycles per tile in profiles/kloop_probe.hip (ABL = 16 against 0, one workgroup per CU).
+    const char* ra0 = nullptr; const char* ra1 = nullptr; const float* rb0 = nullptr; const float* rb1 = nullptr;
+    int rleft = 0, rseg = 0;
+    // (the gathered segments' row pointers -- and the cell state's -- wait in LDS for their turn instead of in a dozen registers
+    // through the whole loop; the B rows are K-contiguous: a scalar step re-bases them)
+    const float** const rstash = reinterpret_cast<const float**>(smem_all + KS * (2 * 2 * TILE_FLOATS) + CELL_LDS_BYTES / 4) + 6 * tid;
+    auto run_set = [&](int kt_rel) {                       // position the running pointers at tile kt_rel
+        const int kt = kt_rel * KS + grp + kt_begin;
+        const long long m1 = (kt >= c0 && kt < c1) ? -1LL : 0LL, m2 = (kt >= c1) ? -1LL : 0LL;
+        const int ko = kt - ((int)m1 & c0) - ((int)m2 & c1);
+        const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * BK;
+        ra0 = (const char*)ap0[0] + (d1_0 & m1) + (d2_0 & m2) + (long long)ko * (BK * 4);
+        ra1 = (const char*)ap0[1] + (d1_1 & m1) + (d2_1 & m2) + (long long)ko * (BK * 4);
+        rb0 = bp[0] + kb; rb1 = bp[1] + kb;
+        rseg = kt >= c1 ? 2 : kt >= c0 ? 1 : 0;
+        rleft = (rseg == 0 ? c0 : rseg == 1 ? c1 : ntiles_all) - kt;
+        rstash[0] = ap1[0]; rstash[1] = ap1[1]; rstash[2] = ap2[0]; rstash[3] = ap2[1];
+        if (EPI == EPI_LSTM) { rstash[4] = cstage ? cptr(0) : bp[0]; rstash[5] = cstage ? cptr(1) : bp[0]; }   // (no cell state: any valid address)
+    };
+    auto run_advance = [&]() {
+        ra0 += BK * 4; ra1 += BK * 4; rb0 += BK; rb1 += BK;
+        if (--rleft == 0) {
+            asm volatile("" ::: "memory");                  // (stays a branch: as selects it would be the mask arithmetic again)
+            if (rseg == 0 && c1 > c0) {
+                rseg = 1; rleft = c1 - c0;
+                ra0 = (const char*)rstash[0]; ra1 = (const char*)rstash[1];
+                rb0 += koff1 - koff0 - c0 * BK; rb1 += koff1 - koff0 - c0 * BK;
+            } else if (rseg <= 1 && ntiles_all > c1) {
+                const int kprev = rseg == 0 ? koff0 + c0 * BK : koff1 + (c1 - c0) * BK;
+                rseg = 2; rleft = ntiles_all - c1;
+                ra0 = (const char*)rstash[2]; ra1 = (const char*)rstash[3];
+                rb0 += koff2 - kprev; rb1 += koff2 - kprev;
+            } else {
+                rleft = 1 << 30;                             // behind the last tile: nothing is requested from here any more
+            }
+        }
+    };
+    auto load_tile_run = [&](GTile& gt) { issue_tile_asm(gt, ra0, ra1, rb0, rb1); };    // (run_advance() follows behind the tile's MFMAs)
+    auto load_tile_run_plain = [&](GTile& gt) {             // the same request, visible to the compiler (tail tiles)
+        gt.a[0] = *reinterpret_cast<const f32x4*>(ra0); gt.a[1] = *reinterpret_cast<const f32x4*>(ra1);
+        gt.b[0] = *reinterpret_cast<const f32x4*>(rb0); gt.b[1] = *reinterpret_cast<const f32x4*>(rb1);
+        run_advance();
+    };
     auto store_tile = [&](const GTile& gt, int buf) {
         float* sa = smem + buf * 2 * TILE_FLOATS + r0 * LDW + 4 * kc;
         float* sb = sa + TILE_FLOATS;
@@ -253,12 +302,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     // (profiles/r04_gemm_stamps.txt): as 16 dependent 4-byte gathers per lane in the prologue the cell state took 26 000 cycles
     // (11 us) to land -- in front of the first MFMA, because no compiler-tracked load may be pending on a path into the loop --
     // and 23 000 when requested behind the loop instead; 4-byte-per-lane accesses are what the memory pipeline is slowest at.
-    auto cptr = [&](int i) { return cin + (long long)crow[i] * sgc.ld + bn * 32 + 4 * kc; };
     // cell-state area behind the tile buffers: [half j of the 128-byte row][row][16 floats], the image a wave's LDS-DMA writes
     // (lane L -> 16 bytes at base + 16 L: rows wave * 16 + L / 4, chunk L % 4)
     float* const cs = smem_all + KS * (2 * 2 * TILE_FLOATS);
     auto cell_dma = [&](int i, int j) {
-        const float* src = cstage ? cptr(i) + 16 * j : bp[0];         // (no cell state: any valid address, the image is not read)
+        const float* src = rstash[4 + i] + 16 * j;
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             (unsigned)(size_t)(__attribute__((address_space(3))) float*)cs + (unsigned)((j * 128 + 64 * i + (tid >> 6) * 16) * 64));
         unsigned keep;
@@ -291,7 +339,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     {                                                                                     \
         asm volatile("s_waitcnt vmcnt(4)" : "+v"(G.a[0]), "+v"(G.a[1]), "+v"(G.b[0]), "+v"(G.b[1]));  \
         store_tile(G, (KT) & 1);                                                          \
-        load_tile_asm(G, (KT) + 4);                                                       \
+        if (KS == 1) load_tile_run(G); else load_tile_asm(G, (KT) + 4);                  \
         EXTRA_LOADS                                                                       \
         read_frags(FN, ((KT) + 1) & 1);                                                   \
         mma(FC);                                                                          \
@@ -302,13 +350,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         }                                                                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 32 - NMEM, 0);                        \
         __builtin_amdgcn_sched_barrier(0);   /* keep all 32 MFMAs in front of the barrier: by then the LDS ops have landed */ \
+        if (KS == 1) run_advance();          /* (its rare branch ends the tile's basic block: behind everything that interleaves) */ \
         __syncthreads();                                                                  \
     }
 #define CASV_TILE_FULL(FC, FN, G, KT) CASV_TILE_FULL_X(FC, FN, G, KT, 18, )
 #define CASV_TILE_STEP(FC, FN, G, KT)                                                     \
     {                                                                                     \
         if ((KT) + 2 < ntiles) store_tile(G, (KT) & 1);                                   \
-        if ((KT) + 4 < ntiles) load_tile(G, (KT) + 4);                                    \
+        if ((KT) + 4 < ntiles) { if (KS == 1) load_tile_run_plain(G); else load_tile(G, (KT) + 4); }  \
         if ((KT) + 1 < ntiles) read_frags(FN, ((KT) + 1) & 1);                            \
         if ((KT) < ntiles) mma(FC);                                                       \
         __syncthreads();                                                                  \
@@ -351,6 +400,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 #ifdef CASV_GEMM_PROF
         pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime();
 #endif
+        if (KS == 1) run_set(4);                    // the first steady-state tile requests tile 4
         for (; kt + 5 < nt_min; kt += 2) {          // both wave groups have all the tiles of the steady state
             CASV_TILE_FULL(f0, f1, g0, kt)
             CASV_TILE_FULL(f1, f0, g1, kt + 1)
@@ -374,6 +424,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     } else {
         if (ntiles > 2) load_tile(g0, 2);
         if (ntiles > 3) load_tile(g1, 3);
+        if (KS == 1 && ntiles > 4) run_set(4);
         __syncthreads();
         if (ntiles > 0) read_frags(f0, 0);
         __syncthreads();
@@ -554,11 +605,11 @@ static void launch_one(const GemmBatch& bb, int blocks, int ksplit, hipStream_t 
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GEMM_LDS_BYTES * KS + (EPI == EPI_LSTM ? CELL_LDS_BYTES : 0));
+                                  GEMM_LDS_BYTES * KS + CELL_LDS_BYTES + STASH_LDS_BYTES);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((gemm_kernel<EPI, KS>), dim3(blocks, bb.count, ksplit), dim3(256 * KS),
-                       GEMM_LDS_BYTES * KS + (EPI == EPI_LSTM ? CELL_LDS_BYTES : 0), stream, bb);
+                       GEMM_LDS_BYTES * KS + CELL_LDS_BYTES + STASH_LDS_BYTES, stream, bb);
 }
 
 static int g_tile_mode = -1;       // -1 by size, 0 = 128x128, 1 = 32x128
