@@ -7,6 +7,11 @@
 // fire-and-forget float atomics (distinct addresses per sample: no contention).  dva / dbv are kept as per-sample partial sums
 // across the steps and reduced once after the loop.
 // HANDOFF: dL/dctx was accumulated by other workgroups of the same launch (read past the L1), dwq is read by them (write-through).
+// DEFER (persistent recurrence, round 4): d_enc / du are NOT touched here -- the step leaves its dL/dscore row (11 floats) in
+// p.ds_out, and two whole-sequence kernels behind the recurrence (attention_deferred_*_kernel, train_kernels.hip) add up
+// d_enc[s] = sum_t a_t[s] dctx_t and du[s] = sum_t dscore_t[s] v_a (1 - tanh^2(wq_t + u_s)) per sample in LDS, from what the
+// passes keep per step anyway: 2 x 5 632 float atomics per sample and step (23 MB per step at configs[3], drained by the memory
+// side at ~1.3 TB/s in the middle of the recurrence's critical path) become one pass over ~0.3 GB at the end.
 #pragma once
 #include "common.h"
 #include "row_kernels.h"
@@ -14,7 +19,7 @@
 
 namespace casv {
 
-template <bool HANDOFF>
+template <bool HANDOFF, int DEFER = 0>       // DEFER bits: 1 = d_enc, 2 = du summed behind the recurrence
 __device__ __forceinline__ void attention_bwd_sample(const AttnBwdArgs& p, const int b, const bool active, const int tid, const int nthr,
                                                      float* s_dx, float* s_da, float* s_ds, float* s_av) {
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
@@ -48,11 +53,14 @@ __device__ __forceinline__ void attention_bwd_sample(const AttnBwdArgs& p, const
     }
     __syncthreads();
     if (!active) return;
-    // d enc_out[s] += a_s * dctx
-    float* de = p.d_enc + (long long)b * p.enc_line + (long long)s_lo * p.enc_time;
-    for (int i = 0; i < cnt; ++i) {
-        const float av = s_av[i];
-        for (int c = tid; c < C; c += nthr) atomicAdd(de + (long long)i * p.enc_time + c, av * s_dx[c]);
+    if (DEFER && tid < 16) p.ds_out[(long long)b * 16 + tid] = s_ds[tid];
+    if (!(DEFER & 1)) {
+        // d enc_out[s] += a_s * dctx
+        float* de = p.d_enc + (long long)b * p.enc_line + (long long)s_lo * p.enc_time;
+        for (int i = 0; i < cnt; ++i) {
+            const float av = s_av[i];
+            for (int c = tid; c < C; c += nthr) atomicAdd(de + (long long)i * p.enc_time + c, av * s_dx[c]);
+        }
     }
     // energies: th = tanh(wq + u_s); dva += dscore*th ; dpre = dscore*va*(1-th^2) -> du_s, dwq
     for (int j = tid; j < W; j += nthr) {
@@ -68,7 +76,7 @@ __device__ __forceinline__ void attention_bwd_sample(const AttnBwdArgs& p, const
             const float ds = s_ds[i];
             dva += ds * th;
             const float dpre = ds * v * (1.0f - th * th);
-            if (i < cnt) atomicAdd(p.du + off0 + (long long)i * p.u_time, dpre);
+            if (!(DEFER & 2) && i < cnt) atomicAdd(p.du + off0 + (long long)i * p.u_time, dpre);
             dwq += dpre;
         }
         if (HANDOFF) store_sc1(p.dwq + (long long)b * W + j, dwq);

@@ -37,7 +37,7 @@ struct TrainState {
     DevBuf ETp, WaN, UaN;                  // derived: E^T padded [W][Vp], W_a [W][W], U_a [C][W]
     int B = 0, T = 0, U = 0, A = 0;
     DevBuf e_idx, e_val, d_in, d_out, d_w, m_enc, m_dec, m_cell;
-    DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, RecIn, prev, logits, dG, d_enc, du, DWQ, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
+    DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, RecIn, prev, logits, dG, d_enc, du, DWQ, DSrows, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
     std::vector<DevBuf> O, DO;             // masked layer outputs (encoder O[n], decoder DO[n])
     DevBuf loss, normsq;
     DevBuf dcalt;                          // second dL/dc buffers of the fused backward steps (two layers)
@@ -110,7 +110,7 @@ int casv_train_release(casv_model* m) {
     for (auto& l : ts->layers) { l.wxT.release(); l.wrT.release(); l.Hown.release(); l.Cs.release(); l.Gt.release(); l.Z.release(); l.dRec.release(); }
     DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
         &ts->m_cell, &ts->X0, &ts->H1, &ts->u, &ts->Y0, &ts->Ym, &ts->WQ, &ts->Ast, &ts->WIN, &ts->RecIn, &ts->prev,
-        &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl, &ts->dYl, &ts->dOin, &ts->dcbuf2, &ts->dvaP, &ts->dbvP,
+        &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->DSrows, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl, &ts->dYl, &ts->dOin, &ts->dcbuf2, &ts->dvaP, &ts->dbvP,
         &ts->loss, &ts->normsq, &ts->rec_cnt, &ts->dcalt};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : ts->O) b.release();
@@ -472,7 +472,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     ENS(ts->X0, TB * W * 4) ENS(ts->H1, TB * 2 * W * 4) ENS(ts->u, TB * W * 4) ENS(ts->Y0, UB * W * 4) ENS(ts->Ym, UB * W * 4)
     ENS(ts->WQ, UB * W * 4) ENS(ts->Ast, (size_t)(U + 1) * B * T * 4) ENS(ts->WIN, UB * 4)
     ENS(ts->RecIn, UB * (C + W) * 4) ENS(ts->prev, (size_t)B * 4) ENS(ts->logits, UB * Vp * 4)
-    ENS(ts->dG, UB * W * 4) ENS(ts->d_enc, TB * C * 4) ENS(ts->du, TB * W * 4) ENS(ts->DWQ, UB * W * 4) ENS(ts->dhatt, UB * W * 4)
+    ENS(ts->dG, UB * W * 4) ENS(ts->d_enc, TB * C * 4) ENS(ts->du, TB * W * 4) ENS(ts->DWQ, UB * W * 4) ENS(ts->DSrows, UB * 16 * 4) ENS(ts->dhatt, UB * W * 4)
     ENS(ts->dfin, (size_t)2 * D * B * W * 4) ENS(ts->dcbuf, (size_t)B * W * 4) ENS(ts->HP, LB * W * 4)
     ENS(ts->dX0, TB * W * 4) ENS(ts->dXtop, UB * W * 4) ENS(ts->dXl, TB * 2 * W * 4) ENS(ts->dYl, UB * W * 4) ENS(ts->dOin, TB * 2 * W * 4)
     ENS(ts->dcbuf2, (size_t)B * W * 4) ENS(ts->dvaP, (size_t)B * W * 4) ENS(ts->dbvP, (size_t)B * 4)
@@ -673,10 +673,21 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             ab.dva_part = ts->dvaP.as<float>(); ab.dbv_part = ts->dbvP.as<float>(); ab.B = B; ab.T = T; ab.W = W; ab.C = C;
             const size_t cb = train_recurrence_bwd_counter_bytes(B);
             ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
+            // d_enc / du summed behind the recurrence instead of by float atomics inside it (attn_bwd.h, DEFER)
+            static const int defer_opt = [] { const char* e = getenv("CASV_ATTN_DEFER"); return e ? atoi(e) : 1; }();
+            const int defer = (T <= ATTN_DEFER_MAX_T && W % 64 == 0 && C % 64 == 0) ? defer_opt : 0;
+            ra.DS = defer ? ts->DSrows.as<float>() : nullptr; ra.defer = defer;
             if (const int grid = train_attention_cell_bwd_grid(ra, m->ncu)) {
                 hipEvent_t ev{};
                 m->prof_begin(PC_PERSIST, 2.0 * B * U * ((double)4 * W * (C + W) + (double)W * W), 0.0, ev);
                 launch_train_attention_cell_bwd(ra, grid, st);
+                if (defer) {
+                    AttnDeferArgs da{};
+                    da.dRec = ra.dRec; da.ld_drec = kr; da.mcell = mcell; da.ld_mcell = W + C; da.mc_off = W;
+                    da.Ast = ra.Ast; da.WIN = ra.WIN; da.DS = ra.DS; da.WQ = ra.WQ; da.va = ab.va; da.u = ab.u;
+                    da.d_enc = ab.d_enc; da.du = ab.du; da.B = B; da.U = U; da.T = T; da.W = W; da.C = C; da.what = defer;
+                    launch_attention_deferred(da, st);
+                }
                 m->prof_end(PC_PERSIST, ev);
                 ts->rec_abort[ts->rec_launches++] = ra.counters + (train_attention_cell_bwd_counter_bytes(B) / sizeof(unsigned) - 32);
                 topb_persistent = true;

@@ -95,8 +95,22 @@ struct AttnBwdArgs {
     float* d_enc; float* du; float* dwq;
     float* dva_part; float* dbv_part;                        // [B][W], [B]: per-sample sums over the steps
     int B, T, W, C;
+    float* ds_out;                                           // deferred form (attn_bwd.h): dL/dscore row of this step, [B][16]
 };
 void launch_attention_bwd(const AttnBwdArgs& p, hipStream_t st);
+// The deferred sums of the persistent attention-cell backward: d_enc += sum_t a_t (x) dctx_t, du += sum_t dpre_t, per sample in LDS
+// (T <= ATTN_DEFER_MAX_T positions).  dctx_t = dRec[t][b][0:C] (row stride ld_drec) x the sample's input mask.
+constexpr int ATTN_DEFER_MAX_T = 288;
+struct AttnDeferArgs {
+    const float* dRec; long long ld_drec;                    // [U][B][ld_drec]
+    const float* mcell; long long ld_mcell; int mc_off;
+    const float* Ast; const int* WIN; const float* DS;       // [U+1][B][T] (row t + 1 belongs to step t), [U][B], [U][B][16]
+    const float* WQ; const float* va; const float* u;        // [U][B][W], [W], [T][B][W]
+    float* d_enc; float* du;                                 // [T][B][C], [T][B][W]
+    int B, U, T, W, C;
+    int what;                                                // bits: 1 = d_enc, 2 = du
+};
+void launch_attention_deferred(const AttnDeferArgs& p, hipStream_t st);
 
 // ... and the attention cell's backward recurrence (train_persist_topb.hip): cell backward, data GEMM, attention backward and
 // query-path GEMM of every time step in one launch.
@@ -109,6 +123,8 @@ struct TopBwdArgs {
     float* dRec;                 // [U][B][C + W] out, zeroed: gradient w.r.t. the cell's input rows [ctx | h(t-1)]
     float* dhatt;                // [U][B][W] out: gradient w.r.t. h(t-1) through the attention query
     float* DWQ;                  // [U][B][W] out: gradient w.r.t. the attention queries
+    float* DS;                   // [U][B][16] out: dL/dscore rows (what is summed behind the recurrence is summed from them) or nullptr
+    int defer;                   // attn_bwd.h DEFER bits: 1 = d_enc, 2 = du summed behind the recurrence instead of by atomics inside it
     const float* WQ; const float* Ast; const int* WIN;     // [U][B][W], [U+1][B][T], [U][B] kept by the forward pass
     float* dc_out;               // [B][W] out: dL/dc0
     AttnBwdArgs ab;              // mask, v_a, u, enc, d_enc, du, dva / dbv partial sums, sizes (dxh / a / win / wq / dwq are set per step)

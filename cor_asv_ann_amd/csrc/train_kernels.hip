@@ -201,6 +201,83 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdArgs p)
     __shared__ float s_da[16], s_ds[16], s_av[16];
     attention_bwd_sample<false>(p, blockIdx.x, true, threadIdx.x, 256, s_dx, s_da, s_ds, s_av);
 }
+// ---- the deferred sums of the attention backward (attn_bwd.h, DEFER): one wave per (sample, 64 columns), its share of the
+// sample's [T][64] sums in LDS, one pass over the steps (loads of four steps in flight together) ----
+__global__ __launch_bounds__(64) void attention_deferred_enc_kernel(const AttnDeferArgs p) {
+    extern __shared__ float s_acc[];                          // [T][64]
+    const int lane = threadIdx.x, c = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const int T = p.T, B = p.B;
+    for (int s = 0; s < T; ++s) s_acc[s * 64 + lane] = 0.0f;
+    const float mk = p.mcell ? p.mcell[(long long)b * p.ld_mcell + p.mc_off + c] : 1.0f;
+    constexpr int NB = 4;
+    for (int t0 = 0; t0 < p.U; t0 += NB) {
+        float dx[NB], av[NB]; int wv[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = t0 + j < p.U ? t0 + j : p.U - 1;
+            wv[j] = p.WIN[(long long)t * B + b];
+            dx[j] = p.dRec[((long long)t * B + b) * p.ld_drec + c];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = t0 + j < p.U ? t0 + j : p.U - 1;
+            const int s_lo = wv[j] & 0xffff, cnt = wv[j] >> 16;
+            av[j] = lane < cnt ? p.Ast[((long long)(t + 1) * B + b) * T + s_lo + lane] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (t0 + j < p.U) {
+                const int s_lo = wv[j] & 0xffff, cnt = wv[j] >> 16;
+                const float d = dx[j] * mk;
+                for (int i = 0; i < cnt; ++i) s_acc[(s_lo + i) * 64 + lane] += __shfl(av[j], i, 64) * d;
+            }
+        }
+    }
+    for (int s = 0; s < T; ++s) {
+        float* o = p.d_enc + ((long long)s * B + b) * p.C + c;
+        *o += s_acc[s * 64 + lane];
+    }
+}
+__global__ __launch_bounds__(64) void attention_deferred_u_kernel(const AttnDeferArgs p) {
+    extern __shared__ float s_acc[];                          // [T][64]
+    const int lane = threadIdx.x, j = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const int T = p.T, B = p.B, W = p.W;
+    for (int s = 0; s < T; ++s) s_acc[s * 64 + lane] = 0.0f;
+    const float v = p.va[j];
+    const float* ub = p.u + (long long)b * W + j;             // u[s][b][j] = ub[s * B * W]
+    for (int t = 0; t < p.U; ++t) {
+        const int wv = p.WIN[(long long)t * B + b];
+        const float q = p.WQ[((long long)t * B + b) * W + j];
+        const float ds = lane < 16 ? p.DS[((long long)t * B + b) * 16 + lane] : 0.0f;
+        const int s_lo = wv & 0xffff, cnt = wv >> 16;
+        float uu[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) uu[i] = ub[(long long)(s_lo + (i < cnt ? i : 0)) * B * W];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const float th = fast_tanh(q + uu[i]);
+            const float dpre = __shfl(ds, i, 64) * v * (1.0f - th * th);
+            if (i < cnt) s_acc[(s_lo + i) * 64 + lane] += dpre;
+        }
+    }
+    for (int s = 0; s < T; ++s) {
+        float* o = p.du + ((long long)s * B + b) * W + j;
+        *o += s_acc[s * 64 + lane];
+    }
+}
+void launch_attention_deferred(const AttnDeferArgs& p, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_deferred_enc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_DEFER_MAX_T * 64 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_deferred_u_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_DEFER_MAX_T * 64 * 4);
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    if (p.what & 1) hipLaunchKernelGGL(attention_deferred_enc_kernel, dim3(p.C / 64, p.B), dim3(64), (size_t)p.T * 64 * 4, st, p);
+    if (p.what & 2) hipLaunchKernelGGL(attention_deferred_u_kernel, dim3(p.W / 64, p.B), dim3(64), (size_t)p.T * 64 * 4, st, p);
+}
+
 void launch_attention_bwd(const AttnBwdArgs& p, hipStream_t st) {
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(p.B), dim3(256), 0, st, p);
 }

@@ -276,9 +276,12 @@ __global__ __launch_bounds__(256, 1) void train_attention_cell_bwd_kernel(const 
             p.dxh = ra.dRec + (long long)t * B * KR; p.ld_dxh = KR; p.ctx_off = 0;
             p.a = ra.Ast + (long long)(t + 1) * B * ra.ab.T; p.win = ra.WIN + (long long)t * B;
             p.wq = ra.WQ + (long long)t * B * W; p.dwq = ra.DWQ + (long long)t * B * W;
+            p.ds_out = ra.DS ? ra.DS + (long long)t * B * 16 : nullptr;
             for (int s0 = 0; s0 < SPW; s0 += GROUPS) {
                 const int b = m0 + slot * SPW + s0 + grp;
-                attention_bwd_sample<true>(p, b < B ? b : B - 1, b < B && s0 + grp < SPW, gtid, nthr, s_dx, s_da, s_ds, s_av);
+                if (ra.defer == 3) attention_bwd_sample<true, 3>(p, b < B ? b : B - 1, b < B && s0 + grp < SPW, gtid, nthr, s_dx, s_da, s_ds, s_av);
+                else if (ra.defer == 1) attention_bwd_sample<true, 1>(p, b < B ? b : B - 1, b < B && s0 + grp < SPW, gtid, nthr, s_dx, s_da, s_ds, s_av);
+                else attention_bwd_sample<true, 0>(p, b < B ? b : B - 1, b < B && s0 + grp < SPW, gtid, nthr, s_dx, s_da, s_ds, s_av);
                 __syncthreads();
             }
         }
