@@ -481,16 +481,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     // ---- epilogue ----
     if (EPI == EPI_PLAIN || g.epi_plain) {
         float* cbase = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
-        if (nsplit == 1 && !g.accumulate && m0 + BM <= g.M && n0 + BN <= g.N) {
+        if (nsplit == 1 && m0 + BM <= g.M && n0 + BN <= g.N) {
             // full tile, plain stores: no control flow between the 64 stores (a branch per element makes the compiler wait for the
-            // element before -- see the LSTM epilogue below)
+            // element before -- see the LSTM epilogue below); C += : all 64 old values are requested first, then added and stored
             float* cb = cbase + (long long)(m0 + wave * 32 + 4 * lh) * g.out.ld + n0 + l31;
+            float bcol[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float b = g.bias ? g.bias[n0 + c * 32 + l31] : 0.0f;
+            for (int c = 0; c < 4; ++c) bcol[c] = g.bias ? g.bias[n0 + c * 32 + l31] : 0.0f;
+            if (g.accumulate) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cb[(long long)((r & 3) + 8 * (r >> 2)) * g.out.ld + c * 32] = acc[c][r] + b;
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][r] += cb[(long long)((r & 3) + 8 * (r >> 2)) * g.out.ld + c * 32];
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cb[(long long)((r & 3) + 8 * (r >> 2)) * g.out.ld + c * 32] = acc[c][r] + bcol[c];
         } else
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
