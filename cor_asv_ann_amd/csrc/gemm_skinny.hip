@@ -130,6 +130,57 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gs.b[i]) : "v"(pb));
         }
     };
+    // Steady state: RUNNING operand pointers, advanced by one stage per request and re-based where the request stream crosses into
+    // the next K segment (a wave-uniform branch, twice per K loop at most) -- gemm.hip's scheme, round 4: the mask arithmetic above
+    // is ~20 vector and ~25 scalar instructions per stage that a wave with the matrix pipe to itself issues between its own MFMAs.
+    const char* ra = nullptr; long long rdl[RB]; const float* rbp[4]; int rleft = 0, rseg = 0;
+    auto run_set = [&](int kt_rel) {
+        const int kt = kt_rel + kt_begin;
+        const long long m1 = (kt >= c0 && kt < c1) ? -1LL : 0LL, m2 = (kt >= c1) ? -1LL : 0LL;
+        const int ko = kt - ((int)m1 & c0) - ((int)m2 & c1);
+        const int kb = koff0 + ((int)m1 & (koff1 - koff0)) + ((int)m2 & (koff2 - koff0)) + ko * SK2;
+        ra = (const char*)ap0 + (d1 & m1) + (d2 & m2) + (long long)ko * (SK2 * 4);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) rdl[r] = (drow[r][0] & ~(m1 | m2)) | (drow[r][1] & m1) | (drow[r][2] & m2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rbp[i] = bp[i] + kb;
+        rseg = kt >= c1 ? 2 : kt >= c0 ? 1 : 0;
+        rleft = (rseg == 0 ? c0 : rseg == 1 ? c1 : ntiles_all) - kt;
+    };
+    auto load_stage_run = [&](GStage& gs) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gs.a[0]) : "v"(ra));
+#pragma unroll
+        for (int r = 1; r < RB; ++r) {
+            const char* par = ra + rdl[r];
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gs.a[r]) : "v"(par));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gs.b[i]) : "v"(rbp[i]));
+    };
+    auto run_advance = [&]() {
+        ra += SK2 * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rbp[i] += SK2;
+        if (--rleft == 0) {
+            asm volatile("" ::: "memory");                  // (stays a branch)
+            if (rseg == 0 && c1 > c0) {
+                rseg = 1; rleft = c1 - c0; ra = (const char*)ap1;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) rdl[r] = drow[r][1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rbp[i] += koff1 - koff0 - c0 * SK2;
+            } else if (rseg <= 1 && ntiles_all > c1) {
+                const int kprev = rseg == 0 ? koff0 + c0 * SK2 : koff1 + (c1 - c0) * SK2;
+                rseg = 2; rleft = ntiles_all - c1; ra = (const char*)ap2;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) rdl[r] = drow[r][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rbp[i] += koff2 - kprev;
+            } else {
+                rleft = 1 << 30;
+            }
+        }
+    };
     auto store_stage = [&](const GStage& gs, int buf) {
         float* sa = s_stage + buf * STAGE_FLOATS + srow * SLD + sk;
 #pragma unroll
@@ -215,8 +266,9 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         {                                                                                                          \
             if constexpr (RB == 1) { CASV_SK_WAIT("5", G) } else { CASV_SK_WAIT("6", G) }                          \
             store_stage(G, ((J) + 1) & 1);                                                                         \
-            load_stage_asm(G, (J) + 3);                                                                            \
+            load_stage_run(G);                                                                                     \
             compute((J) & 1);                                                                                      \
+            run_advance();                                                                                         \
             __syncthreads();                                                                                       \
         }
 #define CASV_SK_STEP(G, J)                                                                                         \
@@ -229,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         if (ntiles > 4) {
             // (no compiler-tracked tile load may be pending on any path into the loop: it would put a vmcnt(0) at the loop head)
             load_stage_asm(g1, 1); load_stage_asm(g0, 2);
+            run_set(3);                                     // the first steady-state stage requests stage 3
             __syncthreads();
             for (; kt + 4 < ntiles; kt += 2) {
                 CASV_SK_FULL(g1, kt)
@@ -255,7 +308,15 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
     if (EPI == EPI_PLAIN || g.epi_plain) {
         float* cbase = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
         const int n = n0 + wave * 32 + l31;
-        if (n < g.N) {
+        if (nsplit == 1 && !g.accumulate && m0 + SBM <= g.M && n0 + SBN <= g.N) {
+            // full tile, plain stores: nothing between the stores that the compiler would wait at (gemm.hip's epilogue, round 4)
+            const float b = g.bias ? g.bias[n] : 0.0f;
+            float* cb = cbase + (long long)(m0 + 4 * lh) * g.out.ld + n;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cb[(long long)(32 * rb + (r & 3) + 8 * (r >> 2)) * g.out.ld] = acc[rb][r] + b;
+        } else if (n < g.N) {
             const float b = g.bias ? g.bias[n] : 0.0f;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
