@@ -85,6 +85,17 @@ extern "C" int casv_comm_all_gather_records(casv_model* m, int32_t* recv) {
     if (!m->rec.p || !m->rec_rows) return fail(CASV_ERR_STATE, "casv_records_reset first");
     HIPCHK(hipSetDevice(m->device));
     const size_t n = (size_t)m->rec_rows * (2 * m->rec_S + 4) * 4;
+    {   // every rank must bring the same record shape: a mismatch would hang or corrupt the collective -- check it first
+        // (max of (rows, S, -rows, -S) over the ranks: all equal iff max == -max of the negatives)
+        double shape[4] = {(double)m->rec_rows, (double)m->rec_S, -(double)m->rec_rows, -(double)m->rec_S};
+        if (int rc = m->comm_send.ensure(sizeof(shape))) return rc;
+        HIPCHK(hipMemcpyAsync(m->comm_send.p, shape, sizeof(shape), hipMemcpyHostToDevice, m->stream));
+        NCHK(g_rccl.AllReduce(m->comm_send.p, m->comm_send.p, 4, ncclFloat64, ncclMax, reinterpret_cast<ncclComm_t>(m->comm), m->stream));
+        HIPCHK(hipMemcpyAsync(shape, m->comm_send.p, sizeof(shape), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (shape[0] != -shape[2] || shape[1] != -shape[3])
+            return fail(CASV_ERR_STATE, "the ranks' record buffers differ in shape (casv_records_reset with the same rows and steps on every rank)");
+    }
     if (int rc = m->comm_recv.ensure(n * m->comm_world)) return rc;
     NCHK(g_rccl.AllGather(m->rec.p, m->comm_recv.p, n, ncclChar, reinterpret_cast<ncclComm_t>(m->comm), m->stream));
     HIPCHK(hipMemcpyAsync(recv, m->comm_recv.p, n * m->comm_world, hipMemcpyDeviceToHost, m->stream));

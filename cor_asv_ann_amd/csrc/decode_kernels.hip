@@ -165,11 +165,28 @@ __global__ __launch_bounds__(64) void pack_records_kernel(const RecordSrc r, int
         }
     }
     if (fallback) {
-        for (int t = lane; t < r.T; t += 64) len += r.src_idx[((long long)j * r.T + t) * r.A] >= 0 ? 1 : 0;
-        len = (int)wave_sum((float)len);
-        len = len < S ? len : S;
+        // The input line itself (seq2seq.py:826-836): every position up to the last one that carries a symbol, in order -- an
+        // unmapped character inside the line keeps its place (index 0, as the host packs it) instead of shortening the line;
+        // of several alternatives at a position (confusion-network input: the slots are sorted by vocabulary index) the one with
+        // the highest confidence, which is the first alternative the reference takes.
+        int last = -1;
+        for (int t = lane; t < r.T; t += 64) {
+            bool any = false;
+            for (int a = 0; a < r.A; ++a) any |= r.src_idx[((long long)j * r.T + t) * r.A + a] >= 0;
+            if (any) last = t;
+        }
+        last = (int)wave_max((float)last);
+        len = last + 1 < S ? last + 1 : S;
         for (int s = lane; s < S; s += 64) {
-            const int c = s < len ? r.src_idx[((long long)j * r.T + s) * r.A] : 0;
+            int c = 0;
+            if (s < len) {
+                float best = -1.0f;
+                for (int a = 0; a < r.A; ++a) {
+                    const int ci = r.src_idx[((long long)j * r.T + s) * r.A + a];
+                    const float cv = r.src_val ? r.src_val[((long long)j * r.T + s) * r.A + a] : 1.0f;
+                    if (ci >= 0 && cv > best) { best = cv; c = ci; }
+                }
+            }
             out[s] = c > 0 ? c : 0;
             out[S + s] = s < len ? __float_as_int(1.0f) : 0;
         }

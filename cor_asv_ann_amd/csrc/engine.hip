@@ -1185,7 +1185,9 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
     if (!strcmp(key, "persistent")) {
         // (2: as -1, and in the train step's first persistent recurrence one workgroup leaves without handing on: its peers give up
         // after their bounded wait and the step falls back to per-step launches -- a test of that path)
-        if (value < -1 || value > 2) return fail(CASV_ERR_ARG, "persistent must be -1 (by batch size), 0 (per-step kernels) or 1 (always)");
+        // The fault injection is not part of the production interface: only a process started with CASV_FAULT_INJECTION=1 gets it.
+        static const bool fault_ok = [] { const char* e = getenv("CASV_FAULT_INJECTION"); return e && e[0] == '1'; }();
+        if (value < -1 || value > (fault_ok ? 2 : 1)) return fail(CASV_ERR_ARG, "persistent must be -1 (by batch size), 0 (per-step kernels) or 1 (always)");
         m->persist_mode = (int)value; return CASV_OK;
     }
     if (!strcmp(key, "eos")) {

@@ -33,6 +33,7 @@ Deliberate divergences from the reference's EFFECTIVE behaviour (both pinned in 
 """
 import logging
 import os
+import threading
 import unicodedata
 from bisect import bisect_left, insort_left
 from difflib import SequenceMatcher
@@ -104,12 +105,19 @@ L2_REPLACEMENTS = dict(_L2_PAIRS)
 
 # Compatibility with the reference's effective behaviour (module docstring): [enabled, single-character keys already popped]
 _QUIRKS = [os.environ.get('CASV_METRICS_REFERENCE_QUIRKS', '') == '1', False]
+_QUIRKS_LOCK = threading.Lock()          # (normalize_text is reachable from worker threads)
 
 
 def reference_quirks(enable=True):
     """Reproduce (True) or not (False, default) the reference's process-global pop of the single-code-point replacements
     (alignment.py:318-320); switching it on starts a fresh "process": the next string normalised is the first one."""
-    _QUIRKS[0], _QUIRKS[1] = bool(enable), False
+    with _QUIRKS_LOCK:
+        _QUIRKS[0], _QUIRKS[1] = bool(enable), False
+
+
+def normalization_mode():
+    """Which of the two behaviours `normalize_text('historic_latin')` has right now -- evaluate() says so beside its figures."""
+    return 'reference-quirks' if _QUIRKS[0] else 'table-applied-to-every-string'
 
 
 def normalize_text(seq, normalization=None, gtlevel=1):
@@ -123,9 +131,10 @@ def normalize_text(seq, normalization=None, gtlevel=1):
             return seq
         single = {k: v for k, v in L2_REPLACEMENTS.items() if len(k) == 1}
         if _QUIRKS[0]:
-            if _QUIRKS[1]:
+            with _QUIRKS_LOCK:           # test-and-set: exactly one string is "the first one"
+                first, _QUIRKS[1] = not _QUIRKS[1], True
+            if not first:
                 single = {}              # the reference popped them from its global table during the first call
-            _QUIRKS[1] = True
         for key, value in L2_REPLACEMENTS.items():
             if len(key) > 1:
                 seq = seq.replace(key, value)        # multi-code-point keys first, in table order

@@ -590,7 +590,7 @@ class Sequence2Sequence(object):
         if not lines:
             return [], [], [], []
         prepared = self._prepare_lines(lines, conf)
-        raw = self._decode_prepared(prepared, fast, greedy, alignments)
+        raw = self._decode_prepared(prepared, fast, greedy, alignments, [bool(line) for line in lines])
         return self._results_of(lines, prepared, raw, fast, greedy, alignments)
 
     def correct_batches(self, batches, fast=True, greedy=True, alignments=True, after_decode=None):
@@ -601,24 +601,36 @@ class Sequence2Sequence(object):
         batch by batch, in order; identical results.  `after_decode(k)`, if given, runs in the device thread right after batch
         k's decode call (its results still lie in the engine's buffers: e.g. `engine.records_append`)."""
         assert not fast or greedy, "cannot decode in fast mode with beam search enabled"
+        import sys
         from .training import prefetch
         self._require_engine()
         self._codepoint_table()                 # (the lookup tables exist before the stages' threads ask for them)
 
         def prepared():
             for item in batches:
-                lines, conf = item if isinstance(item, tuple) else (item, None)
+                # a pair (lines, conf) is a 2-tuple whose first member is itself a sequence of lines -- a batch handed over as a
+                # tuple of strings is a batch of lines
+                pair = isinstance(item, tuple) and len(item) == 2 and isinstance(item[0], (list, tuple))
+                lines, conf = item if pair else (item, None)
                 yield lines, (self._prepare_lines(lines, conf) if lines else None)
 
         def decoded():
             for k, (lines, prep) in enumerate(prefetch(prepared(), depth=2)):
-                raw = self._decode_prepared(prep, fast, greedy, alignments) if lines else None
-                if after_decode is not None:
+                raw = self._decode_prepared(prep, fast, greedy, alignments, [bool(line) for line in lines]) if lines else None
+                if after_decode is not None and raw is not None:      # (no decode ran: the engine still holds the batch before)
                     after_decode(k)
                 yield lines, prep, raw
 
-        for lines, prep, raw in prefetch(decoded(), depth=1):
-            yield self._results_of(lines, prep, raw, fast, greedy, alignments) if lines else ([], [], [], [])
+        # The device stage needs the interpreter lock only between its C-ABI calls; the string building of the stage behind it
+        # is pure Python and gives the lock up once per switch interval (5 ms by default: up to half a millisecond of idle GPU
+        # between two batches of configs[1], rocprofv3 trace of round 4).  A short interval while the pipeline runs.
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(interval, 1e-4))
+        try:
+            for lines, prep, raw in prefetch(decoded(), depth=1):
+                yield self._results_of(lines, prep, raw, fast, greedy, alignments) if lines else ([], [], [], [])
+        finally:
+            sys.setswitchinterval(interval)
 
     # the three stages of correct_lines ------------------------------------------------------------
     def _prepare_lines(self, lines, conf):
@@ -626,8 +638,10 @@ class Sequence2Sequence(object):
         idx, val, _ = self._sparse_lines(lines, conf)
         return idx, val
 
-    def _decode_prepared(self, prepared, fast, greedy, alignments):
-        """The device part: encode + decode, raw result arrays.  (The only stage that talks to the engine.)"""
+    def _decode_prepared(self, prepared, fast, greedy, alignments, nonempty=None):
+        """The device part: encode + decode, raw result arrays.  (The only stage that talks to the engine.)
+        `nonempty[j]`: line j of the batch is not empty (decided on the LINES, as seq2seq.py:815 does: a line of nothing
+        but unmapped symbols is decoded, an empty padding line is not)."""
         eng = self._require_engine()
         want_align = False if not alignments else (True if alignments == 'dense' else 'sparse')
         idx, val = prepared
@@ -640,7 +654,7 @@ class Sequence2Sequence(object):
             return gi, gp, ga
         # the per-line modes never decode the empty padding lines of a partial batch (seq2seq.py:815-816) -- an
         # all-zero input row would also trip the greedy mode's NaN rule for the whole batch
-        live = [j for j in range(B) if (idx[j] >= 0).any()]
+        live = [j for j in range(B) if (nonempty[j] if nonempty is not None else (idx[j] >= 0).any())]
         if greedy:
             if not live:
                 return live, []
@@ -730,15 +744,16 @@ class Sequence2Sequence(object):
     def predict(self, filenames, fast=False, greedy=False, charmap=None):
         """seq2seq.py:756-780: generator of (filenames, lines, scores) per batch."""
         assert self.status == 2
-        names = []
+        import collections
+        names = collections.deque()            # file names of the batches in flight (the producer runs a few batches ahead)
 
         def batches():
             for lines_source, lines_sourceconf, _, lines_filename in self.gen_lines(filenames, repeat=False, unsupervised=True, charmap=charmap):
                 names.append(lines_filename)
                 yield lines_source, lines_sourceconf
         # batch k + 1 is read and vectorised, and the device runs on it, while this generator's consumer handles batch k
-        for k, (lines_result, _, scores_result, _) in enumerate(self.correct_batches(batches(), fast=fast, greedy=greedy, alignments=False)):
-            yield (names[k], lines_result, scores_result)
+        for lines_result, _, scores_result, _ in self.correct_batches(batches(), fast=fast, greedy=greedy, alignments=False):
+            yield (names.popleft(), lines_result, scores_result)
 
     def map_files(self, filenames):
         """Collect the character set of the files and grow the mapping (seq2seq.py:555-588)."""
@@ -901,6 +916,9 @@ class Sequence2Sequence(object):
             c_counts['beamed'].score += sum(scores_beamed)
 
         self.logger.info('finished %d lines', c_counts['origin'].length)
+        if normalization == 'historic_latin':        # (the two behaviours give different CER / WER on ligatures and PUA letters)
+            from .metrics import normalization_mode
+            self.logger.info('historic_latin normalisation: %s (cor_asv_ann_amd.metrics.reference_quirks)', normalization_mode())
         labels = {'origin': 'OCR   ', 'greedy': 'greedy', 'beamed': 'beamed'}
         if confusion > 0:
             for k in names:

@@ -49,7 +49,10 @@ def prefetch(iterable, depth=2):
             yield item
     finally:
         stop.set()
-        thread.join(timeout=5.0)
+        # No timeout: a worker that drives the device (correct_batches' second stage) may be inside a C-ABI call on the engine
+        # when its consumer leaves early; the caller must not get the engine back while that call runs (the handle is not
+        # thread-safe).  The worker returns after the call in progress: its next put() sees `stop`.
+        thread.join()
 
 
 def train_batches(s2s, filenames, split_rand, rng):

@@ -223,9 +223,9 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
  * "persistent" = greedy decoding through the persistent decoder (all steps in ONE launch, workgroups hand rows to each
  * other through memory: small batches, where a step is too short for a launch per kernel): -1 by batch size (default:
  * up to 512 lines), 0 never, 1 always -- the results are the same bit for bit; the same option governs the train step's
- * recurrences (every pair of plain layers walks its sequence in ONE launch forward and ONE backward unless 0; 2 = as -1, and
- * one workgroup of the first forward recurrence leaves without handing on -- a test of the give-up path: the step is redone
- * with per-step launches);
+ * recurrences (every pair of plain layers walks its sequence in ONE launch forward and ONE backward unless 0).  (A process started
+ * with CASV_FAULT_INJECTION=1 -- the test suite -- also accepts 2 = as -1, and one workgroup of the first forward recurrence leaves
+ * without handing on: the give-up path, the step is redone with per-step launches.  Not available otherwise.);
  * "fused_backward" = 1 (default): a backward time step without a persistent form is ONE launch (cell backward inside the data
  * GEMM), 0: two;
  * "vendor_gemm" = 0 (default): every contraction runs in this library's own kernels; 1 = calibration: the train step's plain

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault('CASV_FAULT_INJECTION', '1')     # the library's give-up paths are forced by tests only (casv_set_option)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
