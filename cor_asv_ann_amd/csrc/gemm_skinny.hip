@@ -213,27 +213,32 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
                 for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[r][q][i], fb[q][i], acc[r], 0, 0, 0);
     };
 
-    // LSTM: wave w finishes rows (r & 3, r >> 2 == w) of every row block; fetch their previous cell state under the K loop
+    // LSTM: wave w finishes rows (r & 3, r >> 2 == w) of every row block.  Their previous cell state is requested BEHIND the
+    // steady-state loop, under the tail stages (round 4: requested in front of the loop, these compiler-tracked loads were waited
+    // for before the first MFMA -- no tracked load may be pending on a path into the loop; gemm.hip's stamps put that wait at
+    // 26 000 cycles for its 16 gathers per lane).
     float cpv[RB][4];
-    if (EPI == EPI_LSTM && !g.epi_plain) {
-        const bool cfirst = g.c_in.first_base && step == 0;
-        const bool czero = g.c_in.skip_first && step == 0 && !cfirst;
-        const float* cin = cfirst ? g.c_in.first_base
-            : g.c_in.base + (long long)(step * g.c_in.step_mul + g.c_in.step_add) * g.c_in.slot_stride;
-        const int u = bn * 32 + l31;
+    auto load_cell_state = [&]() {
+        if (EPI == EPI_LSTM && !g.epi_plain) {
+            const bool cfirst = g.c_in.first_base && step == 0;
+            const bool czero = g.c_in.skip_first && step == 0 && !cfirst;
+            const float* cin = cfirst ? g.c_in.first_base
+                : g.c_in.base + (long long)(step * g.c_in.step_mul + g.c_in.step_add) * g.c_in.slot_stride;
+            const int u = bn * 32 + l31;
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+            for (int r = 0; r < RB; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int m = m0 + 32 * r + q + 8 * wave + 4 * lh;
-                m = m < g.M ? m : g.M - 1;
-                cpv[r][q] = 0.0f;
-                if (!czero) {
-                    const int rid = (g.c_in.rows && !cfirst) ? g.c_in.rows[m] : m;
-                    cpv[r][q] = cin[(long long)rid * g.c_in.ld + u];
+                for (int q = 0; q < 4; ++q) {
+                    int m = m0 + 32 * r + q + 8 * wave + 4 * lh;
+                    m = m < g.M ? m : g.M - 1;
+                    cpv[r][q] = 0.0f;
+                    if (!czero) {
+                        const int rid = (g.c_in.rows && !cfirst) ? g.c_in.rows[m] : m;
+                        cpv[r][q] = cin[(long long)rid * g.c_in.ld + u];
+                    }
                 }
-            }
-    }
+        }
+    };
 
     // ... and (train step) the precomputed input pre-activations x.K + b of its (row, unit) elements: requested here, under the
     // K loop, instead of as a dependent round trip between the K loop and the cell
@@ -289,9 +294,11 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
             }
             CASV_SK_WAIT("0", g0)
             CASV_SK_WAIT("0", g1)
+            load_cell_state();
         } else {
             if (ntiles > 1) load_stage(g1, 1);
             if (ntiles > 2) load_stage(g0, 2);
+            load_cell_state();
             __syncthreads();
         }
         for (; kt + 1 < ntiles; kt += 2) {
@@ -302,6 +309,8 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
 #undef CASV_SK_STEP
 #undef CASV_SK_FULL
 #undef CASV_SK_WAIT
+    } else {
+        load_cell_state();
     }
 
     // ---- epilogue ----
