@@ -61,14 +61,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
     // moment ago, so the prefetch is one tile deep -- less than the memory latency of operands that stream from HBM.  Issued
     // from asm statements the loads are invisible to that bookkeeping, and CASV_TN_FULL waits with a counted vmcnt(4): the four
     // loads of the tile it is about to store have landed, the four of the next tile stay in flight.
-    auto load_tile_asm = [&](GTile& gt, int kt_rel) {
+    // (running pointers: one 64-bit add per load and tile instead of a 64-bit multiply-add per load -- gemm.hip, round 4)
+    const float* ra[2] = {nullptr, nullptr}; const float* rb[2] = {nullptr, nullptr};
+    const long long astep = (long long)TBK * g.lda, bstep = (long long)TBK * g.ldb;
+    auto run_set = [&](int kt_rel) {
         const long long k0 = (long long)(kt_begin + kt_rel) * TBK + sk;
 #pragma unroll
+        for (int i = 0; i < 2; ++i) { ra[i] = ap + (k0 + 8 * i) * g.lda; rb[i] = bp + (k0 + 8 * i) * g.ldb; }
+    };
+    auto load_tile_asm = [&](GTile& gt, int kt_rel) {
+        (void)kt_rel;
+#pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float* pa = ap + (k0 + 8 * i) * g.lda;
-            const float* pb = bp + (k0 + 8 * i) * g.ldb;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[i]) : "v"(pa));
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[i]) : "v"(pb));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[i]) : "v"(ra[i]));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[i]) : "v"(rb[i]));
+            ra[i] += astep; rb[i] += bstep;
         }
     };
     // the last tile of the K range may be partial: rows k >= K enter as zeros
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
     if (nwhole > 5) {
         // Steady state.  Tiles 2 and 3 are requested the hidden way already: a compiler-tracked load pending on ANY path into
         // the loop would put a full vmcnt(0) at the loop head, executed in every iteration.
+        run_set(2);
         load_tile_asm(g0, 2); load_tile_asm(g1, 3);
         __syncthreads();
         read_frags(f0, 0);
