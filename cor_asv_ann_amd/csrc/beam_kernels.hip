@@ -485,7 +485,73 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
     const int pre = qn < pop_cap ? qn : pop_cap;
     for (int i = tid; i < pre; i += NT) pop_chr[i] = s.n_chr[nbase + pop_id[i]];
     __syncthreads();
-    if (tid == 0) {
+    // Wide beams (SPLIT: N >= 64 hypotheses per line): the walk is done by all threads -- every head entry is flagged finished /
+    // unfinished, exclusive prefix counts (wave ballots + one pass over the waves' totals) give every unfinished entry its slot in the
+    // next beam and the walk's end (the entry behind the N-th unfinished one); only the FINISHED entries in front of that end -- a
+    // handful at most -- are filed one by one, in order, as the serial walk files them.  Round 4: one thread walking N + 64 entries
+    // took 40-45 us of the page call's 207-us step.  (Not taken when the head held in LDS does not reach the walk's end: the serial
+    // walk below goes on into the queue in HBM.)
+    bool walked = false;
+    if (SPLIT && pop_cap <= NT) {
+        __shared__ int w_nf[NWV], w_fin[NWV];
+        __shared__ int sh_hend, sh_nfin;
+        __shared__ double sh_b0;
+        int* finl = r_off;                                   // (the row records of phase A are dead: r_off and r_beampos, 2 N + 2 >= N + 64 ints)
+        const int h = tid;
+        const bool in = h < pre;
+        const int chr = in ? pop_chr[h] : 0;
+        const bool fin = in && chr == p.eos, unf = in && chr != p.eos;
+        const unsigned long long bu = __ballot(unf), bf = __ballot(fin);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        if (lane == 0) { w_nf[wave] = __popcll(bu); w_fin[wave] = __popcll(bf); }
+        if (tid == 0) { sh_hend = -1; sh_nfin = 0; }
+        __syncthreads();
+        int nf_x = __popcll(bu & below), fin_x = __popcll(bf & below), nf_total = 0;
+        for (int w = 0; w < NWV; ++w) { if (w < wave) { nf_x += w_nf[w]; fin_x += w_fin[w]; } nf_total += w_nf[w]; }
+        if (nf_total >= N || pre == qn) {                    // (uniform) the walk ends inside the head
+            walked = true;
+            const int nb = nf_total < N ? nf_total : N;
+            if (unf && nf_x < N) {
+                const int id = pop_id[h];
+                s.beam_node[line * N + nf_x] = id;
+                r_count[nf_x] = id;                          // r_count is free now: ids of the popped nodes
+                if (nf_x == 0) sh_b0 = pop_key[h];
+                if (nf_x == N - 1) sh_hend = h + 1;
+            }
+            __syncthreads();
+            const int hend = sh_hend >= 0 ? sh_hend : qn;    // fewer than N unfinished entries: the whole queue was walked
+            if (fin && h < hend) { finl[fin_x] = h; atomicMax(&sh_nfin, fin_x + 1); }
+            __syncthreads();
+            if (tid == 0) {
+                int fn = s.f_n[line], ftot = s.f_total[line];
+                double* fkey = s.f_key + (long long)line * s.f_cap;
+                int* fid = s.f_id + (long long)line * s.f_cap;
+                for (int f = 0; f < sh_nfin; ++f) {          // '\n': finished hypothesis -> final_beam (s2s:1402)
+                    const int hh = finl[f];
+                    const int id = pop_id[hh];
+                    const double key = pop_key[hh];
+                    ++ftot;
+                    int ppos = fn;
+                    while (ppos > 0 && before(key, id, fkey[ppos - 1], fid[ppos - 1])) --ppos;
+                    if (ppos < s.f_cap) {
+                        const int last = fn < s.f_cap ? fn : s.f_cap - 1;
+                        for (int q = last; q > ppos; --q) { fkey[q] = fkey[q - 1]; fid[q] = fid[q - 1]; }
+                        fkey[ppos] = key; fid[ppos] = id;
+                        if (fn < s.f_cap) ++fn;
+                    }
+                }
+                int done = 0;
+                if (nb == 0) done = 1;                                                 // s2s:1416
+                else if (ftot > p.width_out && (fn > 0 ? fkey[0] : 0.0) > sh_b0) done = 1;   // s2s:1418-1420
+                if (ftot != s.f_total[line]) { s.f_n[line] = fn; s.f_total[line] = ftot; }
+                s.q_n[line] = qn - hend; s.q_n[s.B + line] = hend;
+                sh_nb = nb; sh_done = done;
+                if (done) { s.line_done[line] = 1; s.nact[line] = 0; atomicSub(s.active_lines, 1); }
+                else s.nact[line] = nb;
+            }
+        }
+    }
+    if (!walked && tid == 0) {
         int nb = 0, h = 0;
         int fn = s.f_n[line], ftot = s.f_total[line];
         double* fkey = s.f_key + (long long)line * s.f_cap;
@@ -526,7 +592,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
     if (sh_done) return;
     BPROF(5);
     const int nb = sh_nb;
-    // next step's inputs: fed-back scores with the better siblings reset (s2s:1515-1520); one wave per row
+    // next step's inputs: fed-back scores with the better siblings reset (s2s:1515-1520); one wave per row.  Wide beams: as a grid
+    // over all rows of all lines behind this kernel (beam_inputs_kernel) -- one workgroup copying its line's 256 rows took 55 us.
+    if (!SPLIT)
     for (int j = wave; j < N; j += NWV) {
         const int r = line * N + j;
         float* pin = s.p_in + (long long)r * Vp;
@@ -549,6 +617,33 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(VPL <=
     if (tid == 0 && line < 4096) { g_beam_wg[3 * line + 1] = (unsigned)wall_clock64(); g_beam_wg[3 * line + 2] = (unsigned)nnew; }
 #endif
 }
+// Wide beams: the next step's input rows (the last part of beam_step_kernel) as a grid of one wave per row.
+__global__ __launch_bounds__(512) void beam_inputs_kernel(const BeamState s, const BeamParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 8 + wave;
+    if (r >= s.R) return;
+    const int N = p.N, line = r / N, j = r - line * N;
+    const int step = s.step_ptr ? *s.step_ptr : s.step_imm;
+    if (s.line_done[line] || step + 1 >= s.S) return;
+    const int Vp = (s.V + 31) & ~31;
+    const int CMAX = (p.width_in < s.V ? p.width_in : s.V) + 1;
+    const long long nbase = (long long)line * s.node_cap;
+    float* pin = s.p_in + (long long)r * Vp;
+    if (j < s.nact[line]) {
+        const int id = s.beam_node[line * N + j];
+        const int exp = s.n_exp[nbase + id];
+        const int k = s.n_k[nbase + id];
+        const float* src = s.p_base + (long long)exp * Vp;
+        const short* cr = s.created + (long long)exp * CMAX;
+        for (int v = lane; v < Vp; v += 64) pin[v] = src[v];
+        for (int q = lane; q < k; q += 64) pin[(int)cr[q]] = 0.f;       // behind the copy, in program order of one wave
+        if (lane == 0) s.prev[r] = exp;
+    } else {
+        for (int v = lane; v < Vp; v += 64) pin[v] = 0.f;
+        if (lane == 0) s.prev[r] = line * N;
+    }
+}
+
 // LDS plan of one launch: sort capacity (new keys held at once), staged entries of the old queue, bytes.
 size_t beam_lds_bytes(int N, int width_in, int V, int q_cap, int* sort_cap, int* q_stage, int* pop_cap) {
     const int cm = (width_in < V ? width_in : V) + 1;
@@ -577,7 +672,8 @@ void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t strea
     const bool split = huge && s.rowrec != nullptr;
 #define CASV_BEAM_LAUNCH(VPL_, NWV_) hipLaunchKernelGGL((beam_step_kernel<VPL_, NWV_, false>), dim3(s.B), dim3(64 * NWV_), lds, stream, s, pp)
 #define CASV_BEAM_SPLIT(VPL_) do { hipLaunchKernelGGL((beam_expand_kernel<VPL_>), dim3((s.R + 7) / 8), dim3(512), 0, stream, s, pp); \
-                                   hipLaunchKernelGGL((beam_step_kernel<VPL_, 16, true>), dim3(s.B), dim3(1024), lds, stream, s, pp); } while (0)
+                                   hipLaunchKernelGGL((beam_step_kernel<VPL_, 16, true>), dim3(s.B), dim3(1024), lds, stream, s, pp); \
+                                   hipLaunchKernelGGL(beam_inputs_kernel, dim3((s.R + 7) / 8), dim3(512), 0, stream, s, pp); } while (0)
     if (vpl <= 4) { if (split) CASV_BEAM_SPLIT(4); else if (huge) CASV_BEAM_LAUNCH(4, 16); else if (wide) CASV_BEAM_LAUNCH(4, 8); else CASV_BEAM_LAUNCH(4, 4); }
     else if (vpl <= 8) { if (split) CASV_BEAM_SPLIT(8); else if (huge) CASV_BEAM_LAUNCH(8, 16); else if (wide) CASV_BEAM_LAUNCH(8, 8); else CASV_BEAM_LAUNCH(8, 4); }
     else if (vpl <= 16) { if (split) CASV_BEAM_SPLIT(16); else if (huge) CASV_BEAM_LAUNCH(16, 16); else if (wide) CASV_BEAM_LAUNCH(16, 8); else CASV_BEAM_LAUNCH(16, 4); }
