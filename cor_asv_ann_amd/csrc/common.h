@@ -264,6 +264,7 @@ void launch_beam_init(const BeamState& s, const BeamParams& p, hipStream_t strea
 void launch_beam_step(const BeamState& s, const BeamParams& p, hipStream_t stream);
 #ifdef CASV_GEMM_PROF
 void gemm_prof_dump();               // diagnostic build: in-kernel cycle stamps of the 128x128 LSTM GEMM (gemm.hip)
+void skinny_prof_dump();             // ... and of the 64x128 LSTM launches (gemm_skinny.hip)
 #endif
 #ifdef CASV_BEAM_PROF
 void beam_prof_dump(int steps);      // diagnostic build: phase times of the beam step kernel (beam_kernels.hip)

@@ -998,7 +998,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     { HIPCHK(hipStreamSynchronize(m->stream)); casv::beam_prof_dump(m->S); }
 #endif
 #ifdef CASV_GEMM_PROF
-    { HIPCHK(hipStreamSynchronize(m->stream)); casv::gemm_prof_dump(); }
+    { HIPCHK(hipStreamSynchronize(m->stream)); casv::gemm_prof_dump(); casv::skinny_prof_dump(); }
 #endif
     launch_beam_extract(s, p, o, m->stream);
     HIPCHK(hipGetLastError());

@@ -27,8 +27,24 @@ constexpr int SK2 = 32, SLD = SK2 + 4;                       // k per LDS stage,
 // RB = row blocks of 32 per workgroup: 32 x 128 tiles, or 64 x 128 (round 3: every wave carries two accumulators on one B
 // fragment -- half the B traffic and LDS reads per FLOP; for launches whose 128x128 grid leaves one workgroup per CU or less
 // while 64-row tiles still give every CU two: the encoder at 1024 lines).  Same k order and MFMA sequence per element.
+#ifdef CASV_GEMM_PROF
+__device__ unsigned long long g_skinny_prof[8];
+void skinny_prof_dump() {
+    unsigned long long h[8];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_skinny_prof), sizeof(h));
+    if (h[5]) fprintf(stderr, "skinny_prof (LSTM, 64x128): %llu workgroups: prologue %.0f cyc, stages %.1f cyc/stage over %.1f stages, epilogue %.0f cyc, workgroup %.0f cyc\n",
+                      h[5], (double)h[0] / h[5], (double)h[1] / (double)h[2], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_skinny_prof), z, sizeof(z));
+}
+#endif
+
 template <int EPI, int RB>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch batch) {
+#ifdef CASV_GEMM_PROF
+    const unsigned long long sp0 = __builtin_amdgcn_s_memtime();
+    unsigned long long sp1 = sp0, sp2 = sp0;
+#endif
     constexpr int SBM = 32 * RB;
     constexpr int STAGE_FLOATS = (SBM + SBN) * SLD;          // A rows, then B rows
     __shared__ __attribute__((aligned(16))) float s_stage[2 * STAGE_FLOATS];      // 46 / 55 KB; the epilogue's gate exchange reuses it
@@ -256,6 +272,9 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
             }
     }
 
+#ifdef CASV_GEMM_PROF
+    sp1 = __builtin_amdgcn_s_memtime();
+#endif
     if (ntiles > 0) {
         // stage j + 1 goes from registers into the LDS buffer whose readers passed the last barrier, stage j + 3 starts its way
         // from global memory into the same register set, stage j is contracted; one barrier per stage
@@ -313,6 +332,9 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
         load_cell_state();
     }
 
+#ifdef CASV_GEMM_PROF
+    sp2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue ----
     if (EPI == EPI_PLAIN || g.epi_plain) {
         float* cbase = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
@@ -397,6 +419,13 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
             }
         }
     }
+#ifdef CASV_GEMM_PROF
+    if (EPI == EPI_LSTM && RB == 2 && threadIdx.x == 0) {
+        const unsigned long long sp3 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_skinny_prof[0], sp1 - sp0); atomicAdd(&g_skinny_prof[1], sp2 - sp1); atomicAdd(&g_skinny_prof[2], (unsigned long long)ntiles);
+        atomicAdd(&g_skinny_prof[3], sp3 - sp2); atomicAdd(&g_skinny_prof[4], sp3 - sp0); atomicAdd(&g_skinny_prof[5], 1ull);
+    }
+#endif
 }
 
 // rows = 32 or 64 per tile (gemm.hip's plan)
