@@ -261,7 +261,7 @@ def train_bench(args):
     # library (hipBLASLt, option "vendor_gemm"; never the default, never in `value`)
     vendor_default = int(os.environ.get('CASV_OPT_VENDOR_GEMM', '0'))
     calibration = None
-    if facade is None and not vendor_default:
+    if facade is None and not vendor_default and not os.environ.get('CASV_BENCH_NO_CALIBRATION'):    # (the variable: profiles of the default path alone)
         eng.set_option('vendor_gemm', 1)
         for _ in range(2):
             one_step()
