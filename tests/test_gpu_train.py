@@ -498,3 +498,50 @@ def test_a_recurrence_that_loses_a_workgroup_gives_up_and_the_step_falls_back(ca
     assert abs(again[0] - want[0]) < 1e-8 * abs(want[0]) and abs(again[1] - want[1]) < 2e-5 * want[1]
     eng.train_end()
     eng.close()
+
+
+def test_attention_sums_behind_the_recurrence_equal_the_atomics(tmp_path):
+    """The persistent attention-cell backward with d_enc (CASV_ATTN_DEFER=1, the default) or d_enc and du (3) summed behind the
+    recurrence gives the gradients of the variant that adds them by float atomics inside it (0): every tensor to 1e-4 of its
+    largest entry.  The switch is read once per process, so each variant runs in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import ModelConfig, make_weights, make_lines, vectorize_lines
+from oracle.decode import OracleModel
+from cor_asv_ann_amd.engine import HipEngine
+cfg = ModelConfig(depth=2, width=128, voc_size=64)
+w = make_weights(cfg, emb_scale=3.0)
+om = OracleModel(cfg, w)
+src, _ = make_lines(96, 23, 5, voc_size=64)
+tgt, _ = make_lines(96, 19, 6, voc_size=64)
+enc_in, dec_in, dec_out, wts = vectorize_lines(om, src, tgt)
+idx_of = lambda a: np.where(a.any(axis=2), a.argmax(axis=2), -1).astype(np.int32)
+eng = HipEngine(2, 128, 64)
+eng.set_weights(w)
+eng.train_begin()
+loss, norm = eng.train_step(idx_of(enc_in), None, idx_of(dec_in), idx_of(dec_out), wts, None, mode=2)
+g = eng.train_gradients()
+np.savez(sys.argv[1], loss=loss, norm=norm, **g)
+''' % root
+    out = {}
+    for mode in ('0', '1', '3'):
+        path = str(tmp_path / ('g%s.npz' % mode))
+        env = dict(os.environ, CASV_ATTN_DEFER=mode)
+        p = subprocess.run([sys.executable, '-c', script, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        with np.load(path) as f:
+            out[mode] = {k: f[k] for k in f.files}
+    ref = out['0']
+    for mode in ('1', '3'):
+        got = out[mode]
+        assert abs(float(got['loss']) - float(ref['loss'])) < 1e-6 * abs(float(ref['loss']))
+        assert abs(float(got['norm']) - float(ref['norm'])) < 2e-5 * float(ref['norm'])
+        for k in ref:
+            if k in ('loss', 'norm'):
+                continue
+            assert np.abs(got[k] - ref[k]).max() < 1e-4 * max(float(np.abs(ref[k]).max()), 1e-6 * float(ref['norm'])) + 1e-7, (mode, k)
