@@ -572,7 +572,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         }
     }
 #ifdef CASV_GEMM_PROF
+#ifdef CASV_GEMM_PROF_PLAIN
+    if (EPI == EPI_PLAIN && KS == 1 && threadIdx.x == 0 && ptiles > 0) {
+#else
     if (EPI == EPI_LSTM && KS == 1 && threadIdx.x == 0 && ptiles > 0) {
+#endif
         const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
         atomicAdd(&g_gemm_prof[0], pt1 - pt0); atomicAdd(&g_gemm_prof[1], pt2 - pt1); atomicAdd(&g_gemm_prof[2], (unsigned long long)ptiles);
         atomicAdd(&g_gemm_prof[3], pt3 - pt2); atomicAdd(&g_gemm_prof[4], pr2 - pr1); atomicAdd(&g_gemm_prof[5], 1ull);

@@ -198,6 +198,13 @@ static GemmArgs plain_gemm(const float* A, long long lda, int M, int K, const fl
 // A plain contraction over the whole sequence (thousands of rows, nothing fused): through the vendor library when that is switched
 // on and has a solution for the shape (vendor_gemm.hip), else gemm.hip.
 static void run_plain(casv_model* m, GemmArgs& g) {
+#ifdef CASV_GEMM_PROF_PLAIN
+    {   // diagnostic build: stamps of every plain whole-sequence contraction, one line per launch (M, N, K)
+        (void)hipStreamSynchronize(m->stream);
+        casv::gemm_prof_dump();
+        fprintf(stderr, "plain gemm M=%d N=%d K=%d accumulate=%d\n", g.M, g.N, g.Ktot, g.accumulate);
+    }
+#endif
     if (m->vendor_gemm && g.nseg == 1 && !g.a[0].rows && !g.step_ptr && g.M >= 4096 && g.a[0].width == g.Ktot && g.a[0].koff == 0) {
         hipEvent_t ev{};
         m->prof_begin(PC_GEMM, 2.0 * g.M * (double)g.N * g.Ktot, 4.0 * ((double)g.M * g.Ktot + (double)g.N * g.Ktot + (double)g.M * g.N), ev);
