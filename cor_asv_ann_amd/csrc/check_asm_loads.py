@@ -16,7 +16,7 @@ import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT = ['gemm.hip', 'gemm_skinny.hip', 'gemm_tn.hip', 'gemm_bwd.hip', 'train_persist.hip', 'train_persist_bwd.hip', 'train_persist_top.hip', 'train_persist_topb.hip']
+DEFAULT = ['gemm.hip', 'gemm_split.hip', 'gemm_skinny.hip', 'gemm_tn.hip', 'gemm_bwd.hip', 'train_persist.hip', 'train_persist_bwd.hip', 'train_persist_top.hip', 'train_persist_topb.hip']
 LOAD = re.compile(r'global_load_dword(x2|x3|x4)? v(?:\[(\d+):(\d+)\]|(\d+))')
 REG = re.compile(r'v\[(\d+):(\d+)\]|\bv(\d+)\b')
 

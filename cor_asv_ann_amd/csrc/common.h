@@ -151,6 +151,12 @@ void vendor_gemm_release(hipStream_t stream);         // frees the vendor path's
 bool gemm_is_skinny(int epi, const GemmBatch& b);     // which tile shape launch_gemm_batch will pick
 // tile shape of the GEMM launches: -1 = by size (default), 0 = always 128x128, 1 = always 32x128 (same results)
 void set_gemm_tile_mode(int mode);
+// experiment, off by default: 128x128-tile launches contract bf16-split operands (three bf16 per fp32 value, six products, fp32
+// accumulation) on the bf16 matrix instruction -- fp32-accurate sums, not the bit pattern of the fp32-input kernels
+void set_gemm_split_bf16(int on);          // 0 off, 1 = 128x128 tiles (gemm.hip), 2 = 256x256 tiles where a job fills the chip (gemm_split.hip)
+bool gemm_split256_wants(int epi, const GemmArgs& g);
+bool launch_gemm_split256(int epi, const GemmBatch& b, hipStream_t stream);     // false: not launched (the caller takes another path)
+int gemm_split_bf16();
 
 // ---- small kernels (decode_kernels.hip) ----
 struct AttnArgs {

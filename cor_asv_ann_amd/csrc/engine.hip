@@ -1200,6 +1200,7 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
         if (value < -1 || value > 2) return fail(CASV_ERR_ARG, "tile must be -1 (by size), 0 (128x128), 1 (32x128) or 2 (64x128 where there is no split-K)");
         set_gemm_tile_mode((int)value); return CASV_OK;
     }
+    if (!strcmp(key, "split_bf16")) { set_gemm_split_bf16((int)value); return CASV_OK; }   // process-wide experiment (gemm.hip)
     return fail(CASV_ERR_ARG, "unknown option '%s'", key);
 }
 

@@ -24,6 +24,10 @@ namespace casv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // Diagnostic build (-DCASV_GEMM_PROF): thread 0 of every workgroup of the 128x128 LSTM kernel adds its shader-clock cycles
 // in prologue / steady-state loop / epilogue, the loop's tile count and its wall-clock ticks (10 ns) to g_gemm_prof;
@@ -55,6 +59,11 @@ constexpr int TILE_FLOATS = 128 * LDW;               // one operand tile
 constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;
 constexpr int CELL_LDS_BYTES = 128 * 128;            // LSTM epilogue: the tile's previous cell state, [half][row][16 floats]
 constexpr int STASH_LDS_BYTES = 256 * 6 * 8;         // per thread: row pointers that wait for their turn outside the register file
+// SPLIT variant (option split_bf16, an experiment -- see the comment in front of gemm_tile): an operand tile lies in LDS as three
+// bf16 planes of 128 rows x 16 k (32-byte rows, the two 16-byte halves of a row swapped where bit 4 of the row is set: conflict-free
+// for ds_read_b128's 16-lane groups without padding)
+constexpr int SPLIT_PLANE_BYTES = 128 * 32;
+constexpr int SPLIT_BUF_FLOATS = 6 * SPLIT_PLANE_BYTES / 4;     // A planes 0..2, B planes 0..2
 
 // Software pipeline (per wave, so that ONE wave keeps its SIMD's matrix pipe busy and the two waves
 // of a SIMD do not have to be out of phase to cover each other):
@@ -69,7 +78,17 @@ constexpr int STASH_LDS_BYTES = 256 * 6 * 8;         // per thread: row pointers
 // small-M recurrent GEMMs (M = 512 gives only 64 workgroups).  Inference keeps KS = 1 so that a row's sum order never
 // depends on the batch it sits in.
 // Tile (bm, bn) of job g by the calling workgroup; split-K part zidx of nsplit.
-template <int EPI, int KS>
+//
+// SPLIT (KS = 1 only; option split_bf16, a measured experiment and NOT the default arithmetic): every fp32 operand value is taken
+// apart into three bf16 values x = x0 + x1 + x2 (round to nearest, each remainder exact in fp32, so the sum is exact) while its tile
+// is staged into LDS, and a K tile is contracted as six v_mfma_f32_32x32x16_bf16 products per 32x32 block with fp32 accumulation --
+// a0.b2, a1.b1, a0.b1, a2.b0, a1.b0, a0.b0; the three dropped products are below 2^-25 |a||b| -- at 6/16 of the matrix-pipe time of
+// the fp32-input instruction.  The sums are fp32-accurate but NOT the k-ordered fmaf chain of the other kernels: results agree with
+// them to rounding, not bit for bit.  Fragment registers roll instead of being double-buffered: a plane's fragments of tile kt + 1
+// are read into the registers of tile kt as soon as their last product has issued (B planes 2 and 1 and A plane 0 behind the
+// tile's barrier, B plane 0 at the head of the next tile), so one barrier per tile still separates every LDS buffer's reads from
+// the stores that refill it.
+template <int EPI, int KS, bool SPLIT = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const int bn, const int zidx, const int nsplit, float* smem_all) {
 #ifdef CASV_GEMM_PROF
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
@@ -77,7 +96,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 #endif
     const int grp = KS > 1 ? (threadIdx.x >> 8) : 0;
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    float* smem = smem_all + grp * (2 * 2 * TILE_FLOATS);
+    static_assert(!SPLIT || KS == 1, "the bf16-split variant has no wave-group split-K");
+    constexpr int BUF_FLOATS = SPLIT ? SPLIT_BUF_FLOATS : 2 * TILE_FLOATS;      // one LDS buffer: an A tile and a B tile
+    float* smem = smem_all + grp * (2 * BUF_FLOATS);
     const int l31 = lane & 31, lh = lane >> 5;
     // wave-uniform by construction; say so (the value arrives through a vector load)
     const int step = __builtin_amdgcn_readfirstlane(g.step_ptr ? *g.step_ptr : g.step_imm);
@@ -221,7 +242,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     int rleft = 0, rseg = 0;
     // (the gathered segments' row pointers -- and the cell state's -- wait in LDS for their turn instead of in a dozen registers
     // through the whole loop; the B rows are K-contiguous: a scalar step re-bases them)
-    const float** const rstash = reinterpret_cast<const float**>(smem_all + KS * (2 * 2 * TILE_FLOATS) + CELL_LDS_BYTES / 4) + 6 * tid;
+    const float** const rstash = reinterpret_cast<const float**>(smem_all + KS * (2 * BUF_FLOATS) + CELL_LDS_BYTES / 4) + 6 * tid;
     auto run_set = [&](int kt_rel) {                       // position the running pointers at tile kt_rel
         const int kt = kt_rel * KS + grp + kt_begin;
         const long long m1 = (kt >= c0 && kt < c1) ? -1LL : 0LL, m2 = (kt >= c1) ? -1LL : 0LL;
@@ -265,6 +286,55 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         *reinterpret_cast<f32x4*>(sa) = gt.a[0]; *reinterpret_cast<f32x4*>(sa + 64 * LDW) = gt.a[1];
         *reinterpret_cast<f32x4*>(sb) = gt.b[0]; *reinterpret_cast<f32x4*>(sb + 64 * LDW) = gt.b[1];
     };
+    // SPLIT: x = x0 + x1 + x2 in bf16 (round to nearest; the remainders are exact), four k of a row at a time -> 8 bytes per plane
+#ifndef CASV_ABLM
+#define CASV_ABLM 0         // timing-only builds of the SPLIT variant (wrong results), a bit mask: 1 no split arithmetic, 2 no LDS stores, 4 no global loads, 8 no barrier, 16 no fragment reads
+#endif
+    auto split4 = [&](const f32x4 x, u32x2& p0, u32x2& p1, u32x2& p2, const bool isb) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (CASV_ABLM & 1) {
+                p0[h] = __float_as_uint(x[2 * h]); p1[h] = __float_as_uint(x[2 * h + 1]); p2[h] = p0[h] ^ p1[h];
+                continue;
+            }
+            const f32x2 v = {x[2 * h], x[2 * h + 1]};
+            const unsigned q0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+            const f32x2 r1 = v - f32x2{__uint_as_float(q0 << 16), __uint_as_float(q0 & 0xffff0000u)};
+            const unsigned q1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+            const f32x2 r2 = r1 - f32x2{__uint_as_float(q1 << 16), __uint_as_float(q1 & 0xffff0000u)};
+            p0[h] = q0; p1[h] = q1; p2[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+        }
+    };
+    // (staging rows r0 and r0 + 64 share bit 4: one offset serves both)
+    const int st_off = r0 * 32 + ((((kc >> 1) ^ (r0 >> 4)) & 1) * 16) + (kc & 1) * 8;
+    auto store_tile_split = [&](const GTile& gt, int buf, const bool opa = true, const bool opb = true) {
+        if (CASV_ABLM & 2) { asm volatile("" :: "v"(gt.a[0]), "v"(gt.a[1]), "v"(gt.b[0]), "v"(gt.b[1])); return; }
+        char* base = reinterpret_cast<char*>(smem + buf * BUF_FLOATS) + st_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x2 p0, p1, p2;
+            if (opa) {
+                split4(gt.a[i], p0, p1, p2, false);
+                *reinterpret_cast<u32x2*>(base + i * 64 * 32) = p0;
+                *reinterpret_cast<u32x2*>(base + SPLIT_PLANE_BYTES + i * 64 * 32) = p1;
+                *reinterpret_cast<u32x2*>(base + 2 * SPLIT_PLANE_BYTES + i * 64 * 32) = p2;
+            }
+            if (opb) {
+                split4(gt.b[i], p0, p1, p2, true);
+                *reinterpret_cast<u32x2*>(base + 3 * SPLIT_PLANE_BYTES + i * 64 * 32) = p0;
+                *reinterpret_cast<u32x2*>(base + 4 * SPLIT_PLANE_BYTES + i * 64 * 32) = p1;
+                *reinterpret_cast<u32x2*>(base + 5 * SPLIT_PLANE_BYTES + i * 64 * 32) = p2;
+            }
+        }
+    };
+    // a lane's 8 k of its row: the 16-byte half lh (k = 8 lh .. 8 lh + 7, the same for both operands)
+    const int fr_off = l31 * 32 + (((lh ^ (l31 >> 4)) & 1) * 16);
+    auto frag_a = [&](int buf, int plane) {
+        return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(smem + buf * BUF_FLOATS) + plane * SPLIT_PLANE_BYTES + wave * 32 * 32 + fr_off);
+    };
+    auto frag_b = [&](int buf, int plane, int c) {
+        return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(smem + buf * BUF_FLOATS) + (3 + plane) * SPLIT_PLANE_BYTES + c * 32 * 32 + fr_off);
+    };
     const int a_off = (wave * 32 + l31) * LDW + 4 * lh;
     const int b_off = TILE_FLOATS + l31 * LDW + 4 * lh;
     struct Frag { f32x4 a[2]; f32x4 b[4][2]; };
@@ -304,7 +374,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     // and 23 000 when requested behind the loop instead; 4-byte-per-lane accesses are what the memory pipeline is slowest at.
     // cell-state area behind the tile buffers: [half j of the 128-byte row][row][16 floats], the image a wave's LDS-DMA writes
     // (lane L -> 16 bytes at base + 16 L: rows wave * 16 + L / 4, chunk L % 4)
-    float* const cs = smem_all + KS * (2 * 2 * TILE_FLOATS);
+    float* const cs = smem_all + KS * (2 * BUF_FLOATS);
     auto cell_dma = [&](int i, int j) {
         const float* src = rstash[4 + i] + 16 * j;
         const unsigned dst = __builtin_amdgcn_readfirstlane(
@@ -327,8 +397,59 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 #ifdef CASV_GEMM_PROF
     CASV_STAMP(pc)
 #endif
-    if (ntiles > 0) store_tile(g0, 0);
-    if (ntiles > 1) store_tile(g1, 1);
+    if constexpr (SPLIT) {
+        if (ntiles > 0) store_tile_split(g0, 0);
+        if (ntiles > 1) store_tile_split(g1, 1);
+    } else {
+        if (ntiles > 0) store_tile(g0, 0);
+        if (ntiles > 1) store_tile(g1, 1);
+    }
+    // SPLIT: rolling fragment registers -- B planes [block][plane], A plane 0 double-buffered (it serves a tile's first and last product)
+    bf16x8 sb[4][3], sa0x, sa0y, sa1, sa2;
+    auto split_first_frags = [&]() {            // what a tile expects to find in registers: B planes 2 and 1, all of A (tile 0, buffer 0)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sb[c][2] = frag_b(0, 2, c); sb[c][1] = frag_b(0, 1, c); }
+        sa0x = frag_a(0, 0); sa1 = frag_a(0, 1); sa2 = frag_a(0, 2);
+    };
+#define CASV_SPLIT_MMA(A, P)                                                              \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                      \
+        acc[c_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, sb[c_][P], acc[c_], 0, 0, 0);
+    // (scheduling fence that vector arithmetic may cross -- the split's arithmetic finds its own place between the
+    // products -- while matrix, LDS and memory instructions stay on their side: left to itself the compiler issues a plane's
+    // fragment reads two products ahead of their first use and every tile waits for the LDS twice)
+#define CASV_SPLIT_PIN __builtin_amdgcn_sched_barrier(0x2);
+    // One K tile of the SPLIT variant.  FULL: steady state (tiles KT+1..KT+4 exist, hidden loads, no conditionals).
+#define CASV_SPLIT_TILE(AC, AN, G, KT, FULL)                                              \
+    {                                                                                     \
+        const bool have_ = FULL || (KT) < ntiles, next_ = FULL || (KT) + 1 < ntiles;      \
+        const bool reads_ = !(FULL && (CASV_ABLM & 16)), loads_ = !(CASV_ABLM & 4);       \
+        if (FULL && loads_) asm volatile("s_waitcnt vmcnt(4)" : "+v"(G.a[0]), "+v"(G.a[1]), "+v"(G.b[0]), "+v"(G.b[1]));  \
+        if (have_) {                                                                      \
+            if (reads_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) sb[c_][0] = frag_b((KT) & 1, 0, c_);   \
+            if (FULL) CASV_SPLIT_PIN                                                      \
+            CASV_SPLIT_MMA(AC, 2) CASV_SPLIT_MMA(sa1, 1) CASV_SPLIT_MMA(AC, 1)            \
+        }                                                                                 \
+        if (FULL) CASV_SPLIT_PIN        /* the 12 products stay in front of the barrier: plane 0's reads land under them */ \
+        if (!(FULL && (CASV_ABLM & 8))) __syncthreads();                                  \
+        if (next_ && reads_) {                                                            \
+            _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) { sb[c_][2] = frag_b(((KT) + 1) & 1, 2, c_); sb[c_][1] = frag_b(((KT) + 1) & 1, 1, c_); }  \
+            AN = frag_a(((KT) + 1) & 1, 0);                                               \
+        }                                                                                 \
+        if (FULL) CASV_SPLIT_PIN                                                          \
+        if (have_) CASV_SPLIT_MMA(sa2, 0)                                                 \
+        if (FULL) CASV_SPLIT_PIN                                                          \
+        if (next_ && reads_) sa2 = frag_a(((KT) + 1) & 1, 2);                             \
+        if (FULL || (KT) + 2 < ntiles) store_tile_split(G, (KT) & 1, true, false);        \
+        if (FULL) CASV_SPLIT_PIN                                                          \
+        if (have_) CASV_SPLIT_MMA(sa1, 0)                                                 \
+        if (FULL) CASV_SPLIT_PIN                                                          \
+        if (next_ && reads_) sa1 = frag_a(((KT) + 1) & 1, 1);                             \
+        if (FULL || (KT) + 2 < ntiles) store_tile_split(G, (KT) & 1, false, true);        \
+        if (FULL) { if (loads_) load_tile_run(G); } else if ((KT) + 4 < ntiles) load_tile_run_plain(G);   \
+        if (FULL) CASV_SPLIT_PIN                                                          \
+        if (have_) CASV_SPLIT_MMA(AC, 0)                                                  \
+        if (FULL) run_advance();                                                          \
+    }
 
     // Steady state (tiles kt+1..kt+4 exist, no conditionals): while the 32 MFMAs of tile kt issue from FC,
     //   LDS[kt&1] <- G (tile kt+2, requested two steps ago; the buffer's old content, tile kt, sits in FC)
@@ -392,7 +513,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
             issue_tile_asm(g0, qa0, qa1, qb0, qb1); issue_tile_asm(g1, ra0, ra1, rb0, rb1);
         }
         __syncthreads();
-        read_frags(f0, 0);
+        if constexpr (SPLIT) split_first_frags(); else read_frags(f0, 0);
         // The first steady-state step stores tile 2 into LDS buffer 0: every wave must have taken its fragments of tile 0
         // out of it first.  (Without this barrier only the latency of the tile-2 global loads kept a fast wave's store
         // behind a slow wave's read -- not enough once other kernels share the CU.)
@@ -401,6 +522,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime();
 #endif
         if (KS == 1) run_set(4);                    // the first steady-state tile requests tile 4
+        if constexpr (SPLIT) {
+            for (; kt + 5 < nt_min; kt += 2) {
+                CASV_SPLIT_TILE(sa0x, sa0y, g0, kt, true)
+                CASV_SPLIT_TILE(sa0y, sa0x, g1, kt + 1, true)
+            }
+        } else
         for (; kt + 5 < nt_min; kt += 2) {          // both wave groups have all the tiles of the steady state
             CASV_TILE_FULL(f0, f1, g0, kt)
             CASV_TILE_FULL(f1, f0, g1, kt + 1)
@@ -426,7 +553,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         if (ntiles > 3) load_tile(g1, 3);
         if (KS == 1 && ntiles > 4) run_set(4);
         __syncthreads();
-        if (ntiles > 0) read_frags(f0, 0);
+        if constexpr (SPLIT) { if (ntiles > 0) split_first_frags(); } else { if (ntiles > 0) read_frags(f0, 0); }
         __syncthreads();
     }
     if (cstage && !c_late) {        // (short K, odd tile counts, wave-group split-K: through registers, stored into the same image)
@@ -436,11 +563,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
             for (int j = 0; j < 2; ++j)
                 *reinterpret_cast<f32x4*>(cs + (j * 128 + r0 + 64 * i) * 16 + 4 * kc) = *reinterpret_cast<const f32x4*>(cptr(i) + 16 * j);
     }
+    if constexpr (SPLIT) {
+        for (; kt + 1 < nt_max; kt += 2) {
+            CASV_SPLIT_TILE(sa0x, sa0y, g0, kt, false)
+            CASV_SPLIT_TILE(sa0y, sa0x, g1, kt + 1, false)
+        }
+        if (kt < nt_max) CASV_SPLIT_TILE(sa0x, sa0y, g0, kt, false)
+    } else {
     for (; kt + 1 < nt_max; kt += 2) {          // same barrier count for both groups
         CASV_TILE_STEP(f0, f1, g0, kt)
         CASV_TILE_STEP(f1, f0, g1, kt + 1)
     }
     if (kt < nt_max) CASV_TILE_STEP(f0, f1, g0, kt)
+    }
+#undef CASV_SPLIT_TILE
+#undef CASV_SPLIT_PIN
+#undef CASV_SPLIT_MMA
 #undef CASV_TILE_STEP
 #undef CASV_TILE_FULL
 
@@ -588,7 +726,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 #endif
 }
 
-template <int EPI, int KS>
+template <int EPI, int KS, bool SPLIT = false>
 __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const GemmArgs& g = batch.g[blockIdx.y];
@@ -605,26 +743,33 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_kernel(const GemmBatch batch
         bm = (xcd / xc) * pr + local / pc;
         bn = (xcd % xc) * pc + local % pc;
     }
-    gemm_tile<EPI, KS>(g, bm, bn, blockIdx.z, gridDim.z, smem_all);
+    gemm_tile<EPI, KS, SPLIT>(g, bm, bn, blockIdx.z, gridDim.z, smem_all);
 }
 
-template <int EPI, int KS>
+template <int EPI, int KS, bool SPLIT = false>
 static void launch_one(const GemmBatch& bb, int blocks, int ksplit, hipStream_t stream) {
+    // (CASV_DEBUG_LDS_PAD: measurement aid -- extra dynamic LDS, e.g. 16384 leaves room for ONE workgroup per CU)
+    static const int lds_pad = [] { const char* e = getenv("CASV_DEBUG_LDS_PAD"); return e ? atoi(e) : 0; }();
+    const int lds_bytes = (SPLIT ? 2 * SPLIT_BUF_FLOATS * 4 : GEMM_LDS_BYTES * KS) + CELL_LDS_BYTES + STASH_LDS_BYTES + lds_pad;
     // the attribute belongs to the (function, device) pair: a second model on another device needs its own
     static bool attr_set[64] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GEMM_LDS_BYTES * KS + CELL_LDS_BYTES + STASH_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, KS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<EPI, KS>), dim3(blocks, bb.count, ksplit), dim3(256 * KS),
-                       GEMM_LDS_BYTES * KS + CELL_LDS_BYTES + STASH_LDS_BYTES, stream, bb);
+    hipLaunchKernelGGL((gemm_kernel<EPI, KS, SPLIT>), dim3(blocks, bb.count, ksplit), dim3(256 * KS), lds_bytes, stream, bb);
 }
 
-static int g_tile_mode = -1;       // -1 by size, 0 = 128x128, 1 = 32x128
+static int g_tile_mode = [] { const char* e = getenv("CASV_GEMM_TILE"); return e && e[0] >= '0' && e[0] <= '2' && !e[1] ? e[0] - '0' : -1; }();   // -1 by size, 0 = 128x128, 1 = 32x128, 2 = 64x128 where possible
 void set_gemm_tile_mode(int mode) { g_tile_mode = mode; }
+// Experiment (option split_bf16 / CASV_SPLIT_BF16 = 1 or 2; off by default): launches that go as 128x128 tiles contract bf16-split
+// operands on the bf16 matrix instruction (1: gemm_tile's SPLIT variant; 2: as 256x256 tiles, gemm_split.hip, where a job fills
+// the chip that way, else as 1).  Process-wide, like the tile shape.
+static int g_split_bf16 = [] { const char* e = getenv("CASV_SPLIT_BF16"); return e && (e[0] == '1' || e[0] == '2') && !e[1] ? e[0] - '0' : 0; }();
+void set_gemm_split_bf16(int on) { g_split_bf16 = on < 0 ? 0 : on > 2 ? 2 : on; }
+int gemm_split_bf16() { return g_split_bf16; }
 
 static int count_ktiles(const GemmArgs& g) {
     int ktiles = 0;
@@ -725,6 +870,22 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     for (int j = 0; j < b.count; ++j)
         if (b.g[j].kgroups != 2 || count_ktiles(b.g[j]) / ksplit < 16) two = false;
     if (blocks * b.count * ksplit > 256) two = false;
+    if (g_split_bf16 && !two) {
+        if (g_split_bf16 >= 2 && ksplit == 1) {
+            // jobs that fill the chip as 256x256 tiles go to gemm_split.hip; the rest of the batch follows as a launch of its own
+            GemmBatch big{}, rest{};
+            for (int j = 0; j < b.count; ++j) {
+                if (gemm_split256_wants(epi, b.g[j])) big.g[big.count++] = b.g[j];
+                else { rest.g[rest.count] = b.g[j]; if (epi == EPI_PLAIN) rest.g[rest.count].epi_plain = 0; ++rest.count; }
+            }
+            if (big.count && launch_gemm_split256(epi, big, stream)) {
+                if (rest.count) launch_gemm_batch(epi, rest, stream);
+                return;
+            }
+        }
+        if (epi == EPI_LSTM) launch_one<EPI_LSTM, 1, true>(bb, blocks, ksplit, stream); else launch_one<EPI_PLAIN, 1, true>(bb, blocks, ksplit, stream);
+        return;
+    }
     if (epi == EPI_LSTM) { if (two) launch_one<EPI_LSTM, 2>(bb, blocks, ksplit, stream); else launch_one<EPI_LSTM, 1>(bb, blocks, ksplit, stream); }
     else { if (two) launch_one<EPI_PLAIN, 2>(bb, blocks, ksplit, stream); else launch_one<EPI_PLAIN, 1>(bb, blocks, ksplit, stream); }
 }
