@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
         const f32x2 v = {x[2 * h], x[2 * h + 1]};
         if (CASV_ABLM & 1) { q0 = __float_as_uint(v[0]); r1 = v; return; }
         q0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-        r1 = v - f32x2{__uint_as_float(q0 << 16), __uint_as_float(q0 & 0xffff0000u)};
+        r1 = v - f32x2{__uint_as_float(q0 << 16), __uint_as_float(q0 & 0xffff0000u)};       // (two v_add_f32: v_pk_add_f32 measured slower)
     };
     auto split_l23 = [&](const unsigned q0, const f32x2 r1, int h, u32x2& p0, u32x2& p1, u32x2& p2) {
         if (CASV_ABLM & 1) { p0[h] = q0; p1[h] = __float_as_uint(r1[0]); p2[h] = __float_as_uint(r1[1]); return; }

@@ -234,7 +234,14 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
  * "eos" = vocabulary index of the end-of-line character '\n' (default 1: '' and '\n' sort first, seq2seq.py:580);
  * "tile" (process-wide; alias "skinny") = tile shape of the GEMM launches: -1 by size (default), 0 always 128x128,
  * 1 always 32x128, 2 = 64x128 wherever there is no split-K -- a measurement/test switch, the values computed are the same bit
- * for bit. */
+ * for bit;
+ * "split_bf16" (process-wide; EXPERIMENT, default 0 = off; also CASV_SPLIT_BF16 in the environment when the library is loaded):
+ * 1 / 2 = GEMM launches that go as 128x128 tiles take every fp32 operand value apart into three bf16 values (round to
+ * nearest, exact sum) and contract six products per K tile on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (1: as 128x128
+ * tiles, csrc/gemm.hip; 2: as 256x256 tiles where a job fills the chip that way, csrc/gemm_split.hip).  fp32-accurate sums
+ * at 6/16 of the matrix-pipe time, but another summation order than the fp32-input kernels: results agree with them (and with
+ * the oracle, within the tolerances of tests/) to rounding, not bit for bit, and a row's low-order bits then depend on which
+ * kernel the batch size selects. */
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 /* Statistics of the last call (tests): "beam_max_new_keys" = most child hypotheses one line created in one search
  * iteration of the last casv_decode_beam; "beam_sort_capacity" = how many of them are sorted in LDS at once (more are

@@ -1,0 +1,90 @@
+"""The split-bf16 EXPERIMENT (library option `split_bf16`, off by default; csrc/gemm.hip SPLIT variant = mode 1,
+csrc/gemm_split.hip = mode 2) against the oracle, on a real MI355X.
+
+With the option on, the fused LSTM GEMM takes every fp32 operand value apart into three bf16 values and contracts six
+products per K tile on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The sums are fp32-accurate but not the k-ordered
+fmaf chain of the fp32-input kernels, so the comparisons that can hold are the ones with the ORACLE (same tolerances as
+tests/test_gpu_parity.py: indices / strings / counts exact, probabilities and states rtol 2e-4 + atol 2e-6, scores 1e-4);
+the tests that compare two kernels of this library bit for bit (tile shapes, batch sizes, persistent kernels) cannot hold
+between a launch that takes the split path and one that does not, and are not repeated here -- the last test states that
+difference instead: same decisions, scores to 1e-5.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ModelConfig, make_weights
+from tests.golden.make_golden import CASES
+from tests import test_gpu_parity as parity
+
+
+@pytest.fixture
+def split_option():
+    """-> set(mode, tile=-1): switches the process-wide options; both are back at their defaults when the test ends."""
+    from cor_asv_ann_amd.engine import HipEngine
+    eng = HipEngine(1, 32, 8)
+
+    def set_(mode, tile=-1):
+        eng.set_option('split_bf16', mode)
+        eng.set_option('tile', tile)
+    try:
+        yield set_
+    finally:
+        eng.set_option('split_bf16', 0)
+        eng.set_option('tile', -1)
+        eng.close()
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_c3_short_lines_equal_the_oracle_with_split_operands(mode, split_option, golden_dir):
+    """BASELINE configs[2]'s shape end to end (depth 4, width 512, 1024 lines, N = 8) against the committed oracle fixture:
+    every line's string, length, n_found, n_steps exact, scores 1e-4, probabilities rtol 2e-4 -- unchanged test body."""
+    split_option(mode)
+    parity.test_c3_short_lines_equal_the_oracle(golden_dir)
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_full_width_decoder_steps_with_split_operands(mode, split_option):
+    """Three teacher-forced decoder steps at R = 8192 rows / depth 4 / width 512 against the oracle -- unchanged test body."""
+    split_option(mode)
+    parity.test_decoder_step_at_full_width_rows()
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_golden_fixtures_with_split_operands(name, split_option, golden_dir):
+    """The golden fixtures (encoder outputs, teacher-forced steps, exact greedy index matrix, beam results) with every GEMM
+    launch forced onto 128x128 tiles and those tiles onto the split path (ragged tiles, all three K segments, the encoder's
+    zero initial state) -- unchanged test body."""
+    split_option(1, tile=0)
+    parity.test_golden(name, golden_dir)
+
+
+@pytest.mark.parametrize('kind,mode_', [('plain', 'beam'), ('prob', 'fast'), ('confmat', 'greedy')])
+def test_correct_lines_with_split_operands(kind, mode_, split_option):
+    split_option(1, tile=0)
+    parity.test_correct_lines_equals_oracle(kind, mode_)
+
+
+def test_split_and_fp32_kernels_take_the_same_decisions(split_option, golden_dir):
+    """What changes between the two arithmetics on configs[2]'s shape: nothing that is decided (strings, lengths, step counts
+    of all 1024 lines), the scores in the sixth digit."""
+    from cor_asv_ann_amd.engine import HipEngine
+    with np.load(os.path.join(golden_dir, 'c3_beam_short.npz')) as f:
+        idx, meta = f['idx'], f['meta']
+    cfg = ModelConfig(depth=4, width=512, voc_size=256)
+    eng = HipEngine(cfg.depth, cfg.width, cfg.voc_size)
+    eng.set_weights(make_weights(cfg, emb_scale=float(meta[6])))
+    outs = []
+    for mode in (0, 1, 2):
+        split_option(mode)
+        eng.encode(idx)
+        outs.append(eng.decode_beam(batch_size=8))
+    eng.close()
+    for other in outs[1:]:
+        for k in ('idx', 'len', 'n_found', 'n_steps'):
+            assert np.array_equal(outs[0][k], other[k]), k
+        assert np.allclose(outs[0]['score'], other['score'], rtol=0, atol=1e-5)
+        assert not np.array_equal(outs[0]['score'], other['score'])       # (it IS another arithmetic: the switch did something)
