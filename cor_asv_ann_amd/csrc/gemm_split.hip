@@ -47,6 +47,11 @@ constexpr int S2_BM = 256, S2_BN = 256, S2_BK = 16;
 constexpr int S2_PLANE = 256 * 32;                 // bytes: one bf16 plane of an operand tile
 constexpr int S2_BUF = 6 * S2_PLANE;               // A planes 0..2, B planes 0..2
 constexpr int S2_CELL = 8 * 64 * 128;              // per wave: 64 rows x 32 units of the previous cell state
+#ifdef CASV_S2_CELL_LAST
+constexpr int S2_TB = 0, S2_CB = 2 * S2_BUF;
+#else
+constexpr int S2_TB = S2_CELL, S2_CB = 0;
+#endif
 constexpr int S2_LDS = S2_CELL + 2 * S2_BUF;       // [cell state | tile buffer 0 | tile buffer 1]
 
 template <int EPI>
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     const int st_off = r0 * 32 + ((((kc >> 1) ^ (r0 >> 4)) & 1) * 16) + (kc & 1) * 8;
     auto store_op = [&](const f32x4 v0, const f32x4 v1, int buf, int plane0) {
         if (CASV_ABLM & 2) { asm volatile("" :: "v"(v0), "v"(v1)); return; }
-        char* base = s2_smem + S2_CELL + buf * S2_BUF + plane0 * S2_PLANE + st_off;
+        char* base = s2_smem + S2_TB + buf * S2_BUF + plane0 * S2_PLANE + st_off;
         u32x2 p0, p1, p2;
         split4(v0, p0, p1, p2);
         *reinterpret_cast<u32x2*>(base) = p0; *reinterpret_cast<u32x2*>(base + S2_PLANE) = p1; *reinterpret_cast<u32x2*>(base + 2 * S2_PLANE) = p2;
@@ -176,18 +181,18 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     };
     auto store_row = [&](const u32x2 p0, const u32x2 p1, const u32x2 p2, int buf, int plane0, int i) {      // row r0 + 128 i
         if (CASV_ABLM & 2) { asm volatile("" :: "v"(p0), "v"(p1), "v"(p2)); return; }
-        char* base = s2_smem + S2_CELL + buf * S2_BUF + plane0 * S2_PLANE + st_off + i * 128 * 32;
+        char* base = s2_smem + S2_TB + buf * S2_BUF + plane0 * S2_PLANE + st_off + i * 128 * 32;
         *reinterpret_cast<u32x2*>(base) = p0; *reinterpret_cast<u32x2*>(base + S2_PLANE) = p1; *reinterpret_cast<u32x2*>(base + 2 * S2_PLANE) = p2;
     };
     // a lane's 8 k of its row: the 16-byte half lh (k = 8 lh .. 8 lh + 7, the same for both operands)
     const int fr_off = l31 * 32 + (((lh ^ (l31 >> 4)) & 1) * 16);
     auto frag_a = [&](int buf, int plane, int rb) {
         if (CASV_ABLM & 16) { bf16x8 z; asm volatile("" : "=v"(z)); return z; }
-        return *reinterpret_cast<const bf16x8*>(s2_smem + S2_CELL + buf * S2_BUF + plane * S2_PLANE + (wm * 64 + rb * 32) * 32 + fr_off);
+        return *reinterpret_cast<const bf16x8*>(s2_smem + S2_TB + buf * S2_BUF + plane * S2_PLANE + (wm * 64 + rb * 32) * 32 + fr_off);
     };
     auto frag_b = [&](int buf, int plane, int c) {
         if (CASV_ABLM & 16) { bf16x8 z; asm volatile("" : "=v"(z)); return z; }
-        return *reinterpret_cast<const bf16x8*>(s2_smem + S2_CELL + buf * S2_BUF + (3 + plane) * S2_PLANE + (wn * 128 + c * 32) * 32 + fr_off);
+        return *reinterpret_cast<const bf16x8*>(s2_smem + S2_TB + buf * S2_BUF + (3 + plane) * S2_PLANE + (wn * 128 + c * 32) * 32 + fr_off);
     };
 
     f32x16 acc[2][4];
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     const bool plain = EPI == EPI_PLAIN || g.epi_plain;
     const bool cfirst = !plain && sgc.first_base && step == 0;
     const bool czero = !plain && sgc.skip_first && step == 0 && !cfirst;
-    char* const cellw = s2_smem + wave * (64 * 128);        // (the cell state lies FIRST in the LDS: the LDS-DMA's base register M0 holds 16 address bits)
+    char* const cellw = s2_smem + S2_CB + wave * (64 * 128);        // (LDS-DMA destinations beyond 64 KB work too: the -DCASV_S2_CELL_LAST build, cell state at 96..160 KB, passes the same tests)
     if (!plain && !czero) {
         const float* cin = cfirst ? sgc.first_base : sgc.base + (long long)(step * sgc.step_mul + sgc.step_add) * sgc.slot_stride;
         const bool cgat = sgc.rows && !cfirst;
