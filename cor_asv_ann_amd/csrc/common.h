@@ -114,6 +114,8 @@ struct GemmArgs {
     int out_zeroed;       // PLAIN with split-K: the caller has already cleared the output (no memset per launch)
     int kgroups;          // 2 = allow the two-wave-group split-K variant (train step; changes the summation order)
     int xcd_rows;         // XCD-aware tile order: the 8 XCDs form an xcd_rows x (8/xcd_rows) grid over the tile grid (0 = off)
+    int b_static;         // Bt changes only at casv_commit_weights (inference weights): the split-bf16 experiment may keep a pre-split image of it
+    const void* Bimg;     // set by launch_gemm_split256: that image (gemm_split.hip), or nullptr
     int ksplit;           // PLAIN: 0/1 = one block per tile; n > 1 = K split over n blocks (float atomics into C);
                           // -1 = let the launcher choose (train step only: sums become order-dependent)
     // step source
@@ -155,6 +157,10 @@ void set_gemm_tile_mode(int mode);
 // accumulation) on the bf16 matrix instruction -- fp32-accurate sums, not the bit pattern of the fp32-input kernels
 void set_gemm_split_bf16(int on);          // 0 off, 1 = 128x128 tiles (gemm.hip), 2 = 256x256 tiles where a job fills the chip (gemm_split.hip)
 bool gemm_split256_wants(int epi, const GemmArgs& g);
+#ifdef CASV_S2_CLOCK
+void s2_clock_dump();
+#endif
+void gemm_split_invalidate();       // drops the pre-split weight images (call where weights change or their buffers are released)
 bool launch_gemm_split256(int epi, const GemmBatch& b, hipStream_t stream);     // false: not launched (the caller takes another path)
 int gemm_split_bf16();
 

@@ -62,6 +62,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
+    gemm_split_invalidate();
     DevBuf* bufs[] = {&m->E, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
         &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->Hc, &m->cfin,
         &m->hfin, &m->u, &m->st_a, &m->st_p, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
@@ -185,6 +186,7 @@ static int pack_dec1(casv_model* m, LstmW& dst, const std::string& prefix, int k
 extern "C" int casv_commit_weights(casv_model* m) {
     if (!m) return fail(CASV_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(m->device));
+    gemm_split_invalidate();            // (split-bf16 experiment: images of the old weights)
     for (auto& kv : m->expect)
         if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());
     const int W = m->W, C = m->C, D = m->D;
@@ -553,7 +555,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
     // shares the launch of layer 1 (a job with the plain epilogue) instead of waiting behind the lower layers
     GemmArgs gq{};
     gq.nseg = 1; gq.a[0] = hseg(m->st_h[D].as<float>(), 0);
-    gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W;
+    gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W; gq.b_static = 1;
     gq.out = mkslot(m->wq.as<float>(), W);
     gq.step_ptr = step_ptr; gq.step_imm = step_imm;
     gq.nact = live; gq.nact_group = m->skip_group;
@@ -562,7 +564,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.nseg = 2;
         g.a[0] = xseg(n);
         g.a[1] = hseg(m->st_h[n].as<float>(), xwidth(n));
-        g.Bt = m->dec[n].wt.as<float>(); g.bias = m->dec[n].bias.as<float>();
+        g.Bt = m->dec[n].wt.as<float>(); g.bias = m->dec[n].bias.as<float>(); g.b_static = 1;
         g.M = R; g.N = 4 * W; g.Ktot = xwidth(n) + W;
         g.out = mkslot(m->st_h[n].as<float>(), W, RW, 1, 1);
         g.c_in = hseg(m->st_c[n].as<float>(), 0);
@@ -600,7 +602,7 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.a[0] = xseg(D);
         g.a[1] = mkseg(m->ctx.as<float>(), C, C, xwidth(D));
         g.a[2] = hseg(m->st_h[D].as<float>(), xwidth(D) + C);
-        g.Bt = m->dec[D].wt.as<float>(); g.bias = m->dec[D].bias.as<float>();
+        g.Bt = m->dec[D].wt.as<float>(); g.bias = m->dec[D].bias.as<float>(); g.b_static = 1;
         g.M = R; g.N = 4 * W; g.Ktot = xwidth(D) + C + W;
         g.out = mkslot(m->st_h[D].as<float>(), W, RW, 1, 1);
         g.c_in = hseg(m->st_c[D].as<float>(), 0);
@@ -1163,6 +1165,7 @@ extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N
     GemmArgs g{};
     g.nseg = 1; g.a[0] = mkseg(A.as<float>(), K, K, 0, rows.as<int>());
     g.Bt = Bt.as<float>(); g.bias = bias.as<float>(); g.M = M; g.N = N; g.Ktot = K;
+    g.b_static = 1;         // (split-bf16 experiment: as the decoder's weights; the image is dropped again below)
     g.out = mkslot(C.as<float>(), lstm ? N / 4 : N);
     if (lstm) { g.c_in = mkseg(cst.as<float>(), N / 4, N / 4, 0, rows.as<int>()); g.c_out = mkslot(cst.as<float>() + (size_t)M * N / 2, N / 4); }
     hipEvent_t e0, e1;
@@ -1175,6 +1178,10 @@ extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N
     float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
     *ms_per_launch = t / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    gemm_split_invalidate();
+#ifdef CASV_S2_CLOCK
+    s2_clock_dump();
+#endif
     A.release(); Bt.release(); bias.release(); C.release(); cst.release(); rows.release();
     return CASV_OK;
 }

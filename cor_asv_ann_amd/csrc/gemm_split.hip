@@ -29,6 +29,9 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace casv {
 
@@ -43,6 +46,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// Diagnostic build (-DCASV_S2_CLOCK): workgroup 0 stamps shader clock and wall clock around its K loop; s2_clock_dump() prints
+// the shader clock the loop ran at (the bf16 matrix pipe with and without memory traffic beside it: power management).
+#ifdef CASV_S2_CLOCK
+__device__ unsigned long long g_s2_clk[4];
+void s2_clock_dump() {
+    unsigned long long h[4];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_s2_clk), sizeof(h));
+    if (h[1]) fprintf(stderr, "gemm_split256: loop of workgroup 0: %llu cycles in %llu wall ticks (10 ns) = %.3f GHz\n", h[0], h[1], (double)h[0] / (double)h[1] * 0.1);
+}
+#endif
 constexpr int S2_BM = 256, S2_BN = 256, S2_BK = 16;
 constexpr int S2_PLANE = 256 * 32;                 // bytes: one bf16 plane of an operand tile
 constexpr int S2_BUF = 6 * S2_PLANE;               // A planes 0..2, B planes 0..2
@@ -52,9 +65,14 @@ constexpr int S2_TB = 0, S2_CB = 2 * S2_BUF;
 #else
 constexpr int S2_TB = S2_CELL, S2_CB = 0;
 #endif
-constexpr int S2_LDS = S2_CELL + 2 * S2_BUF;       // [cell state | tile buffer 0 | tile buffer 1]
+constexpr int S2_LDS = S2_CELL + 2 * S2_BUF;
+constexpr int S2_BIMG_TILE = 3 * S2_PLANE;         // bytes of one (column tile, K tile) of a weight image: its three B planes as they lie in LDS       // [cell state | tile buffer 0 | tile buffer 1]
 
-template <int EPI>
+// BIMG: the B operand (weights that change only at casv_commit_weights) comes from an image in global memory that holds its
+// tiles already split, plane by plane in the LDS layout (split_image_kernel below; the same values, so results do not depend on
+// which form a launch takes): three 1-KB LDS-DMA transfers per wave and tile instead of two register loads, ~45 vector
+// instructions and three LDS stores per thread -- the staging arithmetic of a tile halves.
+template <int EPI, bool BIMG>
 __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch batch) {
     extern __shared__ __attribute__((aligned(16))) char s2_smem[];
     const GemmArgs& g = batch.g[blockIdx.y];
@@ -117,6 +135,8 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     if (rseg == 0) { ra0 = arow(0, 0); ra1 = arow(0, 1); } else if (rseg == 1) { ra0 = arow(1, 0); ra1 = arow(1, 1); } else { ra0 = arow(2, 0); ra1 = arow(2, 1); }
     const float* rb0 = g.Bt + (long long)(n0 + r0) * g.Ktot + 4 * kc + koff[rseg];
     const float* rb1 = rb0 + (long long)128 * g.Ktot;
+    // BIMG: this wave's 3 KB of the tile image of (column tile bn, K tile kt): the lane's 16 bytes of its first 1-KB piece
+    const char* rbi = BIMG ? reinterpret_cast<const char*>(g.Bimg) + ((long long)bn * (g.Ktot / S2_BK) + koff[rseg] / S2_BK) * S2_BIMG_TILE + wave * 3072 + lane * 16 : nullptr;
     auto advance = [&]() {
         ra0 += S2_BK * 4; ra1 += S2_BK * 4; rb0 += S2_BK; rb1 += S2_BK;
         if (--rleft == 0) {
@@ -131,15 +151,42 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
             } else rleft = 1 << 30;
         }
     };
-    struct GTile { f32x4 a[2], b[2]; };
-    auto request = [&](GTile& gt) {
-        if (CASV_ABLM & 4) return;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[0]) : "v"(ra0));
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[1]) : "v"(ra1));
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[0]) : "v"(rb0));
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[1]) : "v"(rb1));
+    // (the image pointer runs on its own: the planes of tile t + 2 are transferred a tile later than A's tile t + 3 is requested)
+    int bseg = rseg, bleft = rleft;
+    auto advance_b = [&]() {
+        rbi += S2_BIMG_TILE;
+        if (--bleft == 0) {
+            if (bseg == 0 && c1 > c0) {
+                bseg = 1; bleft = c1 - c0; rbi += (long long)((koff[1] - koff[0]) / S2_BK - c0) * S2_BIMG_TILE;
+            } else if (bseg <= 1 && nt > c1) {
+                const int kprev = bseg == 0 ? koff[0] + c0 * S2_BK : koff[1] + (c1 - c0) * S2_BK;
+                bseg = 2; bleft = nt - c1; rbi += (long long)((koff[2] - kprev) / S2_BK) * S2_BIMG_TILE;
+            } else bleft = 1 << 30;
+        }
     };
-#define CASV_S2_LANDED(G) { if (!(CASV_ABLM & 4)) asm volatile("s_waitcnt vmcnt(0)" : "+v"(G.a[0]), "+v"(G.a[1]), "+v"(G.b[0]), "+v"(G.b[1])); }
+    struct GTile { f32x4 a[2], b[2]; };
+    // (one statement per load: the steady state spreads a tile's memory instructions over its products -- eight waves that
+    // pass the barrier together and each issue five of them in a row queue up at the CU's one memory pipeline while the matrix
+    // pipe has nothing to do: 3 960 instead of 3 210 cycles per tile, profiles/r04_split_bf16.txt)
+    auto request_a0 = [&](GTile& gt) { if (!(CASV_ABLM & 4)) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[0]) : "v"(ra0)); };
+    auto request_a1 = [&](GTile& gt) { if (!(CASV_ABLM & 4)) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[1]) : "v"(ra1)); };
+    auto request_b0 = [&](GTile& gt) { if (!(CASV_ABLM & 4) && !BIMG) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[0]) : "v"(rb0)); };
+    auto request_b1 = [&](GTile& gt) { if (!(CASV_ABLM & 4) && !BIMG) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[1]) : "v"(rb1)); };
+    auto request = [&](GTile& gt) { request_a0(gt); request_a1(gt); request_b0(gt); request_b1(gt); };
+#define CASV_S2_LANDED(G) { if (!(CASV_ABLM & (4 | 32))) { if (BIMG) asm volatile("s_waitcnt vmcnt(0)" : "+v"(G.a[0]), "+v"(G.a[1])); \
+                            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(G.a[0]), "+v"(G.a[1]), "+v"(G.b[0]), "+v"(G.b[1])); } }
+    // BIMG: the B planes of the tile the running image pointer stands at -> LDS buffer `buf`, this wave's three 1-KB pieces
+    auto dma_b1 = [&](int buf, int j) {
+        if (CASV_ABLM & 4) return;
+        {
+            const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)s2_smem)
+                                 + (unsigned)(S2_TB + buf * S2_BUF + 3 * S2_PLANE) + (unsigned)__builtin_amdgcn_readfirstlane(wave * 3072) + (unsigned)(j * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(rbi + j * 1024), "s"(dst) : "memory");
+        }
+    };
+    auto dma_b = [&](int buf) { dma_b1(buf, 0); dma_b1(buf, 1); dma_b1(buf, 2); };
 
     // ---- staging: split and store ----
     auto split4 = [&](const f32x4 x, u32x2& p0, u32x2& p1, u32x2& p2) {
@@ -213,8 +260,8 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
 
     // ---- prologue: tiles 0 and 1 into LDS, tile 2 requested; the fragments a tile expects in registers ----
     GTile gt;
-    if (nt > 0) { request(gt); advance(); CASV_S2_LANDED(gt); store_op(gt.a[0], gt.a[1], 0, 0); store_op(gt.b[0], gt.b[1], 0, 3); }
-    if (nt > 1) { request(gt); advance(); CASV_S2_LANDED(gt); store_op(gt.a[0], gt.a[1], 1, 0); store_op(gt.b[0], gt.b[1], 1, 3); }
+    if (nt > 0) { request(gt); if (BIMG) { dma_b(0); advance_b(); } advance(); CASV_S2_LANDED(gt); store_op(gt.a[0], gt.a[1], 0, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], 0, 3); }
+    if (nt > 1) { request(gt); if (BIMG) { dma_b(1); advance_b(); } advance(); CASV_S2_LANDED(gt); store_op(gt.a[0], gt.a[1], 1, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], 1, 3); }
     if (nt > 2) { request(gt); advance(); }
     __syncthreads();
     if (nt > 0) {
@@ -239,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
         CASV_S2_FENCE                                                                                          \
         CASV_S2_MMA(1, 1) CASV_S2_MMA(0, 2) CASV_S2_MMA(0, 1)                                                  \
         CASV_S2_FENCE                                                                                          \
-        if (!(CASV_ABLM & 8)) __syncthreads(); \
+        if (!(CASV_ABLM & 8)) __syncthreads();                                                                 \
         CASV_S2_LANDED(gt);                                                                                    \
         CASV_S2_M1(0, 0, 2, 0)                                                                                 \
         fb[0][1] = frag_b(1 - PAR, 1, 0);                                                                      \
@@ -265,6 +312,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
         CASV_S2_M1(1, 1, 2, 0)                                                                                 \
         fb[1][2] = frag_b(1 - PAR, 2, 1);                                                                      \
         split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        request_a0(gt);                                                                                        \
         CASV_S2_FENCE                                                                                          \
         CASV_S2_M1(1, 2, 2, 0)                                                                                 \
         fb[2][2] = frag_b(1 - PAR, 2, 2);                                                                      \
@@ -282,6 +330,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
         CASV_S2_M1(0, 1, 1, 0)                                                                                 \
         fa[1][2] = frag_a(1 - PAR, 2, 1);                                                                      \
         split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        request_a1(gt);                                                                                        \
         CASV_S2_FENCE                                                                                          \
         CASV_S2_M1(0, 2, 1, 0)                                                                                 \
         split_l1(gt.b[0], 1, q0_, r1_);                                                                        \
@@ -308,9 +357,98 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
         CASV_S2_FENCE                                                                                          \
         CASV_S2_M1(0, 1, 0, 0)                                                                                 \
         fa[1][1] = frag_a(1 - PAR, 1, 1);                                                                      \
+        request_b0(gt);                                                                                        \
         CASV_S2_FENCE                                                                                          \
         CASV_S2_M1(0, 2, 0, 0)                                                                                 \
-        request(gt);                                                                                           \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 3, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 0, 0, 0)                                                                                 \
+        request_b1(gt);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 1, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 2, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 3, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        advance();                                                                                             \
+    }
+    // the same with the B planes from the weight image (BIMG): only A is staged through registers
+#define CASV_S2_TILE_BI(T, PAR) \
+    { \
+        u32x2 w0_, w1_, w2_; unsigned q0_; f32x2 r1_;                                                          \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) fb[c_][0] = frag_b(PAR, 0, c_);                       \
+        _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) fa[rb_][0] = frag_a(PAR, 0, rb_);                  \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_MMA(1, 1) CASV_S2_MMA(0, 2) CASV_S2_MMA(0, 1)                                                  \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_LANDED(gt);   /* (this wave's plane transfers of the previous tile too: they are read behind the barrier) */ \
+        if (!(CASV_ABLM & 8)) __syncthreads();                                                                 \
+        CASV_S2_M1(0, 0, 2, 0)                                                                                 \
+        fb[0][1] = frag_b(1 - PAR, 1, 0);                                                                      \
+        split_l1(gt.a[0], 0, q0_, r1_);                                                                        \
+        dma_b1(PAR, 0);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 1, 2, 0)                                                                                 \
+        fb[1][1] = frag_b(1 - PAR, 1, 1);                                                                      \
+        split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 2, 2, 0)                                                                                 \
+        fb[2][1] = frag_b(1 - PAR, 1, 2);                                                                      \
+        split_l1(gt.a[0], 1, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 3, 2, 0)                                                                                 \
+        fb[3][1] = frag_b(1 - PAR, 1, 3);                                                                      \
+        split_l23(q0_, r1_, 1, w0_, w1_, w2_);                                                                 \
+        store_row(w0_, w1_, w2_, PAR, 0, 0);                                                                   \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 0, 2, 0)                                                                                 \
+        fb[0][2] = frag_b(1 - PAR, 2, 0);                                                                      \
+        split_l1(gt.a[1], 0, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 1, 2, 0)                                                                                 \
+        fb[1][2] = frag_b(1 - PAR, 2, 1);                                                                      \
+        split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        request_a0(gt);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 2, 2, 0)                                                                                 \
+        fb[2][2] = frag_b(1 - PAR, 2, 2);                                                                      \
+        split_l1(gt.a[1], 1, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 3, 2, 0)                                                                                 \
+        fb[3][2] = frag_b(1 - PAR, 2, 3);                                                                      \
+        split_l23(q0_, r1_, 1, w0_, w1_, w2_);                                                                 \
+        store_row(w0_, w1_, w2_, PAR, 0, 1);                                                                   \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 0, 1, 0)                                                                                 \
+        fa[0][2] = frag_a(1 - PAR, 2, 0);                                                                      \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 1, 1, 0)                                                                                 \
+        fa[1][2] = frag_a(1 - PAR, 2, 1);                                                                      \
+        request_a1(gt);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 2, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 3, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 0, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 1, 1, 0)                                                                                 \
+        dma_b1(PAR, 1);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 2, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 3, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 0, 0, 0)                                                                                 \
+        fa[0][1] = frag_a(1 - PAR, 1, 0);                                                                      \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 1, 0, 0)                                                                                 \
+        fa[1][1] = frag_a(1 - PAR, 1, 1);                                                                      \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 2, 0, 0)                                                                                 \
+        dma_b1(PAR, 2); advance_b();                                                                           \
         CASV_S2_FENCE                                                                                          \
         CASV_S2_M1(0, 3, 0, 0)                                                                                 \
         CASV_S2_FENCE                                                                                          \
@@ -331,11 +469,12 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
         _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) fb[c_][0] = frag_b(PAR, 0, c_);                  \
         _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) fa[rb_][0] = frag_a(PAR, 0, rb_);             \
         CASV_S2_MMA(1, 1) CASV_S2_MMA(0, 2) CASV_S2_MMA(0, 1)                                             \
+        CASV_S2_LANDED(gt);     /* (unconditional: no path carries a request past a tile, whatever the checker assumes about the conditions; BIMG: the previous tile's plane transfers) */ \
         __syncthreads();                                                                                  \
+        if (BIMG && (T) + 2 < nt) { dma_b(PAR); advance_b(); }                                            \
         if (next_) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) { fb[c_][1] = frag_b(1 - PAR, 1, c_); fb[c_][2] = frag_b(1 - PAR, 2, c_); } }   \
-        CASV_S2_LANDED(gt);     /* (unconditional: no path carries a request past a tile, whatever the checker assumes about the conditions) */ \
         if ((T) + 2 < nt) {                                                                               \
-            store_op(gt.a[0], gt.a[1], PAR, 0); store_op(gt.b[0], gt.b[1], PAR, 3);                       \
+            store_op(gt.a[0], gt.a[1], PAR, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], PAR, 3);            \
             if ((T) + 3 < nt) { request(gt); advance(); }                                                 \
         }                                                                                                 \
         CASV_S2_MMA(2, 0)                                                                                 \
@@ -345,11 +484,25 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
         CASV_S2_MMA(0, 0)                                                                                 \
     }
     int t = 0;
+#ifdef CASV_S2_CLOCK
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if constexpr (BIMG) {
+        for (; t + 4 < nt; t += 2) {
+            CASV_S2_TILE_BI(t, 0)
+            CASV_S2_TILE_BI(t + 1, 1)
+        }
+    } else
     for (; t + 4 < nt; t += 2) {
         CASV_S2_TILE(t, 0)
         CASV_S2_TILE(t + 1, 1)
     }
 
+#ifdef CASV_S2_CLOCK
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        g_s2_clk[0] = __builtin_amdgcn_s_memtime() - ck0; g_s2_clk[1] = __builtin_amdgcn_s_memrealtime() - cr0;
+    }
+#endif
     // ---- previous cell state: every wave fetches the 64 rows x 32 units it will need itself, as LDS-DMA under the last tiles ----
     const bool plain = EPI == EPI_PLAIN || g.epi_plain;
     const bool cfirst = !plain && sgc.first_base && step == 0;
@@ -376,6 +529,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     }
     if (t < nt) CASV_S2_TAIL(t, 0)
 #undef CASV_S2_TILE
+#undef CASV_S2_TILE_BI
 #undef CASV_S2_TAIL
 #undef CASV_S2_M1
 #undef CASV_S2_FENCE
@@ -428,6 +582,60 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     }
 }
 
+// ---- weight images (BIMG) ----
+// One thread per four k of a row of Bt [N][K]: the same split as the staging path (bit for bit), written where that path's LDS
+// stores would put it -- tile (n / 256, k / 16), plane, row n % 256, the 16-byte halves swapped where bit 4 of the row is set.
+__global__ void split_image_kernel(const float* __restrict__ Bt, int N, int K, char* __restrict__ img) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kq4 = K / 4;
+    if (i >= (long long)N * kq4) return;
+    const int n = (int)(i / kq4), k = 4 * (int)(i % kq4);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(Bt + (long long)n * K + k);
+    u32x2 p[3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 v = {x[2 * h], x[2 * h + 1]};
+        const unsigned q0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        const f32x2 r1 = v - f32x2{__uint_as_float(q0 << 16), __uint_as_float(q0 & 0xffff0000u)};
+        const unsigned q1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+        const f32x2 r2 = r1 - f32x2{__uint_as_float(q1 << 16), __uint_as_float(q1 & 0xffff0000u)};
+        p[0][h] = q0; p[1][h] = q1; p[2][h] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+    }
+    const int r = n % S2_BN, kc = (k % S2_BK) / 4;
+    char* tile = img + ((long long)(n / S2_BN) * (K / S2_BK) + k / S2_BK) * S2_BIMG_TILE;
+    const int off = r * 32 + ((((kc >> 1) ^ (r >> 4)) & 1) * 16) + (kc & 1) * 8;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(tile + q * S2_PLANE + off) = p[q];
+}
+
+// Images are made on first use (on the launch's stream, ahead of the launch) and kept per (weight pointer, shape) until
+// gemm_split_invalidate(): called wherever weights change or their buffers go away (casv_commit_weights, casv_model_destroy).
+struct SplitImage { void* img; int N, K; };
+static std::mutex g_img_mutex;
+static std::map<std::pair<int, const float*>, SplitImage> g_images;     // key: (device, Bt)
+static const void* split_image_of(const float* Bt, int N, int K, hipStream_t stream) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_img_mutex);
+    auto it = g_images.find({dev, Bt});
+    if (it != g_images.end()) {
+        if (it->second.N == N && it->second.K == K) return it->second.img;
+        (void)hipFree(it->second.img);
+        g_images.erase(it);
+    }
+    void* img = nullptr;
+    if (hipMalloc(&img, (size_t)N * K * 6) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const long long n4 = (long long)N * (K / 4);
+    hipLaunchKernelGGL(split_image_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, Bt, N, K, reinterpret_cast<char*>(img));
+    g_images[{dev, Bt}] = SplitImage{img, N, K};
+    return img;
+}
+void gemm_split_invalidate() {
+    std::lock_guard<std::mutex> lock(g_img_mutex);
+    for (auto& kv : g_images) (void)hipFree(kv.second.img);        // (hipFree waits for the device: nothing still reads them)
+    g_images.clear();
+}
+
 // Which jobs of a launch can go as 256x256 tiles: whole tiles only, inference outputs only (no gate / second-h / precomputed-term
 // side channels of the train step), K segments in whole tiles.
 static bool split256_job_ok(int epi, const GemmArgs& g) {
@@ -467,18 +675,31 @@ bool launch_gemm_split256(int epi, const GemmBatch& b, hipStream_t stream) {
         }
         g.xcd_rows = best_xr;
     }
-    static bool attr_set[64][2] = {{false}};
+    // weight images: every job of the launch must have one (static weights, K in whole tiles)
+    static const bool images_off = [] { const char* e = getenv("CASV_SPLIT_IMAGES"); return e && e[0] == '0'; }();
+    bool bimg = !images_off;
+    for (int j = 0; j < bb.count && bimg; ++j) bimg = bb.g[j].b_static && bb.g[j].Ktot % S2_BK == 0;
+    for (int j = 0; j < bb.count && bimg; ++j) {
+        for (int i = 0; i < bb.g[j].nseg; ++i) if (bb.g[j].a[i].koff % S2_BK) bimg = false;
+        if (bimg) { bb.g[j].Bimg = split_image_of(bb.g[j].Bt, bb.g[j].N, bb.g[j].Ktot, stream); bimg = bb.g[j].Bimg != nullptr; }
+    }
+    static bool attr_set[64][4] = {{false}};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const int e = epi == EPI_LSTM ? 1 : 0;
+    const int e = (epi == EPI_LSTM ? 1 : 0) + (bimg ? 2 : 0);
+    const void* fn = e == 3 ? reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_LSTM, true>)
+                   : e == 2 ? reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_PLAIN, true>)
+                   : e == 1 ? reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_LSTM, false>)
+                            : reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_PLAIN, false>);
     if (dev < 0 || dev >= 64 || !attr_set[dev][e]) {
-        hipError_t rc = e ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_LSTM>), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS)
-                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
-        if (rc != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
         if (dev >= 0 && dev < 64) attr_set[dev][e] = true;
     }
-    if (e) hipLaunchKernelGGL((gemm_split256_kernel<EPI_LSTM>), dim3(blocks, bb.count, 1), dim3(512), S2_LDS, stream, bb);
-    else hipLaunchKernelGGL((gemm_split256_kernel<EPI_PLAIN>), dim3(blocks, bb.count, 1), dim3(512), S2_LDS, stream, bb);
+    const dim3 grid(blocks, bb.count, 1);
+    if (e == 3) hipLaunchKernelGGL((gemm_split256_kernel<EPI_LSTM, true>), grid, dim3(512), S2_LDS, stream, bb);
+    else if (e == 2) hipLaunchKernelGGL((gemm_split256_kernel<EPI_PLAIN, true>), grid, dim3(512), S2_LDS, stream, bb);
+    else if (e == 1) hipLaunchKernelGGL((gemm_split256_kernel<EPI_LSTM, false>), grid, dim3(512), S2_LDS, stream, bb);
+    else hipLaunchKernelGGL((gemm_split256_kernel<EPI_PLAIN, false>), grid, dim3(512), S2_LDS, stream, bb);
     return true;
 }
 
