@@ -68,6 +68,14 @@ def test_correct_lines_with_split_operands(kind, mode_, split_option):
     parity.test_correct_lines_equals_oracle(kind, mode_)
 
 
+def test_random_beam_configurations_with_split_operands(split_option):
+    """The randomised sweep of model shapes and beam parameters against the oracle (tests/test_gpu_sweep.py: 40 cases, poisoned
+    device memory, ragged batches, unmapped characters) with every GEMM launch on 128x128 split tiles -- unchanged test body."""
+    from tests import test_gpu_sweep as sweep
+    split_option(1)
+    sweep.test_random_beam_configurations(7, 40, 0)
+
+
 def test_split_and_fp32_kernels_take_the_same_decisions(split_option, golden_dir):
     """What changes between the two arithmetics on configs[2]'s shape: nothing that is decided (strings, lengths, step counts
     of all 1024 lines), the scores in the sixth digit."""
