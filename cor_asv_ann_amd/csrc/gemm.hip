@@ -834,11 +834,20 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
     return p;
 }
 bool gemm_is_skinny(int epi, const GemmBatch& b) { return plan_gemm(epi, b).skinny; }
+static bool splittable_launch(int epi, const GemmBatch& b) {        // (a launch whose jobs ask for split-K: never re-planned below)
+    if (epi != EPI_PLAIN) return false;
+    for (int j = 0; j < b.count; ++j) if (b.g[j].ksplit != 0 && b.g[j].ksplit != 1) return true;
+    return false;
+}
 
 void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     const GemmPlan plan = plan_gemm(epi, b);
     const int blocks = plan.blocks, ksplit = plan.ksplit;
-    const bool skinny = plan.skinny;
+    bool skinny = plan.skinny;
+    // split-bf16 experiment: a launch that would go as 64- or 32-row tiles only because 128x128 tiles leave CUs idle (the
+    // encoder's cells at 1024 lines: 256 / 384 tiles; the attention-query job) runs faster as 128x128 tiles on the bf16
+    // instruction, one workgroup per CU, than as small tiles on the fp32-input one (c3: 190.9 -> 178 ms per batch)
+    if (g_split_bf16 && skinny && g_tile_mode < 0 && ksplit == 1 && !splittable_launch(epi, b) && blocks * b.count >= 192) skinny = false;
     // XCD-aware tile order: minimise (A bytes x column-splits + B bytes x row-splits) over the 8 = xr * xc splits
     GemmBatch bb = b;
     for (int j = 0; j < bb.count; ++j) {
