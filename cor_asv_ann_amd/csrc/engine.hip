@@ -62,7 +62,8 @@ extern "C" void casv_model_destroy(casv_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
-    gemm_split_invalidate();
+    for (auto& l : m->dec) gemm_split_invalidate(l.wt.as<float>());
+    gemm_split_invalidate(m->WaT.as<float>()); gemm_split_invalidate(m->E.as<float>());
     DevBuf* bufs[] = {&m->E, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
         &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->Hc, &m->cfin,
         &m->hfin, &m->u, &m->st_a, &m->st_p, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
@@ -186,7 +187,8 @@ static int pack_dec1(casv_model* m, LstmW& dst, const std::string& prefix, int k
 extern "C" int casv_commit_weights(casv_model* m) {
     if (!m) return fail(CASV_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(m->device));
-    gemm_split_invalidate();            // (split-bf16 experiment: images of the old weights)
+    for (auto& l : m->dec) gemm_split_invalidate(l.wt.as<float>());          // (split-bf16 experiment: images of the old weights)
+    gemm_split_invalidate(m->WaT.as<float>()); gemm_split_invalidate(m->E.as<float>());
     for (auto& kv : m->expect)
         if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());
     const int W = m->W, C = m->C, D = m->D;
@@ -1178,7 +1180,7 @@ extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N
     float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
     *ms_per_launch = t / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    gemm_split_invalidate();
+    gemm_split_invalidate(Bt.as<float>());
 #ifdef CASV_S2_CLOCK
     s2_clock_dump();
 #endif

@@ -260,8 +260,17 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
 
     // ---- prologue: tiles 0 and 1 into LDS, tile 2 requested; the fragments a tile expects in registers ----
     GTile gt;
-    if (nt > 0) { request(gt); if (BIMG) { dma_b(0); advance_b(); } advance(); CASV_S2_LANDED(gt); store_op(gt.a[0], gt.a[1], 0, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], 0, 3); }
-    if (nt > 1) { request(gt); if (BIMG) { dma_b(1); advance_b(); } advance(); CASV_S2_LANDED(gt); store_op(gt.a[0], gt.a[1], 1, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], 1, 3); }
+    if (nt > 1) {       // tiles 0 and 1 requested together: one memory round trip in front of the first product instead of two
+        GTile g1;
+        request(gt); if (BIMG) { dma_b(0); advance_b(); } advance();
+        request(g1); if (BIMG) { dma_b(1); advance_b(); } advance();
+        CASV_S2_LANDED(gt); CASV_S2_LANDED(g1);
+        store_op(gt.a[0], gt.a[1], 0, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], 0, 3);
+        store_op(g1.a[0], g1.a[1], 1, 0); if (!BIMG) store_op(g1.b[0], g1.b[1], 1, 3);
+    } else if (nt > 0) {
+        request(gt); if (BIMG) { dma_b(0); advance_b(); } advance(); CASV_S2_LANDED(gt);
+        store_op(gt.a[0], gt.a[1], 0, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], 0, 3);
+    }
     if (nt > 2) { request(gt); advance(); }
     __syncthreads();
     if (nt > 0) {
@@ -609,7 +618,8 @@ __global__ void split_image_kernel(const float* __restrict__ Bt, int N, int K, c
 }
 
 // Images are made on first use (on the launch's stream, ahead of the launch) and kept per (weight pointer, shape) until
-// gemm_split_invalidate(): called wherever weights change or their buffers go away (casv_commit_weights, casv_model_destroy).
+// gemm_split_invalidate(Bt): called wherever a weight buffer changes or goes away (casv_commit_weights, casv_model_destroy) --
+// per buffer, so that another handle decoding on another thread keeps the images it is using.
 struct SplitImage { void* img; int N, K; };
 static std::mutex g_img_mutex;
 static std::map<std::pair<int, const float*>, SplitImage> g_images;     // key: (device, Bt)
@@ -630,10 +640,12 @@ static const void* split_image_of(const float* Bt, int N, int K, hipStream_t str
     g_images[{dev, Bt}] = SplitImage{img, N, K};
     return img;
 }
-void gemm_split_invalidate() {
+void gemm_split_invalidate(const float* Bt) {        // the image(s) of one weight buffer; nullptr: all
     std::lock_guard<std::mutex> lock(g_img_mutex);
-    for (auto& kv : g_images) (void)hipFree(kv.second.img);        // (hipFree waits for the device: nothing still reads them)
-    g_images.clear();
+    for (auto it = g_images.begin(); it != g_images.end();) {
+        if (!Bt || it->first.second == Bt) { (void)hipFree(it->second.img); it = g_images.erase(it); }     // (hipFree waits for the device: nothing still reads it)
+        else ++it;
+    }
 }
 
 // Which jobs of a launch can go as 256x256 tiles: whole tiles only, inference outputs only (no gate / second-h / precomputed-term

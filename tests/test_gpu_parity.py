@@ -362,6 +362,61 @@ def test_c3_short_lines_equal_the_oracle(golden_dir):
     eng.close()
 
 
+def test_c3_bench_batch_agrees_with_the_oracle_like_its_own_fp64_run(golden_dir):
+    """The batch the headline metric is quoted on -- bench.py's own BASELINE configs[2] workload: depth 4, width 512, V 256,
+    its 1024 lines of 100 characters, N = 8, its weights -- decoded in ONE device call and compared with the committed oracle
+    fixture of ALL its lines (tests/golden/make_c3_full_golden.py: the oracle's fp32 AND fp64 searches of every line).
+
+    On this workload a 202-step search amplifies rounding: the oracle's own fp32 run takes another decision than its fp64 run
+    on 20 of the 1024 lines and its character probabilities are off by 1.6e-4 (median of the per-line maximum; 1.6e-3 at
+    the 90th percentile).  No fp32 implementation can match another index for index here, so the bar is the oracle's own
+    noise: the device (sequential fmaf chains over K <= 1536 and exp2/rcp-based gate functions where numpy has blocked sums and
+    libm) must stay within a small factor of it --
+      * decisions (string, number of finished hypotheses, number of search iterations) differ from the fp32 oracle on at most
+        3x as many lines as the fp64 oracle's do,
+      * where all three agree on the string, the per-line maximum relative error of the character probabilities against the
+        fp32 oracle is at most 3x the fp64 oracle's, at the median and at the 90th percentile; line scores likewise at the
+        median, and to 5e-3 everywhere,
+      * and on the lines the oracle itself pins tightly (fp64 within 2e-5 of fp32 on every character: ~35 lines) the usual
+        tolerance holds -- probabilities rtol 2e-4 on 90 % of them, rtol 1e-3 on all; the exceptions are printed.
+    (Measured, one MI355X: 30 lines against the oracle's 20; medians 3.2e-4 against 1.6e-4; 1 of 35 tight lines beyond 2e-4.)"""
+    with np.load(os.path.join(golden_dir, 'c3_beam_full.npz')) as f:
+        g = {k: f[k] for k in f.files}
+    d, W, V, B, L, N, es, count = (int(x) for x in g['meta'])
+    assert (d, W, V, B, L, N, count) == (4, 512, 256, 1024, 100, 8, 1024)
+    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    weights = make_weights(cfg, emb_scale=float(es))
+    eng = _engine(cfg, weights)
+    eng.encode(g['idx'])
+    res = eng.decode_beam(batch_size=N)
+    eng.close()
+    i_c = OracleModel(cfg, weights).mapping[1]
+    tg = [''.join(i_c[int(c)] for c in res['idx'][j, :int(res['len'][j])]) for j in range(B)]
+    t32, t64 = [str(x) for x in g['beam_text']], [str(x) for x in g['beam_text64']]
+    dev = np.array([tg[j] != t32[j] or res['n_found'][j] != g['beam_found'][j] or res['n_steps'][j] != g['beam_steps'][j] for j in range(B)])
+    o64 = np.array([t64[j] != t32[j] or g['beam_found64'][j] != g['beam_found'][j] or g['beam_steps64'][j] != g['beam_steps'][j] for j in range(B)])
+
+    def err(pa, pb, n):
+        return float(np.max(np.abs(pa[:n] - pb[:n]) / np.maximum(pb[:n], 1e-6)))
+    same = [j for j in range(B) if tg[j] and tg[j] == t32[j] == t64[j]]
+    e_dev = np.array([err(res['prob'][j], g['beam_probs'][j], len(tg[j])) for j in same])
+    e_64 = np.array([err(g['beam_probs64'][j], g['beam_probs'][j], len(tg[j])) for j in same])
+    s_dev = np.abs(res['score'][same] - g['beam_score'][same])
+    s_64 = np.abs(g['beam_score64'][same] - g['beam_score'][same])
+    tight = e_64 < 2e-5
+    loose = [same[i] for i in np.nonzero(tight & (e_dev > 2e-4))[0]]
+    print('bench batch, %d lines: decisions differ from the fp32 oracle on %d lines (the fp64 oracle: %d); %d lines with equal non-empty '
+          'strings: per-line max relative probability error median %.2e / p90 %.2e (fp64 oracle: %.2e / %.2e), scores max %.2e; '
+          'tightly pinned lines %d, beyond rtol 2e-4 on %d of them: %s'
+          % (B, dev.sum(), o64.sum(), len(same), np.median(e_dev), np.percentile(e_dev, 90), np.median(e_64), np.percentile(e_64, 90),
+             s_dev.max(), tight.sum(), len(loose), loose[:10]))
+    assert len(same) >= 300 and o64.sum() >= 5                      # the fixture is what it says: searches finish, and fp32 is noisy here
+    assert dev.sum() <= 3 * o64.sum()
+    assert np.median(e_dev) <= 3 * np.median(e_64) and np.percentile(e_dev, 90) <= 3 * np.percentile(e_64, 90)
+    assert np.median(s_dev) <= 3 * np.median(s_64) and s_dev.max() < 5e-3
+    assert tight.sum() >= 20 and len(loose) <= max(2, 0.10 * tight.sum()) and not (tight & (e_dev > 1e-3)).any()
+
+
 def test_model_loaded_from_the_reference_container(golden_dir, tmp_path):
     """A Keras-2.3 HDF5 model file (written by libhdf5, tests/golden/make_keras_h5.py) loads through
     load_config / configure / load_weights (scripts/proc.py:52-55) and decodes like the oracle with the same

@@ -47,6 +47,14 @@ def test_c3_short_lines_equal_the_oracle_with_split_operands(mode, split_option,
 
 
 @pytest.mark.parametrize('mode', [1, 2])
+def test_c3_bench_batch_with_split_operands(mode, split_option, golden_dir):
+    """bench.py's own configs[2] batch (1024 lines x 100 characters) against the oracle's fp32 and fp64 searches of all its
+    lines: within the same factor of the oracle's own fp32 noise as the fp32-input kernels -- unchanged test body."""
+    split_option(mode)
+    parity.test_c3_bench_batch_agrees_with_the_oracle_like_its_own_fp64_run(golden_dir)
+
+
+@pytest.mark.parametrize('mode', [1, 2])
 def test_full_width_decoder_steps_with_split_operands(mode, split_option):
     """Three teacher-forced decoder steps at R = 8192 rows / depth 4 / width 512 against the oracle -- unchanged test body."""
     split_option(mode)
