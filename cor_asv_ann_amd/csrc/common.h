@@ -160,6 +160,7 @@ bool gemm_split256_wants(int epi, const GemmArgs& g);
 #ifdef CASV_S2_CLOCK
 void s2_clock_dump();
 #endif
+void gemm_split_prepare(const float* Bt, int N, int K, hipStream_t stream);    // makes the image of a weight buffer now (ahead of a graph recording)
 void gemm_split_invalidate(const float* Bt);     // drops the pre-split image of a weight buffer (call where it changes or is released); nullptr: all
 bool launch_gemm_split256(int epi, const GemmBatch& b, hipStream_t stream);     // false: not launched (the caller takes another path)
 int gemm_split_bf16();

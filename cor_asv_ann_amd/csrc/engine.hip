@@ -691,6 +691,12 @@ struct StepRunner {
         if (m->use_graph && !m->prof.on) {
             if (!m->step_exec || m->step_graph_key != key) {
                 drop(m);
+                if (gemm_split_bf16() >= 2) {       // (split-bf16 experiment: the weight images are made ahead of the recording, not inside it)
+                    const int W = m->W, C = m->C, D = m->D, Vp = m->Vp;
+                    for (int n = 1; n <= D; ++n)
+                        gemm_split_prepare(m->dec[n].wt.as<float>(), 4 * W, (n == 1 ? Vp : W) + W + (n == D && D > 1 ? C : 0) + (D == 1 ? C : 0), m->stream);
+                    gemm_split_prepare(m->WaT.as<float>(), W, W, m->stream);
+                }
                 HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
                 body(m->d_step.as<int>(), 0);
                 launch_advance_step(m->d_step.as<int>(), m->stream);

@@ -628,8 +628,13 @@ static const void* split_image_of(const float* Bt, int N, int K, hipStream_t str
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_img_mutex);
     auto it = g_images.find({dev, Bt});
+    if (it != g_images.end() && it->second.N == N && it->second.K == K) return it->second.img;
+    // (no allocation while the stream records a graph: that launch stages B itself -- same values -- and the image is made by
+    // the first eager launch that wants it)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cap != hipStreamCaptureStatusNone) return nullptr;
     if (it != g_images.end()) {
-        if (it->second.N == N && it->second.K == K) return it->second.img;
         (void)hipFree(it->second.img);
         g_images.erase(it);
     }
@@ -639,6 +644,22 @@ static const void* split_image_of(const float* Bt, int N, int K, hipStream_t str
     hipLaunchKernelGGL(split_image_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, Bt, N, K, reinterpret_cast<char*>(img));
     g_images[{dev, Bt}] = SplitImage{img, N, K};
     return img;
+}
+static bool split256_set_attributes() {        // the dynamic-LDS size of the four variants, once per device (not inside a recording)
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && attr_set[dev]) return true;
+    const void* fns[4] = {reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_PLAIN, false>), reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_LSTM, false>),
+                          reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_PLAIN, true>), reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_LSTM, true>)};
+    for (const void* fn : fns)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    return true;
+}
+void gemm_split_prepare(const float* Bt, int N, int K, hipStream_t stream) {
+    (void)split256_set_attributes();
+    if (Bt && N > 0 && N % S2_BN == 0 && K > 0 && K % S2_BK == 0) (void)split_image_of(Bt, N, K, stream);
 }
 void gemm_split_invalidate(const float* Bt) {        // the image(s) of one weight buffer; nullptr: all
     std::lock_guard<std::mutex> lock(g_img_mutex);
@@ -695,18 +716,8 @@ bool launch_gemm_split256(int epi, const GemmBatch& b, hipStream_t stream) {
         for (int i = 0; i < bb.g[j].nseg; ++i) if (bb.g[j].a[i].koff % S2_BK) bimg = false;
         if (bimg) { bb.g[j].Bimg = split_image_of(bb.g[j].Bt, bb.g[j].N, bb.g[j].Ktot, stream); bimg = bb.g[j].Bimg != nullptr; }
     }
-    static bool attr_set[64][4] = {{false}};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    if (!split256_set_attributes()) return false;
     const int e = (epi == EPI_LSTM ? 1 : 0) + (bimg ? 2 : 0);
-    const void* fn = e == 3 ? reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_LSTM, true>)
-                   : e == 2 ? reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_PLAIN, true>)
-                   : e == 1 ? reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_LSTM, false>)
-                            : reinterpret_cast<const void*>(&gemm_split256_kernel<EPI_PLAIN, false>);
-    if (dev < 0 || dev >= 64 || !attr_set[dev][e]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (dev >= 0 && dev < 64) attr_set[dev][e] = true;
-    }
     const dim3 grid(blocks, bb.count, 1);
     if (e == 3) hipLaunchKernelGGL((gemm_split256_kernel<EPI_LSTM, true>), grid, dim3(512), S2_LDS, stream, bb);
     else if (e == 2) hipLaunchKernelGGL((gemm_split256_kernel<EPI_PLAIN, true>), grid, dim3(512), S2_LDS, stream, bb);
