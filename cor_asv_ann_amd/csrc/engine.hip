@@ -249,6 +249,7 @@ static void persist_note_abort(casv_model* m, const char* what) {
 static int persist_enc_lds(const casv_model* m) { return 16 * ((m->D >= 2 ? 3 * m->W : 2 * m->W) + 4) * 4; }
 static bool persist_enc_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0 || m->ncu < 64 || m->D > 8) return false;
+    if (gemm_split_bf16()) return false;
     const int W = m->W, D = m->D;
     const int per_cu = persist_encode_blocks_per_cu((size_t)persist_enc_lds(m));            // 0: the staged rows do not fit the LDS
     if (per_cu < 1) return false;
@@ -719,6 +720,7 @@ struct StepRunner {
 // bound by launch and memory latency.  Same results bit for bit (tested), same state / alignment / window stores.
 static bool persist_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0) return false;
+    if (gemm_split_bf16()) return false;        // (split-bf16 experiment: the persistent kernels keep the fp32-input arithmetic -- not mixed with it)
     if (m->ncu < 64 || m->D > 8) return false;
     int kmax = m->W;
     for (int n = 1; n <= m->D; ++n) kmax = std::max(kmax, m->dec[n].kin + m->W);

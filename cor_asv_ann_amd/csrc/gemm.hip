@@ -82,7 +82,8 @@ constexpr int SPLIT_BUF_FLOATS = 6 * SPLIT_PLANE_BYTES / 4;     // A planes 0..2
 // SPLIT (KS = 1 only; option split_bf16, a measured experiment and NOT the default arithmetic): every fp32 operand value is taken
 // apart into three bf16 values x = x0 + x1 + x2 (round to nearest, each remainder exact in fp32, so the sum is exact) while its tile
 // is staged into LDS, and a K tile is contracted as six v_mfma_f32_32x32x16_bf16 products per 32x32 block with fp32 accumulation --
-// a0.b2, a1.b1, a0.b1, a2.b0, a1.b0, a0.b0; the three dropped products are below 2^-25 |a||b| -- at 6/16 of the matrix-pipe time of
+// a1.b1, a0.b2, a0.b1, a2.b0, a1.b0, a0.b0 (the order of gemm_split.hip's 256x256 tiles: an element's sum is the same instruction
+// sequence in both, so the two tile shapes give the same bits); the three dropped products are below 2^-25 |a||b| -- at 6/16 of the matrix-pipe time of
 // the fp32-input instruction.  The sums are fp32-accurate but NOT the k-ordered fmaf chain of the other kernels: results agree with
 // them to rounding, not bit for bit.  Fragment registers roll instead of being double-buffered: a plane's fragments of tile kt + 1
 // are read into the registers of tile kt as soon as their last product has issued (B planes 2 and 1 and A plane 0 behind the
@@ -427,7 +428,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         if (have_) {                                                                      \
             if (reads_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) sb[c_][0] = frag_b((KT) & 1, 0, c_);   \
             if (FULL) CASV_SPLIT_PIN                                                      \
-            CASV_SPLIT_MMA(AC, 2) CASV_SPLIT_MMA(sa1, 1) CASV_SPLIT_MMA(AC, 1)            \
+            CASV_SPLIT_MMA(sa1, 1) CASV_SPLIT_MMA(AC, 2) CASV_SPLIT_MMA(AC, 1)    /* (the product order of gemm_split.hip: same bits) */ \
         }                                                                                 \
         if (FULL) CASV_SPLIT_PIN        /* the 12 products stay in front of the barrier: plane 0's reads land under them */ \
         if (!(FULL && (CASV_ABLM & 8))) __syncthreads();                                  \
@@ -834,6 +835,10 @@ static GemmPlan plan_gemm(int epi, const GemmBatch& b) {
     return p;
 }
 bool gemm_is_skinny(int epi, const GemmBatch& b) { return plan_gemm(epi, b).skinny; }
+static bool train_launch(const GemmBatch& b) {        // (the train step's fused-LSTM launches carry side outputs the decode path never has)
+    for (int j = 0; j < b.count; ++j) if (b.g[j].zinit.base || b.g[j].gates_out.base || b.g[j].out2.base) return true;
+    return false;
+}
 static bool splittable_launch(int epi, const GemmBatch& b) {        // (a launch whose jobs ask for split-K: never re-planned below)
     if (epi != EPI_PLAIN) return false;
     for (int j = 0; j < b.count; ++j) if (b.g[j].ksplit != 0 && b.g[j].ksplit != 1) return true;
@@ -847,7 +852,11 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     // split-bf16 experiment: a launch that would go as 64- or 32-row tiles only because 128x128 tiles leave CUs idle (the
     // encoder's cells at 1024 lines: 256 / 384 tiles; the attention-query job) runs faster as 128x128 tiles on the bf16
     // instruction, one workgroup per CU, than as small tiles on the fp32-input one (c3: 190.9 -> 178 ms per batch)
-    if (g_split_bf16 && skinny && g_tile_mode < 0 && ksplit == 1 && !splittable_launch(epi, b) && blocks * b.count >= 192) skinny = false;
+    // ... and every other inference launch too, whatever tile shape was asked for: with the option on, all GEMM launches of the
+    // decode path share ONE arithmetic (128x128 and 256x256 split tiles give the same bits), so that a row's result does not depend
+    // on the batch it sits in -- the property the fp32-input kernels have among themselves.  (The train step's per-time-step launches
+    // keep the fp32-input small tiles: its persistent recurrences, which they must equal, are fp32-input kernels.)
+    if (g_split_bf16 && skinny && ksplit == 1 && !splittable_launch(epi, b) && !train_launch(b)) skinny = false;
     // XCD-aware tile order: minimise (A bytes x column-splits + B bytes x row-splits) over the 8 = xr * xc splits
     GemmBatch bb = b;
     for (int j = 0; j < bb.count; ++j) {

@@ -240,8 +240,9 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
  * nearest, exact sum) and contract six products per K tile on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (1: as 128x128
  * tiles, csrc/gemm.hip; 2: as 256x256 tiles where a job fills the chip that way, csrc/gemm_split.hip).  fp32-accurate sums
  * at 6/16 of the matrix-pipe time, but another summation order than the fp32-input kernels: results agree with them (and with
- * the oracle, within the tolerances of tests/) to rounding, not bit for bit, and a row's low-order bits then depend on which
- * kernel the batch size selects. */
+ * the oracle, within the tolerances of tests/) to rounding, not bit for bit.  With the option on every GEMM launch of the decode
+ * path takes this arithmetic (both tile shapes give the same bits, so a row's result does not depend on its batch) and the
+ * persistent small-batch kernels, which keep the fp32-input arithmetic, are not used. */
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 /* Statistics of the last call (tests): "beam_max_new_keys" = most child hypotheses one line created in one search
  * iteration of the last casv_decode_beam; "beam_sort_capacity" = how many of them are sorted in LDS at once (more are

@@ -104,3 +104,6 @@ def test_split_and_fp32_kernels_take_the_same_decisions(split_option, golden_dir
             assert np.array_equal(outs[0][k], other[k]), k
         assert np.allclose(outs[0]['score'], other['score'], rtol=0, atol=1e-5)
         assert not np.array_equal(outs[0]['score'], other['score'])       # (it IS another arithmetic: the switch did something)
+    # the two tile shapes of the split arithmetic contract every element with the same instruction sequence: the same bits
+    for k in ('idx', 'len', 'n_found', 'n_steps', 'score', 'prob'):
+        assert np.array_equal(outs[1][k], outs[2][k], equal_nan=True), k
