@@ -625,7 +625,7 @@ class Sequence2Sequence(object):
         # is pure Python and gives the lock up once per switch interval (5 ms by default: up to half a millisecond of idle GPU
         # between two batches of configs[1], rocprofv3 trace of round 4).  A short interval while the pipeline runs.
         interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(interval, 1e-4))
+        sys.setswitchinterval(min(interval, float(os.environ.get('CASV_SWITCH_INTERVAL', '1e-4'))))
         try:
             for lines, prep, raw in prefetch(decoded(), depth=1):
                 yield self._results_of(lines, prep, raw, fast, greedy, alignments) if lines else ([], [], [], [])
