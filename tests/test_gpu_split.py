@@ -107,3 +107,44 @@ def test_split_and_fp32_kernels_take_the_same_decisions(split_option, golden_dir
     # the two tile shapes of the split arithmetic contract every element with the same instruction sequence: the same bits
     for k in ('idx', 'len', 'n_found', 'n_steps', 'score', 'prob'):
         assert np.array_equal(outs[1][k], outs[2][k], equal_nan=True), k
+
+
+def test_split_kernels_do_not_depend_on_what_else_runs_on_the_gpu(split_option, golden_dir):
+    """Two model handles decode the configs[2]-shaped fixture at the same time on two streams (the 256x256 split kernel wants the
+    whole LDS of a CU and hands tiles over through LDS-DMA: foreign workgroups in between must change nothing), and a third run
+    follows alone: all three results are the same bits."""
+    import threading
+    from cor_asv_ann_amd.engine import HipEngine
+    with np.load(os.path.join(golden_dir, 'c3_beam_short.npz')) as f:
+        idx, meta = f['idx'], f['meta']
+    cfg = ModelConfig(depth=4, width=512, voc_size=256)
+    weights = make_weights(cfg, emb_scale=float(meta[6]))
+    split_option(2)
+    engines = [HipEngine(cfg.depth, cfg.width, cfg.voc_size) for _ in range(2)]
+    for e in engines:
+        e.set_weights(weights)
+    results, errors = [None, None], []
+
+    def run(k):
+        try:
+            out = []
+            for _ in range(3):
+                engines[k].encode(idx)
+                out.append(engines[k].decode_beam(batch_size=8))
+            results[k] = out
+        except Exception as err:           # noqa: BLE001 -- reported by the main thread
+            errors.append(err)
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    engines[0].encode(idx)
+    alone = engines[0].decode_beam(batch_size=8)
+    for e in engines:
+        e.close()
+    for out in results:
+        for res in out:
+            for k in ('idx', 'len', 'n_found', 'n_steps', 'score', 'prob'):
+                assert np.array_equal(res[k], alone[k], equal_nan=True), k
