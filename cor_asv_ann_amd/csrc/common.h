@@ -41,6 +41,10 @@ template <class T, class Op> __device__ __forceinline__ T wave_butterfly(T v, Op
     return v;
 }
 
+#ifdef CASV_ACCURATE_ACT       // measurement aid (profiles/r04_split_bf16.txt, section 9): libm's functions in place of the exp2/rcp forms
+__device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+#else
 __device__ __forceinline__ float fast_tanh(float x) {
     // both branches are evaluated and one is selected: a dozen straight-line instructions instead of a divergent branch per
     // call (the attention rows make 44 calls per loop iteration); the selected value is the one the branch computed
@@ -53,6 +57,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * 1.44269504088896340736f));
 }
+#endif
 
 // The LSTM cell on gate pre-activations (Keras gate order i, f, c~, o; recurrent_activation = sigmoid,
 // seq2seq.py:268-272).  ONE definition for every GEMM variant, so that a row's result does not depend on which
