@@ -42,6 +42,7 @@ LINE_SEED = 103
 # metric is about ("Synthetic weights").
 EMB_SCALE = 128.0
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2516.6         # dense bf16: 16x the fp32-input rate (v_mfma_f32_32x32x16_bf16: 32 768 FLOP in 32 cycles per SIMD at 2.4 GHz)
 PEAK_HBM_BYTES_PER_S = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 METRIC = 'corrected chars/sec (whole node) at beam=8, depth-4 width-512, 100-char lines'
 
@@ -605,6 +606,10 @@ def decode_bench(args):
                                # the other roofline of SURVEY 8(d): not the binding one at fp32
                                'hbm_bytes_per_char': qpc,
                                'hbm_frac': chars / elapsed * qpc / world / PEAK_HBM_BYTES_PER_S}}
+        if args.split_bf16 and 'roofline' in result:
+            # the instruction the experiment runs on: six bf16 products per algorithmic one, against the dense bf16-MFMA peak
+            result['roofline']['bf16_mfma'] = {'achieved': 6.0 * result['roofline']['achieved'], 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                               'frac': 6.0 * result['roofline']['achieved'] / PEAK_BF16_MFMA_TFLOPS}
         if others:
             result['kernel_ms_per_step'] = {k: v['ms'] for k, v in others.items()}     # from one extra untimed step
         if world == 1 and not args.no_cpu_baseline and not dry and not wl.get('confmat'):
@@ -652,6 +657,8 @@ def other_workloads(with_cpu_baseline=True):
                                     if k in r['roofline']}
                 if 'whole_path' in r['roofline']:
                     keep['roofline']['whole_path_frac'] = r['roofline']['whole_path']['frac']
+                if 'bf16_mfma' in r['roofline']:
+                    keep['roofline']['bf16_mfma'] = r['roofline']['bf16_mfma']
             for k in ('kernel_ms_per_step', 'realign_ms_per_step', 'cpu_baseline', 'calibration'):
                 if k in r:
                     keep[k] = r[k]
