@@ -578,12 +578,13 @@ def decode_bench(args):
             achieved = prof['flops'] / max(prof['ms'], 1e-9) / 1e9            # TFLOP/s
             traffic = None
             try:
-                with open(os.path.join(ROOT, 'profiles', 'persist_decode_traffic.json' if dom == 'persist' else 'lstm_gemm_traffic.json')) as f:
+                with open(os.path.join(ROOT, 'profiles', 'persist_decode_traffic.json' if dom == 'persist' else
+                                       ('split256_gemm_traffic.json' if args.split_bf16 == 2 else 'lstm_gemm_traffic.json'))) as f:
                     traffic = json.load(f).get('hbm_bytes_per_launch')
             except Exception:
                 pass
-            if args.workload == 'page':
-                traffic = None          # the committed PMC passes were taken on the c3 shapes
+            if args.workload == 'page' or args.split_bf16 == 1:
+                traffic = None          # the committed PMC passes were taken on the c3 shapes (and for the kernels named in them)
             result['roofline'] = {
                 'bound': 'mfma',
                 'kernel': ('gemm_kernel<EPI_LSTM, 1> (fused LSTM-cell GEMM, 128x128 tiles, fp32 MFMA)' if not args.split_bf16 else
@@ -653,7 +654,7 @@ def other_workloads(with_cpu_baseline=True):
             keep = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype') if k in r}
             keep['workload'] = r['config']['workload']
             if 'roofline' in r:
-                keep['roofline'] = {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_us')
+                keep['roofline'] = {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_us')
                                     if k in r['roofline']}
                 if 'whole_path' in r['roofline']:
                     keep['roofline']['whole_path_frac'] = r['roofline']['whole_path']['frac']
