@@ -185,6 +185,18 @@ class HipEngine(object):
         return out
 
     # -- encoder -------------------------------------------------------------------------------
+    @staticmethod
+    def source_rejection(idx, val):
+        """The rejection candidate of every input position: argmax of its input row, -1 for all-zero rows (seq2seq.py:1458-1462).
+        idx / val (B,T,A).  (Host arithmetic on the whole batch: callers that prepare batches ahead of the device stage compute
+        it there and hand it to encode().)"""
+        masked = np.where(idx >= 0, val, -np.inf)
+        best = masked.max(axis=2, keepdims=True)
+        cand = np.where((masked == best) & (idx >= 0), idx, np.iinfo(np.int32).max)
+        src_rej = cand.min(axis=2)
+        anyval = ((idx >= 0) & (val != 0)).any(axis=2)
+        return np.where(anyval, src_rej, -1).astype(np.int32)
+
     def encode(self, idx, val=None, src_rej=None):
         """idx int32 (B,T) or (B,T,A) with -1 for empty slots; val float32 same shape (default 1)."""
         idx = nv.carray(idx, np.int32)
@@ -196,13 +208,7 @@ class HipEngine(object):
             val = np.ones(idx.shape, np.float32)
         val = nv.carray(np.broadcast_to(np.asarray(val, np.float32).reshape(B, T, -1), idx.shape), np.float32)
         if src_rej is None:
-            # argmax of each input row, -1 for all-zero rows (seq2seq.py:1458-1462)
-            masked = np.where(idx >= 0, val, -np.inf)
-            best = masked.max(axis=2, keepdims=True)
-            cand = np.where((masked == best) & (idx >= 0), idx, np.iinfo(np.int32).max)
-            src_rej = cand.min(axis=2)
-            anyval = ((idx >= 0) & (val != 0)).any(axis=2)
-            src_rej = np.where(anyval, src_rej, -1)
+            src_rej = self.source_rejection(idx, val)
         src_rej = nv.carray(src_rej, np.int32)
         nv.check(self.lib.casv_encode(self.handle, B, T, A, nv.ptr(idx), nv.ptr(val), nv.ptr(src_rej)))
         self.B, self.T = B, T

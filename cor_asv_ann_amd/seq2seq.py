@@ -634,9 +634,12 @@ class Sequence2Sequence(object):
 
     # the three stages of correct_lines ------------------------------------------------------------
     def _prepare_lines(self, lines, conf):
-        """Host, before the device: strings / confidences -> index and value arrays."""
+        """Host, before the device: strings / confidences -> index and value arrays, and the rejection candidate of every
+        position (batch-wide numpy arithmetic that would otherwise run in the device stage, between two C-ABI calls)."""
         idx, val, _ = self._sparse_lines(lines, conf)
-        return idx, val
+        from .engine import HipEngine
+        rej = HipEngine.source_rejection(idx, val) if idx.ndim == 3 and idx.shape[1] else None
+        return idx, val, rej
 
     def _decode_prepared(self, prepared, fast, greedy, alignments, nonempty=None):
         """The device part: encode + decode, raw result arrays.  (The only stage that talks to the engine.)
@@ -644,12 +647,13 @@ class Sequence2Sequence(object):
         but unmapped symbols is decoded, an empty padding line is not)."""
         eng = self._require_engine()
         want_align = False if not alignments else (True if alignments == 'dense' else 'sparse')
-        idx, val = prepared
+        idx, val = prepared[:2]
+        rej = prepared[2] if len(prepared) > 2 else None
         B, T = idx.shape[:2]
         if T == 0:                  # nothing but padding lines
             return None
         if fast:
-            eng.encode(idx, val)
+            eng.encode(idx, val, rej)
             gi, gp, _, ga = eng.decode_greedy(mode=0, want_align=want_align)
             return gi, gp, ga
         # the per-line modes never decode the empty padding lines of a partial batch (seq2seq.py:815-816) -- an
@@ -658,7 +662,7 @@ class Sequence2Sequence(object):
         if greedy:
             if not live:
                 return live, []
-            eng.encode(idx[live], val[live])
+            eng.encode(idx[live], val[live], None if rej is None else rej[live])
             return live, self._sequence_greedy_results(eng, len(live), want_align)
         # The search keeps every expansion's state on the device (nothing is recomputed, nothing crosses to the host):
         # S x (lines x N) rows of h, c per layer, scores and alignments.  Large beams (the reference's default
@@ -672,14 +676,14 @@ class Sequence2Sequence(object):
         out = []
         for lo in range(0, len(live), chunk):
             rows = live[lo:lo + chunk]
-            eng.encode(idx[rows], val[rows])
+            eng.encode(idx[rows], val[rows], None if rej is None else rej[rows])
             res = eng.decode_beam(max_results=1, want_align=want_align, **self._beam_kwargs())
             out.append((rows, res, eng.T))
         return live, out
 
     def _results_of(self, lines, prepared, raw, fast, greedy, alignments):
         """Host, after the device: raw arrays -> strings, probability lists, scores, alignment views."""
-        idx, val = prepared
+        idx, val = prepared[:2]
         B = idx.shape[0]
         if raw is None:
             return self._finish(lines, [('', [], 0, []) for _ in range(B)])
