@@ -95,6 +95,124 @@ def launch_ranks(n, argv):
 
 
 # ------------------------------------------------------------------------------------------------------
+# host placement of a rank (the scaling risk of the line-sharded job is what the processes share on the host)
+# ------------------------------------------------------------------------------------------------------
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        out += list(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(sysfs='/sys'):
+    """NUMA node of every GPU in HIP's device order, read from sysfs WITHOUT touching the GPU: the KFD topology lists the
+    nodes in the order the runtime enumerates them (GPU nodes have simd_count > 0 and a drm_render_minor), the render node's
+    PCI device says which NUMA node it hangs on.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES given as plain index lists are
+    applied.  None where the information is not there (no GPU, a container without the topology)."""
+    base = os.path.join(sysfs, 'class', 'kfd', 'kfd', 'topology', 'nodes')
+    try:
+        ids = sorted(int(x) for x in os.listdir(base) if x.isdigit())
+    except OSError:
+        return None
+    nodes = []
+    for i in ids:
+        props = {}
+        try:
+            with open(os.path.join(base, str(i), 'properties')) as f:
+                for row in f:
+                    k, _, v = row.strip().partition(' ')
+                    props[k] = v
+        except OSError:
+            continue
+        if int(props.get('simd_count', '0') or 0) <= 0:
+            continue                    # a CPU node
+        numa = -1
+        try:
+            with open(os.path.join(sysfs, 'class', 'drm', 'renderD%s' % props.get('drm_render_minor', ''), 'device', 'numa_node')) as f:
+                numa = int(f.read().strip())
+        except (OSError, ValueError):
+            pass
+        nodes.append(numa)
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES'):
+        sel = os.environ.get(var)
+        if sel:
+            try:
+                nodes = [nodes[int(x)] for x in sel.split(',') if x.strip()]
+            except (ValueError, IndexError):
+                return None
+    return nodes or None
+
+
+def rank_cpus(local_rank, local_world, allowed, numa_of_gpu=None, cpus_of_node=None):
+    """The CPUs of local rank `local_rank` of `local_world` on this host: the allowed CPUs of its GPU's NUMA node, shared out
+    evenly (contiguous slices) among the ranks whose GPUs hang on the same node; without NUMA information -- or where some
+    node has fewer allowed CPUs than ranks -- an even share of all allowed CPUs, for EVERY rank (one rule per host, so that the
+    shares are disjoint by construction).  Returns (cpus, numa node or -1)."""
+    allowed = sorted(allowed)
+    node_of = [(numa_of_gpu[r] if numa_of_gpu and r < len(numa_of_gpu) else -1) for r in range(local_world)]
+    by_node = all(n >= 0 for n in node_of) and bool(cpus_of_node)
+    pools = {}
+    if by_node:
+        ok = set(allowed)
+        for n in set(node_of):
+            pools[n] = [c for c in cpus_of_node.get(n, []) if c in ok]
+            if len(pools[n]) < node_of.count(n):
+                by_node = False
+    if by_node:
+        node = node_of[local_rank]
+        peers, pool = [r for r in range(local_world) if node_of[r] == node], pools[node]
+    else:
+        peers, pool = list(range(local_world)), allowed
+    k, n = peers.index(local_rank), len(peers)
+    if len(pool) < n:
+        return pool, node_of[local_rank]             # fewer CPUs than ranks: no pinning worth the name
+    return pool[k * len(pool) // n:(k + 1) * len(pool) // n], node_of[local_rank]
+
+
+def place_rank(local_rank, local_world):
+    """Called by every rank of a multi-rank run BEFORE numpy / torch / the GPU library are loaded: CPU affinity to the NUMA node
+    of the rank's GPU and a cap on the BLAS / OpenMP threads at the rank's share of the host, so that eight processes do not
+    each start a thread per core of the whole machine.  Returns what the line reports."""
+    if os.environ.get('CASV_BENCH_NO_PIN'):
+        return {'cpus': 'unpinned (CASV_BENCH_NO_PIN)', 'numa_node': None, 'threads': None}
+    allowed = sorted(os.sched_getaffinity(0))
+    numa = gpu_numa_nodes()
+    cpus_of_node = {}
+    for node in set(numa or []):
+        if node >= 0:
+            try:
+                with open('/sys/devices/system/node/node%d/cpulist' % node) as f:
+                    cpus_of_node[node] = parse_cpulist(f.read())
+            except OSError:
+                pass
+    cpus, node = rank_cpus(local_rank, local_world, allowed, numa, cpus_of_node)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return {'cpus': 'unpinned (sched_setaffinity refused)', 'numa_node': node, 'threads': None}
+    threads = max(1, len(cpus))
+    for var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
+        os.environ[var] = str(threads)
+    return {'cpus': format_cpulist(cpus), 'numa_node': node if node >= 0 else None, 'threads': threads}
+
+
+def format_cpulist(cpus):
+    out, i = [], 0
+    cpus = sorted(cpus)
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else '%d-%d' % (cpus[i], cpus[j]))
+        i = j + 1
+    return ','.join(out)
+
+
+# ------------------------------------------------------------------------------------------------------
 def make_model(device, depth=DEPTH, width=WIDTH, batch_size=BEAM_N, emb_scale=EMB_SCALE, voc=VOC):
     from cor_asv_ann_amd.synthetic import ModelConfig, make_weights, make_vocabulary
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
@@ -153,13 +271,17 @@ def host_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(cfg, weights, lines, batch_size, fast, length=LENGTH, budget_s=22.0, repeats=5, min_lines=4):
+def cpu_baseline(cfg, weights, lines, batch_size, fast, length=LENGTH, budget_s=22.0, repeats=5, min_lines=4, confmat=False, **beam):
     """The oracle in the reference's dataflow (per-character decoder call, dense-T attention, u recomputed
     every step, per-line best-first search / batched greedy loop) on the host cores: best of `repeats`
-    samples of the same workload, each sized to a share of the time budget."""
-    from oracle.decode import OracleModel, correct_lines
-    om = OracleModel(cfg, weights, batch_size=batch_size, recompute_u=True)
+    samples of the same workload, each sized to a share of the time budget.
+    confmat: the lines are confusion networks, handed over as `correct_lines(lines, conf=lines)` (wrapper/transcode.py:111-115)."""
+    from oracle.decode import OracleModel, correct_lines as oracle_correct_lines
+    om = OracleModel(cfg, weights, batch_size=batch_size, recompute_u=True, **beam)
     kw = dict(fast=True, greedy=True) if fast else dict(fast=False, greedy=False)
+
+    def correct_lines(m, chunk, **k):
+        return oracle_correct_lines(m, chunk, conf=chunk, **k) if confmat else oracle_correct_lines(m, chunk, **k)
     n0 = 8 if fast else 1
     t0 = time.perf_counter()
     correct_lines(om, lines[:n0], **kw)                      # warm-up (BLAS threads, page-in); also sizes the sample
@@ -318,12 +440,15 @@ WORKLOADS = {
 
 
 def decode_bench(args):
-    import numpy as np
-    wl = WORKLOADS[args.workload]
-    L, V = wl['length'], wl['voc']
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # several ranks on one host: each to the CPUs next to its GPU, BLAS / OpenMP threads capped at its share -- before numpy, torch
+    # or the GPU library are loaded (one rank keeps the whole host: its cpu_baseline uses all cores)
+    placement = place_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1 else None
+    import numpy as np
+    wl = WORKLOADS[args.workload]
+    L, V = wl['length'], wl['voc']
     if world != args.gpus and 'WORLD_SIZE' in os.environ:
         sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
         return 2
@@ -528,9 +653,13 @@ def decode_bench(args):
         eng.profile(False)
     per_rank_s = [mine]
     gather_ms = 1e3 * t_gather[0] / max(args.steps, 1)
+    placements = [placement]
     if comm:
         elapsed = comm.max(elapsed)
-        per_rank_s = [mine] * world               # (the per-rank times are not gathered on this path)
+        # every rank's own time and placement: one more all-gather of a small fixed-width record
+        report = comm.all_gather_objects({'s': mine, 'placement': placement})
+        per_rank_s = [r['s'] for r in report]
+        placements = [r['placement'] for r in report]
     elif dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device or 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -539,6 +668,8 @@ def decode_bench(args):
         tt[rank] = mine
         dist.all_reduce(tt)
         per_rank_s = [float(x) for x in tt.cpu()]
+        placements = [None] * world
+        dist.all_gather_object(placements, placement)
 
     result = None
     if rank == 0:
@@ -568,6 +699,9 @@ def decode_bench(args):
             'ms_per_step_by_rank': [1e3 * x / args.steps for x in per_rank_s],
             'gather_ms_per_step': gather_ms if dist_on else 0.0,
         }
+        if world > 1:
+            # where each rank's host side ran: CPU list (NUMA node of its GPU where the host says which) and BLAS / OpenMP threads
+            result['config']['host_placement_by_rank'] = placements
         if wl.get('confmat') and want_align:
             result['realign_ms_per_step'] = realign_ms       # inside ms_per_step: host time of the Viterbi re-alignment
         if dist_on:
@@ -576,25 +710,30 @@ def decode_bench(args):
                 np.save(args.dump_records, np.asarray(last, np.int32))
         if prof is not None and prof['launches']:
             achieved = prof['flops'] / max(prof['ms'], 1e-9) / 1e9            # TFLOP/s
-            traffic = None
+            # HBM-side bytes per launch of the dominant kernel: NOT measured by this run -- a constant from the committed rocprofv3
+            # PMC passes over this same command (profiles/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE in separate passes), named here
+            traffic, traffic_source = None, None
+            tname = {'persist': 'persist_decode_traffic.json'}.get(dom) or \
+                ('page_gemm_traffic.json' if args.workload == 'page' else
+                 ('split256_gemm_traffic.json' if args.split_bf16 == 2 else (None if args.split_bf16 == 1 else 'lstm_gemm_traffic.json')))
             try:
-                with open(os.path.join(ROOT, 'profiles', 'persist_decode_traffic.json' if dom == 'persist' else
-                                       ('split256_gemm_traffic.json' if args.split_bf16 == 2 else 'lstm_gemm_traffic.json'))) as f:
-                    traffic = json.load(f).get('hbm_bytes_per_launch')
+                with open(os.path.join(ROOT, 'profiles', tname)) as f:
+                    tj = json.load(f)
+                traffic = tj.get('hbm_bytes_per_launch')
+                traffic_source = ('profiles/%s: constant from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s (commit %s) over this '
+                                  'command, not a measurement of this run' % (tname, tj.get('round', '?'), tj.get('commit', '?')))
             except Exception:
                 pass
-            if args.workload == 'page' or args.split_bf16 == 1:
-                traffic = None          # the committed PMC passes were taken on the c3 shapes (and for the kernels named in them)
             result['roofline'] = {
                 'bound': 'mfma',
                 'kernel': ('gemm_kernel<EPI_LSTM, 1> (fused LSTM-cell GEMM, 128x128 tiles, fp32 MFMA)' if not args.split_bf16 else
                            'fused LSTM-cell GEMM on v_mfma_f32_32x32x16_bf16, bf16x3-split operands: ' +
                            ('gemm_kernel<EPI_LSTM, 1, split> 128x128 tiles' if args.split_bf16 == 1 else 'gemm_split256_kernel 256x256 tiles') +
-                           '; achieved / peak / frac are ALGORITHMIC fp32 FLOP against the fp32-MFMA peak (the executed bf16 FLOP are 6x)')
+                           '; achieved / peak / frac are the EXECUTED bf16 FLOP (6 per algorithmic fp32 one) against the dense bf16-MFMA peak')
                           if dom == 'lstm_gemm' else 'persist_decode_kernel (all 2T greedy steps of the batch in one launch: 16x16x4 fp32-MFMA tiles, '
                                'row-block hand-offs between workgroups)',
                 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
                 'launches': prof['launches'], 'avg_launch_us': 1e3 * prof['ms'] / max(prof['launches'], 1),
                 'flops_per_launch': prof['flops'] / max(prof['launches'], 1),
                 # the whole path priced with SURVEY.md section 8(d)'s algorithmic FLOP per corrected character
@@ -608,14 +747,23 @@ def decode_bench(args):
                                'hbm_bytes_per_char': qpc,
                                'hbm_frac': chars / elapsed * qpc / world / PEAK_HBM_BYTES_PER_S}}
         if args.split_bf16 and 'roofline' in result:
-            # the instruction the experiment runs on: six bf16 products per algorithmic one, against the dense bf16-MFMA peak
-            result['roofline']['bf16_mfma'] = {'achieved': 6.0 * result['roofline']['achieved'], 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                               'frac': 6.0 * result['roofline']['achieved'] / PEAK_BF16_MFMA_TFLOPS}
+            # The split kernels run on the bf16 matrix instruction: six bf16 products per algorithmic fp32 one.  Their roofline is the
+            # dense bf16-MFMA peak; the algorithmic fp32 rate stays in the line as a rate, not as a fraction of a peak it is not bound by.
+            rl = result['roofline']
+            rl['algorithmic_fp32_tflops'] = rl['achieved']
+            rl['achieved'], rl['peak'] = 6.0 * rl['achieved'], PEAK_BF16_MFMA_TFLOPS
+            rl['frac'] = rl['achieved'] / PEAK_BF16_MFMA_TFLOPS
+            rl['bf16_mfma'] = {'achieved': rl['achieved'], 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': rl['frac']}
+            for k in ('frac', 'frac_executed'):        # (whole-path prices against the fp32 peak mean nothing here either)
+                rl['whole_path'].pop(k, None)
+            rl['whole_path']['note'] = 'achieved = algorithmic fp32 TFLOP/s of the whole path; no fraction: the path is not bound by the fp32-input instruction under this option'
         if others:
             result['kernel_ms_per_step'] = {k: v['ms'] for k, v in others.items()}     # from one extra untimed step
-        if world == 1 and not args.no_cpu_baseline and not dry and not wl.get('confmat'):
+        if world == 1 and not args.no_cpu_baseline and not dry:
+            beam = {('rejection_threshold' if k == 'rejection' else k): wl[k] for k in ('rejection', 'beam_width_in', 'beam_threshold_in') if k in wl}
             result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64], wl['n'] if not wl['fast'] else 256, wl['fast'], L,
-                                                  budget_s=args.cpu_budget)
+                                                  budget_s=args.cpu_budget, confmat=bool(wl.get('confmat')),
+                                                  min_lines=1 if wl.get('confmat') else 4, **beam)
     if comm:
         comm.close()
     elif dist_on:
@@ -641,7 +789,7 @@ def other_workloads(with_cpu_baseline=True):
                         # the headline's workload under the split-bf16 experiment: reported here only
                         ('c3_split_bf16', ['--steps', '5', '--warmup', '2', '--split-bf16', '2'])):
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', name.split('_')[0], '--no-others'] + extra
-        cmd += ['--cpu-budget', '8'] if name == 'c2' and with_cpu_baseline else ['--no-cpu-baseline']
+        cmd += ['--cpu-budget', '8'] if name in ('c2', 'page') and with_cpu_baseline else ['--no-cpu-baseline']
         env = {k: v for k, v in os.environ.items() if not k.startswith('CASV_BENCH_')}
         try:
             t0 = time.perf_counter()
@@ -654,9 +802,9 @@ def other_workloads(with_cpu_baseline=True):
             keep = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype') if k in r}
             keep['workload'] = r['config']['workload']
             if 'roofline' in r:
-                keep['roofline'] = {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_us')
+                keep['roofline'] = {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'launches', 'avg_launch_us', 'algorithmic_fp32_tflops')
                                     if k in r['roofline']}
-                if 'whole_path' in r['roofline']:
+                if 'whole_path' in r['roofline'] and 'frac' in r['roofline']['whole_path']:
                     keep['roofline']['whole_path_frac'] = r['roofline']['whole_path']['frac']
                 if 'bf16_mfma' in r['roofline']:
                     keep['roofline']['bf16_mfma'] = r['roofline']['bf16_mfma']

@@ -62,6 +62,7 @@ SIGNATURES = {
     'casv_profile_read': (c_int, [c_void_p, c_char_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double),
                                   POINTER(c_double)]),
     'casv_debug_gemm': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_double)]),
+    'casv_debug_contract': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     'casv_set_option': (c_int, [c_void_p, c_char_p, c_int64]),
     'casv_get_alignments_sparse': (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     'casv_comm_unique_id': (c_int, [c_void_p]),

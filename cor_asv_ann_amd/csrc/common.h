@@ -169,6 +169,8 @@ void gemm_split_prepare(const float* Bt, int N, int K, hipStream_t stream);    /
 void gemm_split_invalidate(const float* Bt);     // drops the pre-split image of a weight buffer (call where it changes or is released); nullptr: all
 bool launch_gemm_split256(int epi, const GemmBatch& b, hipStream_t stream);     // false: not launched (the caller takes another path)
 int gemm_split_bf16();
+long gemm_split_epoch();                   // changes whenever the option or a pre-split weight image does (key of captured step graphs)
+void gemm_split_bump_epoch();
 
 // ---- small kernels (decode_kernels.hip) ----
 struct AttnArgs {

@@ -682,7 +682,8 @@ struct StepRunner {
     // so their identity is part of the key too.
     StepRunner(casv_model* m_, const std::string& key_)
         : m(m_), key(key_ + "/" + std::to_string(g_devbuf_generation) + "/" + std::to_string((unsigned long long)(uintptr_t)m_->enc_out) +
-                     "/" + std::to_string((unsigned long long)(uintptr_t)m_->u.p) + "/" + std::to_string((int)m_->has_a0)) {}
+                     "/" + std::to_string((unsigned long long)(uintptr_t)m_->u.p) + "/" + std::to_string((int)m_->has_a0) +
+                     "/" + std::to_string(gemm_split_bf16()) + "." + std::to_string(gemm_split_epoch())) {}
     static void drop(casv_model* m) {
         if (m->step_exec) { (void)hipStreamSynchronize(m->stream); (void)hipGraphExecDestroy(m->step_exec); m->step_exec = nullptr; }
         if (m->step_graph) { (void)hipGraphDestroy(m->step_graph); m->step_graph = nullptr; }
@@ -1193,6 +1194,38 @@ extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N
     s2_clock_dump();
 #endif
     A.release(); Bt.release(); bias.release(); C.release(); cst.release(); rows.release();
+    return CASV_OK;
+}
+
+// Test support: ONE plain contraction on the caller's operands through the library's launcher (whatever tile shape, split-K form
+// and arithmetic the options select), result back to the host.
+extern "C" int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int32_t N, int32_t K, const float* A_, const float* Bt_,
+                                   const float* bias_, float* C_) {
+    if (!m || !A_ || !Bt_ || !C_) return fail(CASV_ERR_ARG, "null argument");
+    if (M < 1 || N < 1 || K < 32 || K % 32) return fail(CASV_ERR_ARG, "M, N positive, K a positive multiple of 32");
+    HIPCHK(hipSetDevice(m->device));
+    DevBuf A, Bt, bias, C;
+    if (int rc = A.ensure((size_t)M * K * 4)) return rc;
+    if (int rc = Bt.ensure((size_t)N * K * 4)) return rc;
+    if (int rc = bias.ensure((size_t)N * 4)) return rc;
+    if (int rc = C.ensure((size_t)M * N * 4)) return rc;
+    HIPCHK(hipMemcpyAsync(A.p, A_, (size_t)M * K * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(Bt.p, Bt_, (size_t)N * K * 4, hipMemcpyHostToDevice, m->stream));
+    if (bias_) HIPCHK(hipMemcpyAsync(bias.p, bias_, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemsetAsync(C.p, 0xff, (size_t)M * N * 4, m->stream));           // (NaN: an element the launch does not write shows)
+    GemmArgs g{};
+    g.nseg = 1; g.a[0] = mkseg(A.as<float>(), K, K, 0);
+    g.Bt = Bt.as<float>(); g.bias = bias_ ? bias.as<float>() : nullptr; g.M = M; g.N = N; g.Ktot = K;
+    g.out = mkslot(C.as<float>(), N);
+    if (flags & 1) g.ksplit = -1;               // the launcher may split K over workgroups (train step's plain contractions)
+    if (flags & 2) g.kgroups = 2;               // ... and over two wave groups of a workgroup
+    if (flags & 4) g.b_static = 1;              // Bt is a weight: the split-bf16 arithmetic may keep a pre-split image of it
+    launch_gemm(EPI_PLAIN, g, m->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(C_, C.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    gemm_split_invalidate(Bt.as<float>());
+    A.release(); Bt.release(); bias.release(); C.release();
     return CASV_OK;
 }
 

@@ -495,7 +495,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         // (c0 >= 4: tiles 2 and 3 lie in the layer input too -- their addresses do not wait for the gathered segments' row indices)
         {
             const char *qa0, *qa1, *ra0, *ra1; const float *qb0, *qb1, *rb0, *rb1;
-            if (kt_begin == 0 && c0 >= 4) {
+            if (KS == 1 && kt_begin == 0 && c0 >= 4) {      // (KS = 2: a wave group's tiles 2 and 3 are tiles 4 + grp and 6 + grp)
                 qa0 = (const char*)(ap0[0] + 2 * BK); qa1 = (const char*)(ap0[1] + 2 * BK); qb0 = bp[0] + koff0 + 2 * BK; qb1 = bp[1] + koff0 + 2 * BK;
                 ra0 = (const char*)(ap0[0] + 3 * BK); ra1 = (const char*)(ap0[1] + 3 * BK); rb0 = bp[0] + koff0 + 3 * BK; rb1 = bp[1] + koff0 + 3 * BK;
                 asm volatile("" : "+v"(qa0), "+v"(ra0));           // (keeps the two paths apart: a select would wait for the indices)
@@ -769,7 +769,12 @@ void set_gemm_tile_mode(int mode) { g_tile_mode = mode; }
 // operands on the bf16 matrix instruction (1: gemm_tile's SPLIT variant; 2: as 256x256 tiles, gemm_split.hip, where a job fills
 // the chip that way, else as 1).  Process-wide, like the tile shape.
 static int g_split_bf16 = [] { const char* e = getenv("CASV_SPLIT_BF16"); return e && (e[0] == '1' || e[0] == '2') && !e[1] ? e[0] - '0' : 0; }();
-void set_gemm_split_bf16(int on) { g_split_bf16 = on < 0 ? 0 : on > 2 ? 2 : on; }
+// (a captured step graph bakes in the arithmetic and the addresses of the pre-split weight images: both are part of its key through
+// this counter -- engine.hip, StepRunner)
+static long g_split_epoch = 0;
+long gemm_split_epoch() { return g_split_epoch; }
+void gemm_split_bump_epoch() { ++g_split_epoch; }
+void set_gemm_split_bf16(int on) { const int v = on < 0 ? 0 : on > 2 ? 2 : on; if (v != g_split_bf16) ++g_split_epoch; g_split_bf16 = v; }
 int gemm_split_bf16() { return g_split_bf16; }
 
 static int count_ktiles(const GemmArgs& g) {

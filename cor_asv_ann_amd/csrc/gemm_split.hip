@@ -637,6 +637,7 @@ static const void* split_image_of(const float* Bt, int N, int K, hipStream_t str
     if (it != g_images.end()) {
         (void)hipFree(it->second.img);
         g_images.erase(it);
+        gemm_split_bump_epoch();
     }
     void* img = nullptr;
     if (hipMalloc(&img, (size_t)N * K * 6) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -664,7 +665,7 @@ void gemm_split_prepare(const float* Bt, int N, int K, hipStream_t stream) {
 void gemm_split_invalidate(const float* Bt) {        // the image(s) of one weight buffer; nullptr: all
     std::lock_guard<std::mutex> lock(g_img_mutex);
     for (auto it = g_images.begin(); it != g_images.end();) {
-        if (!Bt || it->first.second == Bt) { (void)hipFree(it->second.img); it = g_images.erase(it); }     // (hipFree waits for the device: nothing still reads it)
+        if (!Bt || it->first.second == Bt) { (void)hipFree(it->second.img); it = g_images.erase(it); gemm_split_bump_epoch(); }     // (hipFree waits for the device: nothing still reads it; a captured step graph that holds the address is rebuilt)
         else ++it;
     }
 }

@@ -681,7 +681,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             const size_t cb = train_recurrence_bwd_counter_bytes(B);
             ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
             // d_enc / du summed behind the recurrence instead of by float atomics inside it (attn_bwd.h, DEFER)
-            static const int defer_opt = [] { const char* e = getenv("CASV_ATTN_DEFER"); return e ? atoi(e) : 1; }();
+            static const int defer_opt = [] { const char* e = getenv("CASV_ATTN_DEFER"); const int v = e ? atoi(e) : 1; return v == 3 ? 3 : v == 0 ? 0 : 1; }();       // (the recurrence has forms 0, 1 and 3 only)
             const int defer = (T <= ATTN_DEFER_MAX_T && W % 64 == 0 && C % 64 == 0) ? defer_opt : 0;
             ra.DS = defer ? ts->DSrows.as<float>() : nullptr; ra.defer = defer;
             if (const int grid = train_attention_cell_bwd_grid(ra, m->ncu)) {

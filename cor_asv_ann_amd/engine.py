@@ -339,6 +339,17 @@ class HipEngine(object):
     def set_option(self, key, value):
         nv.check(self.lib.casv_set_option(self.handle, key.encode(), int(value)))
 
+    def debug_contract(self, A, Bt, bias=None, split_k=False, wave_groups=False, weight=False):
+        """Test support (casv_debug_contract): C = A . Bt^T (+ bias) through the launcher all GEMMs of the path go through."""
+        A, Bt = nv.carray(A, np.float32), nv.carray(Bt, np.float32)
+        bias = None if bias is None else nv.carray(bias, np.float32)
+        (M, K), N = A.shape, Bt.shape[0]
+        assert Bt.shape[1] == K and (bias is None or bias.shape == (N,))
+        C = np.empty((M, N), np.float32)
+        flags = (1 if split_k else 0) | (2 if wave_groups else 0) | (4 if weight else 0)
+        nv.check(self.lib.casv_debug_contract(self.handle, flags, M, N, K, nv.ptr(A), nv.ptr(Bt), nv.ptr(bias), nv.ptr(C)))
+        return C
+
     def alignments_sparse(self, rows, steps, K=None):
         """Window form of the last decode call's soft alignments: (lo int32 (rows, S), w float32 (rows, S, K))."""
         K = int(K or 2 * self.window_width + 1)

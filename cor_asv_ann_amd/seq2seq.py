@@ -27,6 +27,36 @@ _UNSUPPORTED = ('residual_connections', 'deep_bidirectional_encoder', 'bridge_de
                 'lm_predict', 'scheduled_sampling', 'stateful')
 
 
+class _ShortSwitchInterval(object):
+    """The interpreter's thread switch interval is process-wide: a counted guard, so that overlapping pipelines (two
+    `correct_batches` generators, or one that is never exhausted) neither restore each other's saved value in the wrong
+    order nor leave the short interval behind.  Entered around the stretches in which a pipeline's consumer thread runs
+    Python beside its device thread, left before every yield."""
+    _lock = __import__('threading').Lock()
+    _users = 0
+    _saved = None
+
+    def __enter__(self):
+        import sys
+        cls = _ShortSwitchInterval
+        with cls._lock:
+            if cls._users == 0:
+                cls._saved = sys.getswitchinterval()
+                sys.setswitchinterval(min(cls._saved, float(os.environ.get('CASV_SWITCH_INTERVAL', '1e-4'))))
+            cls._users += 1
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        cls = _ShortSwitchInterval
+        with cls._lock:
+            cls._users -= 1
+            if cls._users == 0 and cls._saved is not None:
+                sys.setswitchinterval(cls._saved)
+                cls._saved = None
+        return False
+
+
 class Sequence2Sequence(object):
     """Character-level encoder-attention-decoder corrector (API of seq2seq.py:13)."""
 
@@ -601,7 +631,6 @@ class Sequence2Sequence(object):
         batch by batch, in order; identical results.  `after_decode(k)`, if given, runs in the device thread right after batch
         k's decode call (its results still lie in the engine's buffers: e.g. `engine.records_append`)."""
         assert not fast or greedy, "cannot decode in fast mode with beam search enabled"
-        import sys
         from .training import prefetch
         self._require_engine()
         self._codepoint_table()                 # (the lookup tables exist before the stages' threads ask for them)
@@ -614,23 +643,42 @@ class Sequence2Sequence(object):
                 lines, conf = item if pair else (item, None)
                 yield lines, (self._prepare_lines(lines, conf) if lines else None)
 
+        import threading
+        closing, in_call = threading.Event(), threading.Event()
+
         def decoded():
-            for k, (lines, prep) in enumerate(prefetch(prepared(), depth=2)):
-                raw = self._decode_prepared(prep, fast, greedy, alignments, [bool(line) for line in lines]) if lines else None
-                if after_decode is not None and raw is not None:      # (no decode ran: the engine still holds the batch before)
-                    after_decode(k)
+            for k, (lines, prep) in enumerate(prefetch(prepared(), depth=2, cancel=closing)):
+                if closing.is_set():            # (the consumer has left: no further call on the engine)
+                    return
+                in_call.set()
+                try:
+                    raw = self._decode_prepared(prep, fast, greedy, alignments, [bool(line) for line in lines]) if lines else None
+                    # (no decode ran -- no lines, nothing but padding, or no live line in the per-line greedy mode --: the engine
+                    # still holds the batch before)
+                    ran = raw is not None and (fast or bool(raw[0]))
+                    if after_decode is not None and ran:
+                        after_decode(k)
+                finally:
+                    in_call.clear()
                 yield lines, prep, raw
 
         # The device stage needs the interpreter lock only between its C-ABI calls; the string building of the stage behind it
         # is pure Python and gives the lock up once per switch interval (5 ms by default: up to half a millisecond of idle GPU
-        # between two batches of configs[1], rocprofv3 trace of round 4).  A short interval while the pipeline runs.
-        interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(interval, float(os.environ.get('CASV_SWITCH_INTERVAL', '1e-4'))))
+        # between two batches of configs[1], rocprofv3 trace of round 4).  A short interval while THIS generator runs -- not
+        # while it is suspended at a yield or abandoned: the setting is process-wide (_ShortSwitchInterval counts its users).
+        stage = prefetch(decoded(), depth=1, in_call=in_call)
         try:
-            for lines, prep, raw in prefetch(decoded(), depth=1):
-                yield self._results_of(lines, prep, raw, fast, greedy, alignments) if lines else ([], [], [], [])
+            while True:
+                with _ShortSwitchInterval():
+                    try:
+                        lines, prep, raw = next(stage)
+                    except StopIteration:
+                        return
+                    result = self._results_of(lines, prep, raw, fast, greedy, alignments) if lines else ([], [], [], [])
+                yield result
         finally:
-            sys.setswitchinterval(interval)
+            closing.set()
+            stage.close()
 
     # the three stages of correct_lines ------------------------------------------------------------
     def _prepare_lines(self, lines, conf):

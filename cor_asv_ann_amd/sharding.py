@@ -158,6 +158,25 @@ class NativeComm(object):
         return np.concatenate([out[r, :shard_bounds(n_total, self.world, r)[1] - shard_bounds(n_total, self.world, r)[0]]
                                for r in range(self.world)], axis=0)
 
+    def all_gather_objects(self, obj, width=1024):
+        """A small JSON-serialisable object of every rank, in rank order (reports: per-rank times, host placement) -- one
+        casv_comm_all_gather of a fixed-width record."""
+        import json
+        raw = json.dumps(obj).encode()
+        if len(raw) > width - 4:
+            raise ValueError('object of %d bytes does not fit a %d-byte record' % (len(raw), width))
+        mine = np.zeros(width, np.uint8)
+        mine[:4] = np.frombuffer(np.int32(len(raw)).tobytes(), np.uint8)
+        mine[4:4 + len(raw)] = np.frombuffer(raw, np.uint8)
+        out = np.empty(self.world * width, np.uint8)
+        self.nv.check(self.engine.lib.casv_comm_all_gather(self.engine.handle, self.nv.ptr(mine), self.nv.ptr(out), width))
+        res = []
+        for r in range(self.world):
+            rec = out[r * width:(r + 1) * width]
+            n = int(np.frombuffer(rec[:4].tobytes(), np.int32)[0])
+            res.append(json.loads(rec[4:4 + n].tobytes().decode()))
+        return res
+
     def max(self, value):
         """Maximum of a float over the ranks (also a barrier)."""
         from ctypes import byref, c_double

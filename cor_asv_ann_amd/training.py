@@ -10,11 +10,17 @@ import numpy as np
 from . import keras_h5
 
 
-def prefetch(iterable, depth=2):
+def prefetch(iterable, depth=2, cancel=None, in_call=None, detach_after=5.0):
     """Run `iterable` in a worker thread, `depth` items ahead of the consumer -- the reference feeds `train_on_batch` from a
     `GeneratorEnqueuer` worker (keras_train.py:133-145) so that vectorising the next batch overlaps the device step; here the
     C ABI call releases the GIL for the whole step, so a thread does.  Exceptions of the producer surface in the consumer;
-    a consumer that stops early (NaN loss, stop signal) releases the producer."""
+    a consumer that stops early (NaN loss, stop signal) releases the producer.
+
+    Leaving early: the worker is joined.  While `in_call` (an Event the producer sets around its C-ABI calls) is set the
+    wait is unbounded -- the caller must not get the engine back while a call runs on it, the handle is not thread-safe --;
+    a worker that is merely blocked in `next(iterable)` (a user generator reading a pipe, a nested stage) is left behind
+    after `detach_after` seconds (a daemon thread; its next put() sees `stop`).  `cancel`: an Event of the caller that ends
+    the consumer loop as well (a nested stage's consumer is another stage's worker: it must not sit in q.get() for good)."""
     q = queue.Queue(maxsize=max(1, depth))
     done, stop = object(), threading.Event()
 
@@ -41,7 +47,15 @@ def prefetch(iterable, depth=2):
     thread.start()
     try:
         while True:
-            kind, item = q.get()
+            if cancel is None:
+                kind, item = q.get()
+            else:
+                try:
+                    kind, item = q.get(timeout=0.1)
+                except queue.Empty:
+                    if cancel.is_set():
+                        return
+                    continue
             if kind == 'done':
                 return
             if kind == 'error':
@@ -49,10 +63,14 @@ def prefetch(iterable, depth=2):
             yield item
     finally:
         stop.set()
-        # No timeout: a worker that drives the device (correct_batches' second stage) may be inside a C-ABI call on the engine
-        # when its consumer leaves early; the caller must not get the engine back while that call runs (the handle is not
-        # thread-safe).  The worker returns after the call in progress: its next put() sees `stop`.
-        thread.join()
+        waited = 0.0
+        while thread.is_alive():
+            thread.join(0.1)
+            if in_call is not None and in_call.is_set():
+                continue                        # a device call of the worker is in flight: wait it out, however long it takes
+            waited += 0.1
+            if waited >= detach_after:
+                break
 
 
 def train_batches(s2s, filenames, split_rand, rng):

@@ -219,6 +219,13 @@ int casv_profile_read(casv_model* m, const char* name, int64_t* launches, double
  * operands; lstm=1 selects the fused LSTM-cell epilogue (N = 4*units), gather=1 a permuted row index. */
 int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K, int32_t gather,
                     int32_t iters, double* ms_per_launch);
+/* Test support: ONE plain contraction C (M,N) = A (M,K) . Bt (N,K)^T (+ bias (N) or NULL) on the caller's operands through the
+ * launcher every GEMM of the path goes through -- with whatever tile shape ("tile") and arithmetic ("split_bf16") the options
+ * select; K a multiple of 32.  flags: 1 = the launcher may split K over workgroups and 2 = over the two wave groups of a
+ * workgroup (the forms the train step's contractions take: sums in another order), 4 = Bt counts as a weight (the split-bf16
+ * arithmetic keeps a pre-split image of it for the call).  tests/test_gpu_gemm.py compares the result with a float64 product. */
+int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int32_t N, int32_t K, const float* A, const float* Bt,
+                        const float* bias, float* C);
 /* Options: "graph" = replay the decode step through a captured hipGraph (1) or launch kernels eagerly (0);
  * "persistent" = greedy decoding through the persistent decoder (all steps in ONE launch, workgroups hand rows to each
  * other through memory: small batches, where a step is too short for a launch per kernel): -1 by batch size (default:

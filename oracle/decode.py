@@ -106,7 +106,9 @@ def vectorize_lines(m, encoder_input_sequences, decoder_input_sequences, encoder
 
 
 def decode_batch_greedy(m, encoder_input_data, return_indexes=False):
-    """seq2seq.py:1215-1286: 2T fixed steps, argmax without index 0, full softmax fed back."""
+    """seq2seq.py:1215-1286: 2T fixed steps, argmax without index 0, full softmax fed back.
+    return_indexes: also the (B, 2T) matrix of the indices picked at every step (the reference keeps them only up to a line's
+    newline); 'probs': and the matrix of their probabilities."""
     V = m.voc_size
     i_c = m.mapping[1]
     enc = m.encode(encoder_input_data)
@@ -120,6 +122,7 @@ def decode_batch_greedy(m, encoder_input_data, return_indexes=False):
     scores_acc = [0.] * B
     aligns = [[] for _ in range(B)]
     all_idx = np.zeros((B, 2 * T), np.int64)
+    all_prob = np.zeros((B, 2 * T), np.float64)
     nonpad = [bool(np.any(encoder_input_data[j])) for j in range(B)]
     for i in range(T * 2):
         dec_out_data[:, i] = dec_in          # uint32 truncation quirk
@@ -127,6 +130,7 @@ def decode_batch_greedy(m, encoder_input_data, return_indexes=False):
         alignment = states[-1]
         indexes = np.nanargmax(scores[:, 1:], axis=1) + 1     # s2s:1250
         all_idx[:, i] = indexes
+        all_prob[:, i] = scores[np.arange(B), indexes]
         dec_in = scores                                        # s2s:1252
         with np.errstate(divide='ignore'):
             logscores = -np.log(scores)
@@ -140,6 +144,8 @@ def decode_batch_greedy(m, encoder_input_data, return_indexes=False):
     for j in range(B):
         if seqs[j]:
             scores_acc[j] /= len(seqs[j])
+    if return_indexes == 'probs':
+        return dec_out_data, seqs, probs, scores_acc, aligns, all_idx, all_prob
     if return_indexes:
         return dec_out_data, seqs, probs, scores_acc, aligns, all_idx
     return dec_out_data, seqs, probs, scores_acc, aligns

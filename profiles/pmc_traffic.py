@@ -43,6 +43,8 @@ def main():
     write_kb, n2 = per_kernel_average(sys.argv[2], 'WRITE_SIZE')
     out = {'hbm_bytes_per_launch': (fetch_scale * fetch_kb + write_kb) * 1024.0, 'fetch_scale': fetch_scale, 'fetch_kb_raw_avg': fetch_kb, 'write_kb_raw_avg': write_kb,
            'launches': n1, 'kernel': KERNEL,
+           # which build the passes were taken on (bench.py names both beside roofline.traffic: the figure is a committed constant)
+           'round': int(os.environ.get('CASV_PROFILE_ROUND', '0')) or None, 'commit': os.environ.get('CASV_PROFILE_COMMIT'),
            'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 1; average over all '
                    'dispatches of the kernel; FETCH x fetch_scale (2: the gfx950 correction for 16-B-per-lane reads); '
                    'WRITE_SIZE uncalibrated for 4-B-per-lane stores.' + (' First version of round 1 (round-robin tile order): fetch '

@@ -244,6 +244,43 @@ def test_multi_gpu_launch_defaults_to_the_configs4_shape():
     assert out['config']['lines_per_decode_call'] == 1024
 
 
+def test_rank_placement_follows_the_numa_node_of_the_gpu(tmp_path, monkeypatch):
+    """bench.py's host placement (what the eight processes share on the host is the scaling risk): the NUMA
+    node of every GPU from the KFD topology in sysfs -- no GPU call -- and per rank a disjoint share of that node's CPUs."""
+    import bench
+    sysfs = tmp_path / 'sys'
+    # a host like an 8-GPU node: KFD nodes 0, 1 = the two CPU sockets, nodes 2..9 = GPUs on render minors 128..135
+    for i in range(10):
+        d = sysfs / 'class' / 'kfd' / 'kfd' / 'topology' / 'nodes' / str(i)
+        d.mkdir(parents=True)
+        gpu = i >= 2
+        (d / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\ndrm_render_minor %d\n' % (0 if gpu else 96, 1024 if gpu else 0, 126 + i if gpu else 0))
+        if gpu:
+            r = sysfs / 'class' / 'drm' / ('renderD%d' % (126 + i)) / 'device'
+            r.mkdir(parents=True)
+            (r / 'numa_node').write_text('%d\n' % (0 if i < 6 else 1))
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES', raising=False)
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False)
+    assert bench.gpu_numa_nodes(str(sysfs)) == [0, 0, 0, 0, 1, 1, 1, 1]
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '4,1')
+    assert bench.gpu_numa_nodes(str(sysfs)) == [1, 0]
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    assert bench.gpu_numa_nodes(str(tmp_path / 'nothing')) is None
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    cpus_of_node = {0: list(range(0, 48)) + list(range(96, 144)), 1: list(range(48, 96)) + list(range(144, 192))}
+    shares = [bench.rank_cpus(r, 8, range(192), numa, cpus_of_node) for r in range(8)]
+    assert [n for _, n in shares] == numa
+    assert all(len(c) == 24 and set(c) <= set(cpus_of_node[n]) for c, n in shares)
+    assert len(set().union(*[set(c) for c, _ in shares])) == 192                       # disjoint, nothing left idle
+    # a cpuset that leaves a node fewer CPUs than it has ranks: the even share of everything allowed instead
+    tight = [bench.rank_cpus(r, 8, list(range(0, 2)) + list(range(48, 96)), numa, cpus_of_node)[0] for r in range(8)]
+    assert all(tight) and sum(len(c) for c in tight) == len(set().union(*[set(c) for c in tight])) == 50
+    # no topology at all (this container): contiguous shares of the allowed CPUs
+    plain = [bench.rank_cpus(r, 4, range(8))[0] for r in range(4)]
+    assert plain == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    assert bench.format_cpulist(bench.parse_cpulist('0-3,8,10-11')) == '0-3,8,10-11'
+
+
 def test_eight_ranks_of_configs4_rehearsed_without_a_device(tmp_path):
     """BASELINE configs[4] with all EIGHT ranks on this host, dry (CASV_BENCH_DRY_RUN: every rank echoes its 8192 lines instead of
     decoding them; gloo carries the gather): launcher, sharding, record packing, the all-gather of 65 536 records and the
@@ -262,6 +299,16 @@ def test_eight_ranks_of_configs4_rehearsed_without_a_device(tmp_path):
     wl = bench.WORKLOADS['c5']
     assert out['n_gpus'] == 8 and out['gathered_records'] == 65536 and out['config']['lines_per_gpu'] == 8192
     assert len(out['ms_per_step_by_rank']) == 8
+    # every rank reports its OWN time (not rank 0's eight times) and ran on CPUs of its own: disjoint sets that cover no more
+    # than the host offers, BLAS / OpenMP threads capped at the rank's share
+    assert len(set(out['ms_per_step_by_rank'])) == 8, out['ms_per_step_by_rank']
+    place = out['config']['host_placement_by_rank']
+    assert len(place) == 8 and all(p and p['threads'] >= 1 for p in place), place
+    sets = [set(bench.parse_cpulist(p['cpus'])) for p in place]
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert all(sets) and sum(len(x) for x in sets) == len(set().union(*sets)), place          # pairwise disjoint
+        assert set().union(*sets) <= set(os.sched_getaffinity(0))
+        assert all(p['threads'] == len(x) for p, x in zip(place, sets))
     rec = np.load(dump)
     S = 2 * (wl['length'] + 1)
     assert rec.shape == (65536, 2 * S + 4)

@@ -281,6 +281,7 @@ def test_pipelined_batches_equal_one_call_per_batch(mode):
         conf = [list(rng.uniform(0.5, 1.0, len(line)).astype(np.float32)) for line in lines] if k == 3 else None
         batches.append((lines, conf))
     batches.insert(2, ([], None))
+    batches.insert(4, (['', ''], None))                       # nothing but padding lines: no decode call either
     fast, greedy = mode == 'fast', mode != 'beam'
     want = []
     for lines, conf in batches:
@@ -288,11 +289,22 @@ def test_pipelined_batches_equal_one_call_per_batch(mode):
             want.append(s2s.correct_lines(lines, conf, fast=fast, greedy=greedy))
         except ValueError:                                      # the per-line greedy mode's NaN rule (seq2seq.py:1334)
             pytest.skip('this seed trips the NaN rule of the per-line greedy mode')
-    seen = []
-    got = list(s2s.correct_batches(batches, fast=fast, greedy=greedy, after_decode=seen.append))
-    # the hook runs behind every batch that was decoded -- not behind the empty one, whose "results" in the engine would be the
+    import sys
+    seen, got = [], []
+    interval = sys.getswitchinterval()
+    for item in s2s.correct_batches(batches, fast=fast, greedy=greedy, after_decode=seen.append):
+        assert sys.getswitchinterval() == interval           # (the pipeline's short interval is not held across a yield)
+        got.append(item)
+    assert sys.getswitchinterval() == interval
+    # the hook runs behind every batch that was decoded -- not behind the empty ones, whose "results" in the engine would be the
     # batch before's
-    assert seen == [k for k, (lines, _) in enumerate(batches) if lines] and len(got) == len(want)
+    assert seen == [k for k, (lines, _) in enumerate(batches) if any(lines)] and len(got) == len(want)
+    # a pipeline that is abandoned half way gives the engine back (and the interval): the next call works
+    gen = s2s.correct_batches(batches, fast=fast, greedy=greedy)
+    next(gen); gen.close()
+    assert sys.getswitchinterval() == interval
+    again = s2s.correct_lines(batches[0][0], batches[0][1], fast=fast, greedy=greedy)
+    assert again[0] == want[0][0]
     for g, w in zip(got, want):
         assert g[0] == w[0] and g[1] == w[1] and g[2] == w[2]
         assert len(g[3]) == len(w[3])

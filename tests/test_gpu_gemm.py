@@ -1,0 +1,92 @@
+"""The GEMM launcher alone, on caller-given operands (C ABI: casv_debug_contract), against a float64 product on the host.
+
+What the end-to-end parity tests cannot see: launch forms that only the train step's big contractions take (K split over
+workgroups and over the two wave groups of a workgroup -- ADVICE round 4 found a wrong prologue shortcut there by reading the
+code), and HOW accurate each arithmetic is: the fp32-input kernels' k-ordered fmaf chain against the split-bf16 kernels' six
+bf16 products per K tile, both measured against float64 on the bench's operand shapes.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def engine():
+    from cor_asv_ann_amd.engine import HipEngine
+    eng = HipEngine(1, 32, 8)
+    try:
+        yield eng
+    finally:
+        eng.set_option('split_bf16', 0)
+        eng.set_option('tile', -1)
+        eng.close()
+
+
+def _operands(M, N, K, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    A = (rng.standard_normal((M, K)) * scale).astype(np.float32)
+    Bt = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    return A, Bt, bias
+
+
+def _errors(C, A, Bt, bias):
+    """(rms, max) error of C against the float64 product, in units of the float32 spacing of sum |a||b| (what a forward
+    error bound of any summation order is stated in)."""
+    ref = A.astype(np.float64) @ Bt.astype(np.float64).T + bias.astype(np.float64)
+    mag = np.abs(A).astype(np.float64) @ np.abs(Bt).astype(np.float64).T + np.abs(bias)
+    err = (C.astype(np.float64) - ref) / (mag * 2.0 ** -24)
+    assert np.isfinite(C).all(), 'an element was not written'
+    return float(np.sqrt(np.mean(err ** 2))), float(np.abs(err).max())
+
+
+@pytest.mark.parametrize('shape', [(2048, 1024, 512), (2048, 1024, 1024), (1536, 1024, 768), (512, 2048, 512), (51712 // 8, 512, 512)])
+@pytest.mark.parametrize('tile', [-1, 0])
+def test_split_k_forms_of_the_plain_contraction(engine, shape, tile):
+    """K split over workgroups (float atomics) and over the two wave groups of a workgroup (KS = 2: the form a plain
+    contraction takes when its 128x128 grid leaves CUs idle, e.g. M = 2048, N = 1024, K = 512 -> two K shares of 16 tiles, grid
+    256): every element equals the float64 product to fp32 rounding.  (Round 4's prologue shortcut for K tiles 2 and 3 loaded
+    the wrong tiles under KS = 2: K tiles 2 and 3 counted twice, 4..7 dropped.)"""
+    M, N, K = shape
+    A, Bt, bias = _operands(M, N, K, seed=M + N + K)
+    engine.set_option('tile', tile)
+    for split_k, groups in ((False, False), (True, False), (True, True)):
+        C = engine.debug_contract(A, Bt, bias, split_k=split_k, wave_groups=groups)
+        rms, mx = _errors(C, A, Bt, bias)
+        assert rms < 0.5 and mx < 4.0, (shape, tile, split_k, groups, rms, mx)
+
+
+@pytest.mark.parametrize('M,N,K', [(8192, 2048, 768), (8192, 2048, 1024), (8192, 2048, 1536), (1024, 512, 512), (333, 200, 96)])
+def test_plain_contraction_equals_float64_to_rounding(engine, M, N, K):
+    """The shapes of the decoder's launches (and a ragged one), every tile shape: same bits from all of them, float64 to rounding."""
+    A, Bt, bias = _operands(M, N, K, seed=K)
+    first = None
+    for tile in (0, 1, 2, -1):
+        engine.set_option('tile', tile)
+        C = engine.debug_contract(A, Bt, bias)
+        rms, mx = _errors(C, A, Bt, bias)
+        assert rms < 0.5 and mx < 4.0, (tile, rms, mx)
+        if first is None:
+            first = C
+        assert np.array_equal(first, C), 'tile shape %d changes the bits' % tile
+
+
+@pytest.mark.parametrize('K', [768, 1024, 1536])
+@pytest.mark.parametrize('scale', [1.0, 37.0])
+def test_split_bf16_is_as_accurate_as_the_fp32_chain(engine, K, scale):
+    """the split-bf16 arithmetic (three bf16 parts per value, six products per K tile, fp32
+    accumulation) against float64, beside the fp32-input kernels' k-ordered fmaf chain against float64, on the bench's operand
+    shapes (M = 8192 rows, N = 2048 gate columns, K = 768 / 1024 / 1536): RMS and maximum error of the split sums at most 1.1 x
+    the chain's.  Both modes of the option, weights as a pre-split image and staged per tile."""
+    M, N = 8192, 2048
+    A, Bt, bias = _operands(M, N, K, seed=7 * K, scale=scale)
+    engine.set_option('split_bf16', 0)
+    chain = _errors(engine.debug_contract(A, Bt, bias), A, Bt, bias)
+    for mode in (1, 2):
+        engine.set_option('split_bf16', mode)
+        for weight in (False, True):
+            C = engine.debug_contract(A, Bt, bias, weight=weight)
+            rms, mx = _errors(C, A, Bt, bias)
+            assert rms <= 1.1 * chain[0] and mx <= 1.1 * chain[1], (mode, weight, K, (rms, mx), chain)
+    engine.set_option('split_bf16', 0)

@@ -259,6 +259,80 @@ def test_batch_prefetch_runs_ahead_keeps_order_and_hands_errors_over():
     assert not any(t.name == 'casv-batch-prefetch' and t.is_alive() for t in threading.enumerate())
 
 
+def test_prefetch_leaves_a_blocked_producer_behind_but_waits_for_a_device_call():
+    """a consumer that leaves early must not hang on a worker that is blocked in next(iterable) (a user
+    generator reading a pipe, a nested stage waiting on q.get()), but it must wait as long as it takes while the worker is
+    inside a call on the engine (`in_call`)."""
+    import threading
+    import time
+    from cor_asv_ann_amd.training import prefetch
+    release = threading.Event()
+
+    def blocked():
+        yield 0
+        release.wait(30)                   # "reads a pipe"
+        yield 1
+
+    gen = prefetch(blocked(), depth=1, detach_after=0.3)
+    assert next(gen) == 0
+    t0 = time.perf_counter()
+    gen.close()
+    assert time.perf_counter() - t0 < 2.0
+    release.set()
+
+    # nested stages: the inner consumer loop (the outer stage's worker) ends when the caller's `cancel` is set
+    cancel, release2 = threading.Event(), threading.Event()
+
+    def inner_source():
+        yield 0
+        release2.wait(30)
+        yield 1
+
+    def outer_source():
+        for item in prefetch(inner_source(), depth=1, cancel=cancel, detach_after=0.3):
+            yield item
+
+    gen = prefetch(outer_source(), depth=1, detach_after=5.0)
+    assert next(gen) == 0
+    t0 = time.perf_counter()
+    cancel.set()
+    gen.close()
+    assert time.perf_counter() - t0 < 2.0
+    release2.set()
+
+    # a device call in flight is waited for, beyond detach_after
+    in_call, finished = threading.Event(), []
+
+    def device_stage():
+        yield 0
+        in_call.set()
+        time.sleep(0.8)                    # "the C-ABI call"
+        finished.append(True)
+        in_call.clear()
+        yield 1
+
+    gen = prefetch(device_stage(), depth=1, in_call=in_call, detach_after=0.1)
+    assert next(gen) == 0
+    time.sleep(0.1)
+    gen.close()
+    assert finished == [True]
+
+
+def test_switch_interval_guard_is_counted_and_not_held_across_yields():
+    """correct_batches must not leave the process-wide switch interval changed while its generator is
+    suspended or abandoned; overlapping pipelines must restore the original value."""
+    import sys
+    from cor_asv_ann_amd.seq2seq import _ShortSwitchInterval
+    before = sys.getswitchinterval()
+    a, b = _ShortSwitchInterval(), _ShortSwitchInterval()
+    a.__enter__(); b.__enter__()
+    assert sys.getswitchinterval() <= before and sys.getswitchinterval() <= 1e-3
+    a.__exit__(None, None, None)           # (the first to enter leaves first: the "wrong" order)
+    assert sys.getswitchinterval() <= 1e-3
+    b.__exit__(None, None, None)
+    assert sys.getswitchinterval() == before
+
+
 def test_no_kernel_reads_a_register_whose_hidden_load_is_in_flight():
     """The GEMM kernels hide their tile loads from the compiler's wait bookkeeping (asm loads + counted s_waitcnt); a register
     copy the compiler inserts between such a load and its wait would move stale data.  csrc/check_asm_loads.py compiles the
