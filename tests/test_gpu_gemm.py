@@ -31,9 +31,15 @@ def _operands(M, N, K, seed, scale=1.0):
     return A, Bt, bias
 
 
+# A sequential fp32 chain over K random-sign terms leaves an error of about sum|a||b| * 2^-24 * 0.64 (rms; each of the K additions
+# rounds the running sum, which grows like sqrt(k)) whatever K is -- the fp32-input MFMA's k-ordered fmaf chain measures 0.45 in
+# these units; a wrong or missing K tile would show as 1e4 and more.
+RMS_BOUND, MAX_BOUND = 1.5, 12.0
+
+
 def _errors(C, A, Bt, bias):
-    """(rms, max) error of C against the float64 product, in units of the float32 spacing of sum |a||b| (what a forward
-    error bound of any summation order is stated in)."""
+    """(rms, max) error of C against the float64 product, in units of 2^-24 * sum |a||b| (what a forward error bound of any
+    summation order is stated in)."""
     ref = A.astype(np.float64) @ Bt.astype(np.float64).T + bias.astype(np.float64)
     mag = np.abs(A).astype(np.float64) @ np.abs(Bt).astype(np.float64).T + np.abs(bias)
     err = (C.astype(np.float64) - ref) / (mag * 2.0 ** -24)
@@ -54,7 +60,7 @@ def test_split_k_forms_of_the_plain_contraction(engine, shape, tile):
     for split_k, groups in ((False, False), (True, False), (True, True)):
         C = engine.debug_contract(A, Bt, bias, split_k=split_k, wave_groups=groups)
         rms, mx = _errors(C, A, Bt, bias)
-        assert rms < 0.5 and mx < 4.0, (shape, tile, split_k, groups, rms, mx)
+        assert rms < RMS_BOUND and mx < MAX_BOUND, (shape, tile, split_k, groups, rms, mx)
 
 
 @pytest.mark.parametrize('M,N,K', [(8192, 2048, 768), (8192, 2048, 1024), (8192, 2048, 1536), (1024, 512, 512), (333, 200, 96)])
@@ -66,7 +72,7 @@ def test_plain_contraction_equals_float64_to_rounding(engine, M, N, K):
         engine.set_option('tile', tile)
         C = engine.debug_contract(A, Bt, bias)
         rms, mx = _errors(C, A, Bt, bias)
-        assert rms < 0.5 and mx < 4.0, (tile, rms, mx)
+        assert rms < RMS_BOUND and mx < MAX_BOUND, (tile, rms, mx)
         if first is None:
             first = C
         assert np.array_equal(first, C), 'tile shape %d changes the bits' % tile

