@@ -285,17 +285,21 @@ def cpu_baseline(cfg, weights, lines, batch_size, fast, length=LENGTH, budget_s=
     n0 = 8 if fast else 1
     t0 = time.perf_counter()
     correct_lines(om, lines[:n0], **kw)                      # warm-up (BLAS threads, page-in); also sizes the sample
-    per_line = (time.perf_counter() - t0) / n0
+    first = time.perf_counter() - t0
+    per_line = first / n0
     n = int(max(n0, min(len(lines), (budget_s / repeats) / max(per_line, 1e-6))))
     if n < min_lines:                   # a sample of at least `min_lines` lines (a one- or two-line sample is noisy), fewer runs
         n = min(min_lines, len(lines))
-        repeats = int(max(2, min(repeats, budget_s / max(n * per_line, 1e-6))))
-    best = None
+    # as many runs as the budget holds (a wide search takes its whole budget for ONE line: then the warm-up run is the sample too)
+    repeats = int(min(repeats, max(budget_s / max(n * per_line, 1e-6), 0 if n == n0 else 1)))
+    best = first if n == n0 else None
+    runs = repeats + (1 if n == n0 else 0)
     for _ in range(repeats):
         t0 = time.perf_counter()
         correct_lines(om, lines[:n], **kw)
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
+    repeats = runs
     return {'value': n * length / best, 'unit': 'chars/s', 'cores': host_threads(), 'kind': 'port',
             'sample': 'best of %d runs over %d lines of the same workload (numpy fp32 oracle, reference dataflow: '
                       'per-character decoder call, dense-T attention, u recomputed per step), %.1f s per run' % (repeats, n, best)}
