@@ -94,6 +94,8 @@ def load():
                            '(there is no CPU fallback)' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
+        if os.environ.get('CASV_LIB_PATH') and name.startswith('casv_debug_') and not hasattr(lib, name):
+            continue                     # (A/B against an older build of the library: it may lack a test-support entry)
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes

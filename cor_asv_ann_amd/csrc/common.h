@@ -229,6 +229,23 @@ struct RecordSrc {
 void launch_pack_records(const RecordSrc& r, int* rec, hipStream_t stream);
 void launch_scatter_rows(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,
                          int dst_row_mul, hipStream_t stream);
+// Small fills and row copies batched into one launch (decode_kernels.hip): op = fill `n` 4-byte words at dst with `fill`
+// (src == nullptr), or copy rows: word w < width of source row r (stride src_ld) -> destination row r * row_mul (stride dst_ld),
+// n = rows * width.
+struct SmallOp { void* dst; const void* src; long long n; long long src_ld, dst_ld; int width, row_mul; unsigned fill; };
+constexpr int SMALL_OPS_MAX = 28;
+struct SmallOps {
+    SmallOp op[SMALL_OPS_MAX]; int count;
+    bool fill(void* dst, size_t bytes, unsigned word = 0u) {
+        if (count >= SMALL_OPS_MAX || (bytes & 3)) return false;
+        op[count++] = SmallOp{dst, nullptr, (long long)(bytes / 4), 0, 0, 1, 1, word}; return true;
+    }
+    bool rows(const float* src, long long src_ld, float* dst, long long dst_ld, int nrows, int width, int row_mul) {
+        if (count >= SMALL_OPS_MAX) return false;
+        op[count++] = SmallOp{dst, src, (long long)nrows * width, src_ld, dst_ld, width, row_mul, 0u}; return true;
+    }
+};
+void launch_small_ops(const SmallOps& ops, hipStream_t stream);
 
 // ---- beam search (beam_kernels.hip) ----
 struct BeamParams {

@@ -212,6 +212,31 @@ void launch_advance_step(int* step_ptr, hipStream_t stream) {
     hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, stream, step_ptr);
 }
 
+// A list of small fills and row copies as ONE launch (the set-up in front of a decode: zeroed slots, flags and counters, the
+// encoder's final states spread over the hypothesis rows -- a dozen launches of ~5 us each otherwise; blockIdx.y = the operation).
+__global__ void small_ops_kernel(const SmallOps ops) {
+    const SmallOp& o = ops.op[blockIdx.y];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if (!o.src) {
+        unsigned* d = reinterpret_cast<unsigned*>(o.dst);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < o.n; i += stride) d[i] = o.fill;
+    } else {
+        const unsigned* sp = reinterpret_cast<const unsigned*>(o.src);
+        unsigned* d = reinterpret_cast<unsigned*>(o.dst);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < o.n; i += stride) {
+            const long long r = i / o.width; const int w = (int)(i - r * o.width);
+            d[r * o.row_mul * o.dst_ld + w] = sp[r * o.src_ld + w];
+        }
+    }
+}
+void launch_small_ops(const SmallOps& ops, hipStream_t stream) {
+    if (ops.count < 1) return;
+    long long most = 0;
+    for (int i = 0; i < ops.count; ++i) most = ops.op[i].n > most ? ops.op[i].n : most;
+    const int blocks = (int)((most + 4 * 256 - 1) / (4 * 256));           // ~four words per thread for the largest operation
+    hipLaunchKernelGGL(small_ops_kernel, dim3(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks, ops.count), dim3(256), 0, stream, ops);
+}
+
 __global__ void scatter_rows_kernel(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,
                                     int dst_row_mul) {
     const int i = blockIdx.x;

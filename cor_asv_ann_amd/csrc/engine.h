@@ -100,6 +100,10 @@ struct casv_model {
     DevBuf E, WaT, bUW, va, bv, UT;
     DevBuf WaP, EP;                                       // query / output projection in the persistent decoder's K order
     DevBuf p_ctx, p_wq, p_logits, p_counters;             // persistent decoder: slot-indexed hand-off buffers, counters
+    DevBuf p_enc_counters, d_flags;                       // persistent encoder's counters; [0] its give-up word set aside, [1] the decoder's, [2] the NaN flag
+    bool enc_check_pending = false;                       // the persistent encoder's give-up word has not been looked at yet (engine.hip, settle_encoder)
+    char* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned staging of casv_encode's inputs (reused behind ev_inputs)
+    char* pin_out = nullptr; size_t pin_out_cap = 0;      // pinned staging of the greedy decode's results
     int persist_mode = -1;                                // -1 by size, 0 never, 1 always (greedy decode of small batches)
     int persist_skip = 0, persist_penalty = 0; bool persist_told = false;   // back-off after a persistent launch gave up waiting
     int ncu = 0;

@@ -76,7 +76,9 @@ extern "C" void casv_model_destroy(casv_model* m) {
     for (auto& l : m->enc) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
     for (LstmW* l : {&m->enc_fw, &m->enc_bw}) { l->pw.release(); l->pbias.release(); }
     for (auto& l : m->dec) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
-    for (DevBuf* b : {&m->WaP, &m->EP, &m->p_ctx, &m->p_wq, &m->p_logits, &m->p_counters}) b->release();
+    for (DevBuf* b : {&m->WaP, &m->EP, &m->p_ctx, &m->p_wq, &m->p_logits, &m->p_counters, &m->p_enc_counters, &m->d_flags}) b->release();
+    if (m->pin_in) (void)hipHostFree(m->pin_in);
+    if (m->pin_out) (void)hipHostFree(m->pin_out);
     for (auto& b : m->st_h) b.release();
     for (auto& b : m->st_c) b.release();
     (void)casv_train_release(m);
@@ -259,36 +261,16 @@ static bool persist_enc_applies(const casv_model* m, int B) {
     return B <= 512 && (2 * ntile + grid - 1) / grid <= 2 && ((D - 1) * ntile + grid - 1) / grid <= 2;
 }
 
-extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const int32_t* idx, const float* val,
-                           const int32_t* src_rej) {
-    if (!m || !idx || !val) return fail(CASV_ERR_ARG, "null argument");
-    if (!m->committed) return fail(CASV_ERR_STATE, "weights not committed");
-    if (B < 1 || T < 1 || A < 1) return fail(CASV_ERR_ARG, "bad shape B=%d T=%d A=%d", B, T, A);
-    if (T > CASV_MAX_T) return fail(CASV_ERR_ARG, "line length %d exceeds the supported maximum of %d", T, CASV_MAX_T);
-    HIPCHK(hipSetDevice(m->device));
+// The encoder (seq2seq.py:237-314) on the inputs that lie in d_idx / d_val: embedding, BiLSTM layer, stacked layers, final states,
+// u = attention_dense(enc_out).  Small batches: the whole recurrence as ONE launch of the persistent encoder (persist.hip; same
+// values bit for bit) -- whose give-up word is NOT waited for here: it is copied aside (d_flags[0]) and looked at where the host
+// waits for the device anyway (settle_encoder: the end of the greedy decode, or the first other consumer of the outputs); a launch
+// that gave up is redone with the per-step kernels then.  (Waiting here cost every batch of configs[1] a host round trip with the
+// GPU idle between its encoder and its decoder's set-up.)
+static int run_encoder(casv_model* m, bool try_persistent) {
+    const int B = m->B, T = m->T, A = m->A;
     const int W = m->W, C = m->C, D = m->D;
     const size_t BT = (size_t)B * T;
-    if (int rc = m->d_idx.ensure(BT * A * 4)) return rc;
-    if (int rc = m->d_val.ensure(BT * A * 4)) return rc;
-    if (int rc = m->d_srcrej.ensure(BT * 4)) return rc;
-    if (int rc = m->x0.ensure(BT * W * 4)) return rc;
-    if (int rc = m->H1.ensure(BT * 2 * W * 4)) return rc;
-    if (D == 2 || D == 3) { if (int rc = m->Ha.ensure(BT * W * 4)) return rc; }
-    if (D == 3) { if (int rc = m->Hb.ensure(BT * W * 4)) return rc; }
-    if (int rc = m->cfin.ensure((size_t)(D + 1) * B * W * 4)) return rc;     // slot D: forward c of layer 1 (unused later)
-    if (int rc = m->hfin.ensure((size_t)D * B * W * 4)) return rc;
-    if (int rc = m->u.ensure(BT * W * 4)) return rc;
-    HIPCHK(hipMemcpyAsync(m->d_idx.p, idx, BT * A * 4, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipMemcpyAsync(m->d_val.p, val, BT * A * 4, hipMemcpyHostToDevice, m->stream));
-    if (src_rej) HIPCHK(hipMemcpyAsync(m->d_srcrej.p, src_rej, BT * 4, hipMemcpyHostToDevice, m->stream));
-    else HIPCHK(hipMemsetAsync(m->d_srcrej.p, 0xff, BT * 4, m->stream));
-    // The caller owns idx / val / src_rej and may release them as soon as this function returns (the encoder itself
-    // runs asynchronously): wait until the three copies have left the host buffers.
-    HIPCHK(hipEventRecord(m->ev_inputs, m->stream));
-    HIPCHK(hipEventSynchronize(m->ev_inputs));
-    m->B = B; m->T = T; m->A = A;
-    m->last_decode = 0; m->has_a0 = false;
-
     hipEvent_t ev{};
     m->prof_begin(PC_EMBED, 2.0 * BT * A * W, 4.0 * BT * W * (A + 1), ev);
     launch_embed_sparse(m->E.as<float>(), m->d_idx.as<int>(), m->d_val.as<float>(), m->x0.as<float>(), (int)BT, A,
@@ -323,13 +305,15 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         if (int rc = m->Hc.ensure((size_t)(D - 1) * BT * W * 4)) return rc;
         for (int n = 2; n <= D; ++n) lout[n] = m->Hc.as<float>() + (size_t)(n - 2) * BT * W;
     }
+    if (int rc = m->d_flags.ensure(64)) return rc;
     // Small batches: the whole encoder in one launch of the persistent encoder (persist.hip; same values bit for bit)
-    bool persistent = persist_enc_applies(m, B) && !persist_backed_off(m);
+    const bool persistent = try_persistent && persist_enc_applies(m, B) && !persist_backed_off(m);
+    unsigned* enc_abort_word = nullptr;
     if (persistent) {
         std::lock_guard<std::mutex> lock(g_persist_mutex);
         const size_t cbytes = persist_enc_counter_bytes(B, D);
-        if (int rc = m->p_counters.ensure(cbytes)) return rc;
-        HIPCHK(hipMemsetAsync(m->p_counters.p, 0, cbytes, m->stream));
+        if (int rc = m->p_enc_counters.ensure(cbytes)) return rc;
+        HIPCHK(hipMemsetAsync(m->p_enc_counters.p, 0, cbytes, m->stream));
         PersistEncArgs pa{};
         pa.B = B; pa.T = T; pa.D = D; pa.W = W; pa.lda = (D >= 2 ? 3 * W : 2 * W) + 4;
         pa.l1[0] = PersistLayer{m->enc_fw.pw.as<float>(), m->enc_fw.pbias.as<float>(), 2 * W};
@@ -338,7 +322,7 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
             pa.ln[n - 2] = PersistLayer{m->enc[n].pw.as<float>(), m->enc[n].pbias.as<float>(), m->enc[n].kin + W};
             pa.Hn[n - 2] = lout[n];
         }
-        pa.x0 = x0; pa.H1 = H1; pa.cfin = cfin; pa.counters = m->p_counters.as<unsigned>();
+        pa.x0 = x0; pa.H1 = H1; pa.cfin = cfin; pa.counters = m->p_enc_counters.as<unsigned>();
         const int nrb = (B + 15) / 16, ntile = nrb * (W / 16);
         const int per_cu = persist_encode_blocks_per_cu((size_t)16 * pa.lda * 4);                      // all workgroups resident at once
         const int grid = std::min(std::max(2, D - 1) * ntile, std::max(per_cu, 1) * m->ncu);
@@ -353,9 +337,7 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         if (launch_persist_encode(pa, grid, m->stream)) return fail(CASV_ERR_ARG, "persistent encoder: rows do not fit the LDS");
         m->prof_end(PC_PERSIST, pev);
         HIPCHK(hipGetLastError());
-        unsigned aborted = 0;
-        HIPCHK(hipMemcpyAsync(&aborted, m->p_counters.as<unsigned>() + (size_t)nrb * (D + 1) * 32, 4, hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(hipStreamSynchronize(m->stream));
+        enc_abort_word = m->p_enc_counters.as<unsigned>() + (size_t)nrb * (D + 1) * 32;
 #ifdef CASV_PERSIST_PROF
         {
             unsigned long long h[32];
@@ -365,8 +347,6 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
                     h[8] * 0.01 / T, h[9] * 0.01 / T, h[10] * 0.01 / T, h[11] * 0.01 / T, h[12] * 0.01 / T, h[16] * 0.01, h[17] * 0.01);
         }
 #endif
-        if (aborted) { persist_note_abort(m, "encoder"); persistent = false; }
-        else m->persist_penalty = 0;
     }
     if (!persistent) {
     for (int t = 0; t < T; ++t) {
@@ -375,8 +355,6 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         run_gemm_batch(m, EPI_LSTM, b);
     }
     }
-    // backward final h = output at time 0 (seq2seq.py:280)
-    launch_scatter_rows(H1 + W, T * 2 * W, m->hfin.as<float>(), W, B, W, 1, m->stream);
     // layers 2..D (seq2seq.py:283): cell (n, t) needs (n-1, t) and (n, t-1); the cells of one
     // anti-diagonal k = t + (n-2) are independent -> one launch per diagonal (<= GEMM_MAX_JOBS cells,
     // deeper stacks are cut into groups of GEMM_MAX_JOBS layers)
@@ -406,9 +384,16 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
             run_gemm_batch(m, EPI_LSTM, b);
         }
     }
-    for (int n = 2; n <= D; ++n)
-        launch_scatter_rows(lout[n] + (size_t)(T - 1) * W, T * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1,
-                            m->stream);
+    {   // final hidden states, and the persistent launch's give-up word set aside, in one launch:
+        // backward final h of layer 1 = its output at time 0 (seq2seq.py:280); layers n >= 2: the output at the last position
+        SmallOps ops{};
+        ops.rows(H1 + W, (long long)T * 2 * W, m->hfin.as<float>(), W, B, W, 1);
+        for (int n = 2; n <= D; ++n)
+            ops.rows(lout[n] + (size_t)(T - 1) * W, (long long)T * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1);
+        if (enc_abort_word) ops.rows(reinterpret_cast<const float*>(enc_abort_word), 1, m->d_flags.as<float>(), 1, 1, 1, 1);
+        launch_small_ops(ops, m->stream);
+    }
+    m->enc_check_pending = persistent;
     float* outb = lout[D];
     m->enc_out = D == 1 ? H1 : outb;
     // u = attention_dense(enc_out) once per line (seq2seq.py:313; the reference redoes it every step)
@@ -420,6 +405,68 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
         run_gemm(m, EPI_PLAIN, g);
     }
     HIPCHK(hipGetLastError());
+    return CASV_OK;
+}
+
+// The persistent encoder's give-up word, where the host has to wait for the device anyway.  `have_flag`: the caller has already
+// brought d_flags[0] to the host (value in *flag) behind a synchronisation of its own; otherwise this function does both.
+// A launch that gave up (its workgroups were not all resident: another process's persistent kernel on this GPU) is redone with the
+// per-step kernels -- same values.  Returns 1 if the encoder was redone (whatever was decoded from its outputs must be redone too).
+static int settle_encoder(casv_model* m, const unsigned* flag = nullptr) {
+    if (!m->enc_check_pending) return 0;
+    unsigned aborted = 0;
+    if (flag) aborted = *flag;
+    else {
+        HIPCHK(hipMemcpyAsync(&aborted, m->d_flags.p, 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    m->enc_check_pending = false;
+    if (!aborted) { m->persist_penalty = 0; return 0; }
+    persist_note_abort(m, "encoder");
+    if (int rc = run_encoder(m, false)) return rc;
+    return 1;
+}
+
+extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const int32_t* idx, const float* val,
+                           const int32_t* src_rej) {
+    if (!m || !idx || !val) return fail(CASV_ERR_ARG, "null argument");
+    if (!m->committed) return fail(CASV_ERR_STATE, "weights not committed");
+    if (B < 1 || T < 1 || A < 1) return fail(CASV_ERR_ARG, "bad shape B=%d T=%d A=%d", B, T, A);
+    if (T > CASV_MAX_T) return fail(CASV_ERR_ARG, "line length %d exceeds the supported maximum of %d", T, CASV_MAX_T);
+    HIPCHK(hipSetDevice(m->device));
+    const int W = m->W, D = m->D;
+    const size_t BT = (size_t)B * T;
+    if (int rc = m->d_idx.ensure(BT * A * 4)) return rc;
+    if (int rc = m->d_val.ensure(BT * A * 4)) return rc;
+    if (int rc = m->d_srcrej.ensure(BT * 4)) return rc;
+    if (int rc = m->x0.ensure(BT * W * 4)) return rc;
+    if (int rc = m->H1.ensure(BT * 2 * W * 4)) return rc;
+    if (D == 2 || D == 3) { if (int rc = m->Ha.ensure(BT * W * 4)) return rc; }
+    if (D == 3) { if (int rc = m->Hb.ensure(BT * W * 4)) return rc; }
+    if (int rc = m->cfin.ensure((size_t)(D + 1) * B * W * 4)) return rc;     // slot D: forward c of layer 1 (unused later)
+    if (int rc = m->hfin.ensure((size_t)D * B * W * 4)) return rc;
+    if (int rc = m->u.ensure(BT * W * 4)) return rc;
+    // The caller owns idx / val / src_rej and may release them as soon as this function returns (the encoder itself runs
+    // asynchronously).  They are copied into a pinned staging buffer of the handle first: the device copies then need no wait --
+    // the function returns while they are still queued (waiting for pageable copies cost every batch of configs[1] ~40 us of idle
+    // GPU) -- and the staging buffer is reused only once its previous copies have gone (ev_inputs).
+    const size_t nin = BT * A * 4, nrej = BT * 4, need = 2 * nin + nrej;
+    if (m->pin_in_cap < need) {
+        if (m->pin_in) { HIPCHK(hipStreamSynchronize(m->stream)); (void)hipHostFree(m->pin_in); m->pin_in = nullptr; m->pin_in_cap = 0; }
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->pin_in), need, hipHostMallocDefault));
+        m->pin_in_cap = need;
+    } else HIPCHK(hipEventSynchronize(m->ev_inputs));
+    memcpy(m->pin_in, idx, nin); memcpy(m->pin_in + nin, val, nin);
+    if (src_rej) memcpy(m->pin_in + 2 * nin, src_rej, nrej);
+    HIPCHK(hipMemcpyAsync(m->d_idx.p, m->pin_in, nin, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_val.p, m->pin_in + nin, nin, hipMemcpyHostToDevice, m->stream));
+    if (src_rej) HIPCHK(hipMemcpyAsync(m->d_srcrej.p, m->pin_in + 2 * nin, nrej, hipMemcpyHostToDevice, m->stream));
+    else HIPCHK(hipMemsetAsync(m->d_srcrej.p, 0xff, nrej, m->stream));
+    HIPCHK(hipEventRecord(m->ev_inputs, m->stream));
+    m->B = B; m->T = T; m->A = A;
+    m->last_decode = 0; m->has_a0 = false;
+    m->enc_check_pending = false;
+    if (int rc = run_encoder(m, true)) return rc;
     m->encoded = true;
     return CASV_OK;
 }
@@ -454,7 +501,7 @@ extern "C" int casv_set_encoder_outputs(casv_model* m, int32_t B, int32_t T, con
     HIPCHK(hipEventRecord(m->ev_inputs, m->stream));
     HIPCHK(hipEventSynchronize(m->ev_inputs));
     m->B = B; m->T = T; m->A = 1;
-    m->last_decode = 0;
+    m->last_decode = 0; m->enc_check_pending = false;
     {   // u = attention_dense(enc_out) (seq2seq.py:313,459-460)
         GemmArgs g{};
         g.nseg = 1; g.a[0] = mkseg(m->enc_out, C, C, 0);
@@ -471,6 +518,7 @@ extern "C" int casv_get_encoder_outputs(casv_model* m, float* enc_out, float* st
     if (!m) return fail(CASV_ERR_ARG, "null argument");
     if (!m->encoded) return fail(CASV_ERR_STATE, "nothing encoded");
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = settle_encoder(m); rc < 0) return rc;
     HIPCHK(hipStreamSynchronize(m->stream));
     const size_t BW = (size_t)m->B * m->W;
     if (enc_out) HIPCHK(hipMemcpy(enc_out, m->enc_out, (size_t)m->B * m->T * m->C * 4, hipMemcpyDeviceToHost));
@@ -516,19 +564,21 @@ static int ensure_session(casv_model* m, int R, int S) {
     return 0;
 }
 
-// Initial decoder state = encoder final states (seq2seq.py:339,352), zero alignment, zero input.
-static int init_root(casv_model* m, int rows_per_line) {
+// Initial decoder state = encoder final states (seq2seq.py:339,352), zero alignment, zero input -- and whatever else the caller
+// wants cleared ahead of its first step (`ops`: result arrays, hand-off counters): ONE launch for all of it (a memset or row
+// scatter of its own costs ~5 us of an otherwise idle GPU each: 13 of them in front of every batch of configs[1]).
+static int init_root(casv_model* m, int rows_per_line, SmallOps ops = SmallOps{}) {
     const int W = m->W, Vp = m->Vp, T = m->T, D = m->D, R = m->R, B = m->B;
-    HIPCHK(hipMemsetAsync(m->st_a.p, 0, (size_t)R * T * 4, m->stream));
-    if (m->has_a0) launch_scatter_rows(m->a0.as<float>(), T, m->st_a.as<float>(), T, B, T, rows_per_line, m->stream);
-    HIPCHK(hipMemsetAsync(m->st_p.p, 0, (size_t)R * Vp * 4, m->stream));
-    HIPCHK(hipMemsetAsync(m->logits.p, 0, (size_t)R * Vp * 4, m->stream));
+    bool ok = ops.fill(m->st_a.p, (size_t)R * T * 4);
+    if (m->has_a0) ok = ok && ops.rows(m->a0.as<float>(), T, m->st_a.as<float>(), T, B, T, rows_per_line);
+    ok = ok && ops.fill(m->st_p.p, (size_t)R * Vp * 4) && ops.fill(m->logits.p, (size_t)R * Vp * 4);
     for (int n = 1; n <= D; ++n) {
-        launch_scatter_rows(m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, m->st_h[n].as<float>(), W, B, W, rows_per_line, m->stream);
-        launch_scatter_rows(m->cfin.as<float>() + (size_t)(n - 1) * B * W, W, m->st_c[n].as<float>(), W, B, W, rows_per_line, m->stream);
+        ok = ok && ops.rows(m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, m->st_h[n].as<float>(), W, B, W, rows_per_line);
+        ok = ok && ops.rows(m->cfin.as<float>() + (size_t)(n - 1) * B * W, W, m->st_c[n].as<float>(), W, B, W, rows_per_line);
     }
-    HIPCHK(hipMemsetAsync(m->d_step.p, 0, 16, m->stream));
-    HIPCHK(hipMemsetAsync(m->d_nan.p, 0, 16, m->stream));
+    ok = ok && ops.fill(m->d_step.p, 16) && ops.fill(m->d_nan.p, 16);
+    if (!ok) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
+    launch_small_ops(ops, m->stream);
     return 0;
 }
 
@@ -645,6 +695,7 @@ extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, 
     if (R < 1) return fail(CASV_ERR_ARG, "R must be positive");
     for (int r = 0; r < R; ++r) if (line[r] < 0 || line[r] >= m->B) return fail(CASV_ERR_ARG, "line[%d]=%d out of range", r, line[r]);
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = settle_encoder(m); rc < 0) return rc;
     const int W = m->W, V = m->V, Vp = m->Vp, T = m->T, D = m->D;
     m->last_decode = 0;         // the step overwrites slots 0 and 1 of the stores casv_get_alignments_sparse would read
     if (int rc = ensure_session(m, R, 1)) return rc;
@@ -734,17 +785,14 @@ static bool persist_applies(const casv_model* m, int B) {
     const int g_lstm = std::max(1, m->ncu * per_cu * 4 / 8), ntile = ((B + 15) / 16) * (m->W / 16);
     return B <= 512 && (ntile + g_lstm - 1) / g_lstm <= 2;
 }
-static int decode_greedy_persistent(casv_model* m, int mode, int S, bool* aborted_out) {
+static int decode_greedy_persistent(casv_model* m, int mode, int S) {
     std::lock_guard<std::mutex> lock(g_persist_mutex);
-    *aborted_out = false;
     const int W = m->W, Vp = m->Vp, C = m->C, T = m->T, D = m->D, R = m->R;
     const size_t slots = (size_t)(S + 1) * R;
     if (int rc = m->p_ctx.ensure(slots * C * 4)) return rc;
     if (int rc = m->p_wq.ensure(slots * W * 4)) return rc;
     if (int rc = m->p_logits.ensure(slots * Vp * 4)) return rc;
-    const size_t cbytes = persist_counter_bytes(R, D);
-    if (int rc = m->p_counters.ensure(cbytes)) return rc;
-    HIPCHK(hipMemsetAsync(m->p_counters.p, 0, cbytes, m->stream));
+    if (m->p_counters.cap < persist_counter_bytes(R, D)) return fail(CASV_ERR_STATE, "hand-off counters not set up");      // (cleared by the caller's set-up launch)
     PersistArgs pa{};
     pa.R = R; pa.D = D; pa.W = W; pa.V = m->V; pa.Vp = Vp; pa.C = C; pa.T = T; pa.S = S; pa.mode = mode;
     for (int n = 1; n <= D; ++n) {
@@ -823,10 +871,12 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S, bool* aborte
         }
     }
 #endif
-    unsigned aborted = 0;
-    HIPCHK(hipMemcpyAsync(&aborted, m->p_counters.as<unsigned>() + (size_t)nrb * (D + 3) * 32, 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
-    *aborted_out = aborted != 0;
+    // the launch's give-up word, set aside beside the encoder's (the caller brings both to the host with the results)
+    {
+        SmallOps ops{};
+        ops.rows(reinterpret_cast<const float*>(m->p_counters.as<unsigned>() + (size_t)nrb * (D + 3) * 32), 1, m->d_flags.as<float>() + 1, 1, 1, 1, 1);
+        launch_small_ops(ops, m->stream);
+    }
     return 0;
 }
 
@@ -842,38 +892,55 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (int rc = ensure_session(m, B, S)) return rc;
     if (int rc = m->o_idx.ensure((size_t)B * S * 4)) return rc;
     if (int rc = m->o_prob.ensure((size_t)B * S * 4)) return rc;
-    if (int rc = init_root(m, 1)) return rc;
-    HIPCHK(hipMemsetAsync(m->o_idx.p, 0, (size_t)B * S * 4, m->stream));
-    HIPCHK(hipMemsetAsync(m->o_prob.p, 0, (size_t)B * S * 4, m->stream));
+    if (int rc = m->d_flags.ensure(64)) return rc;
+    // results and flags come back through a pinned staging buffer: three queued copies, ONE wait for the device
+    const size_t nres = (size_t)B * S * 4, need = 2 * nres + 64;
+    if (m->pin_out_cap < need) {
+        if (m->pin_out) { (void)hipHostFree(m->pin_out); m->pin_out = nullptr; m->pin_out_cap = 0; }
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->pin_out), need, hipHostMallocDefault));
+        m->pin_out_cap = need;
+    }
     bool persistent = persist_applies(m, B) && !persist_backed_off(m);
-    if (persistent) {
-        bool aborted = false;
-        if (int rc = decode_greedy_persistent(m, mode, S, &aborted)) return rc;
-        if (!aborted) m->persist_penalty = 0;
-        if (aborted) {
-            // a hand-off wait ran out: the workgroups were not all resident (another process running a persistent kernel on
-            // this GPU).  Nothing is lost -- the per-step kernels compute the same values; start over with them.
-            persist_note_abort(m, "decoder");
-            if (int rc = init_root(m, 1)) return rc;
-            HIPCHK(hipMemsetAsync(m->o_idx.p, 0, (size_t)B * S * 4, m->stream));
-            HIPCHK(hipMemsetAsync(m->o_prob.p, 0, (size_t)B * S * 4, m->stream));
-            persistent = false;
+    auto begin = [&](bool with_counters) -> int {        // the set-up of a run, as one launch
+        SmallOps ops{};
+        ops.fill(m->o_idx.p, nres); ops.fill(m->o_prob.p, nres);
+        ops.fill(m->d_flags.as<unsigned>() + 1, 4);
+        if (with_counters) {
+            const size_t cbytes = persist_counter_bytes(B, m->D);
+            if (int rc = m->p_counters.ensure(cbytes)) return rc;
+            ops.fill(m->p_counters.p, cbytes);
         }
+        return init_root(m, 1, ops);
+    };
+    for (int attempt = 0; ; ++attempt) {
+        if (int rc = begin(persistent)) return rc;
+        if (persistent) {
+            if (int rc = decode_greedy_persistent(m, mode, S)) return rc;
+        } else {
+            char key[96];
+            snprintf(key, sizeof key, "greedy/%d/%d/%d/%d/%d", mode, B, T, S, m->eos);
+            StepRunner runner(m, key);
+            if (int rc = runner.run(0, S, [&](const int* step_ptr, int step_imm) {
+                    launch_step(m, false, mode, nullptr, 1, m->o_idx.as<int>(), m->o_prob.as<float>(), step_ptr, step_imm);
+                })) return rc;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(m->pin_out, m->o_idx.p, nres, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(m->pin_out + nres, m->o_prob.p, nres, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(m->pin_out + 2 * nres, m->d_flags.p, 8, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        const unsigned* flags = reinterpret_cast<const unsigned*>(m->pin_out + 2 * nres);
+        // a persistent launch whose hand-off wait ran out (its workgroups were not all resident: another process running a
+        // persistent kernel on this GPU) loses nothing -- the per-step kernels compute the same values; start over with them
+        const int redone = settle_encoder(m, &flags[0]);
+        if (redone < 0) return redone;
+        const bool dec_aborted = persistent && flags[1] != 0;
+        if (dec_aborted) { persist_note_abort(m, "decoder"); persistent = false; }
+        else if (persistent) m->persist_penalty = 0;
+        if (!redone && !dec_aborted) break;
+        if (attempt >= 2) return fail(CASV_ERR_STATE, "persistent launches keep giving up");
     }
-    if (!persistent) {
-        char key[96];
-        snprintf(key, sizeof key, "greedy/%d/%d/%d/%d/%d", mode, B, T, S, m->eos);
-        StepRunner runner(m, key);
-        if (int rc = runner.run(0, S, [&](const int* step_ptr, int step_imm) {
-                launch_step(m, false, mode, nullptr, 1, m->o_idx.as<int>(), m->o_prob.as<float>(), step_ptr, step_imm);
-            })) return rc;
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_idx, m->o_idx.p, (size_t)B * S * 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(out_prob, m->o_prob.p, (size_t)B * S * 4, hipMemcpyDeviceToHost, m->stream));
-    int nanflag = 0;
-    HIPCHK(hipMemcpyAsync(&nanflag, m->d_nan.p, 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
+    memcpy(out_idx, m->pin_out, nres); memcpy(out_prob, m->pin_out + nres, nres);
     // mode 1 stops a line at its end-of-line character (seq2seq.py:1344); np.nanargmax raises only if an all-NaN row
     // turns up BEFORE that (the device marks such a step with a NaN probability) -- rows keep stepping in lockstep
     // after their line has ended, and what they produce there is nobody's business
@@ -896,7 +963,6 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     }
     if (m->prof.on) m->prof.collect();
     m->last_decode = 1; m->last_S = S; m->last_rows = B; m->last_mode = mode; m->last_signature = decode_buffers_signature(m);
-    (void)nanflag;
     if (nan_before_end && mode == 1) return fail(CASV_ERR_NAN, "All-NaN slice encountered");
     return CASV_OK;
 }
@@ -916,6 +982,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     if (1LL + (long long)S * N * CM >= (1LL << 31) || (long long)(S + 1) * m->B * N >= (1LL << 31))
         return fail(CASV_ERR_ARG, "search too large: S * batch_size * (beam_width_in + 1) nodes per line overflow int32 (decode fewer lines or steps per call)");
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = settle_encoder(m); rc < 0) return rc;
     const int B = m->B, T = m->T, R = B * N, MR = bp->max_results;
     m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, R, S)) return rc;
@@ -1004,9 +1071,11 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     o.idx = m->bo_idx.as<int>(); o.prob = m->bo_prob.as<float>(); o.len = m->bo_len.as<int>(); o.score = m->bo_score.as<double>();
     o.rejpos = m->bo_rej.as<int>(); o.align = out_align ? m->bo_align.as<float>() : nullptr; o.n_found = m->bo_found.as<int>();
     o.n_steps = m->bo_nsteps.as<int>(); o.a_base = m->st_a.as<float>();
-    HIPCHK(hipMemsetAsync(m->bo_idx.p, 0, OR * S * 4, m->stream));
-    HIPCHK(hipMemsetAsync(m->bo_prob.p, 0, OR * S * 4, m->stream));
-    HIPCHK(hipMemsetAsync(m->bo_rej.p, 0xff, OR * S * 4, m->stream));
+    {
+        SmallOps ops{};
+        ops.fill(m->bo_idx.p, OR * S * 4); ops.fill(m->bo_prob.p, OR * S * 4); ops.fill(m->bo_rej.p, OR * S * 4, 0xffffffffu);
+        launch_small_ops(ops, m->stream);
+    }
 #ifdef CASV_BEAM_PROF
     { HIPCHK(hipStreamSynchronize(m->stream)); casv::beam_prof_dump(m->S); }
 #endif

@@ -685,6 +685,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
             }
             float* cb = cout + (long long)(m0 + wave * 32 + 4 * lh) * g.c_out.ld + u;
             float* hb = hout + (long long)(m0 + wave * 32 + 4 * lh) * g.out.ld + u;
+            // (16-byte stores from an in-quad transpose of the accumulators -- 8 store instructions per wave instead of 32 --
+            // measured again in round 5, behind the round-4 epilogue: c3 271.0-271.3 ms without, 271.6-272.7 with.  Not store-issue bound.)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dm = (r & 3) + 8 * (r >> 2);
@@ -850,8 +852,41 @@ static bool splittable_launch(int epi, const GemmBatch& b) {        // (a launch
     return false;
 }
 
+// Train step's big plain contractions (GemmArgs.ksplit = -1: the caller leaves the launch form to the launcher; M = 51 712 rows):
+// a 128x128 tile grid that ends in a partial round of workgroups -- 1 616 tiles on 512 slots = 3.16 rounds -- spends the time of
+// most of a round on its last few tiles (a workgroup alone on its CU still needs ~2/3 of the time two of them share).  The row
+// blocks of that partial round go as a second launch of 32-row (64-row) tiles instead: four (two) times the workgroups for the same
+// rows, every element contracted by the same k-ordered chain (gemm_skinny.hip: same bits, no split-K, nothing atomic).
+// CASV_TAIL_CUT=0 switches it off (A/B measurements).
+static bool cut_partial_round(int epi, const GemmBatch& b, const GemmPlan& plan, hipStream_t stream) {
+    static const bool enabled = [] { const char* e = getenv("CASV_TAIL_CUT"); return !(e && e[0] == '0'); }();
+    if (!enabled || epi != EPI_PLAIN || b.count != 1 || plan.ksplit != 1 || plan.skinny || g_tile_mode >= 0 || g_split_bf16) return false;
+    const GemmArgs& g = b.g[0];
+    if (g.ksplit != -1 || g.step_ptr || g.nact || g.Bimg) return false;
+    for (int i = 0; i < g.nseg; ++i) if (g.a[i].rows || g.a[i].skip_first || g.a[i].first_base) return false;    // rows at base + m * ld only
+    static const int ncu = [] { hipDeviceProp_t pr{}; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+    const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN, slots = 2 * ncu;
+    const int tiles = nbm * nbn, rounds = tiles / slots, rem = tiles % slots;
+    if (rounds < 1 || rem == 0 || rem * 4 > slots * 3) return false;         // (a last round that is three quarters full is left alone)
+    const int main_bm = (rounds * slots) / nbn;
+    if (main_bm < 1 || main_bm >= nbm) return false;
+    GemmBatch bm{}, bt{};
+    bm.count = bt.count = 1;
+    GemmArgs& gm = bm.g[0]; GemmArgs& gt = bt.g[0];
+    gm = g; gt = g;
+    gm.M = main_bm * BM; gm.ksplit = 0;                                      // (0: one block per tile, and no second look at this function)
+    gt.M = g.M - gm.M; gt.ksplit = 0;
+    for (int i = 0; i < g.nseg; ++i) gt.a[i].base += (long long)gm.M * g.a[i].ld;
+    gt.out.base += (long long)gm.M * g.out.ld;
+    launch_gemm_batch(epi, bm, stream);
+    const int tail_tiles = (nbm - main_bm) * nbn;
+    launch_gemm_skinny(epi, bt, 1, tail_tiles * 4 <= 2 * slots ? 32 : 64, stream);
+    return true;
+}
+
 void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     const GemmPlan plan = plan_gemm(epi, b);
+    if (cut_partial_round(epi, b, plan, stream)) return;
     const int blocks = plan.blocks, ksplit = plan.ksplit;
     bool skinny = plan.skinny;
     // split-bf16 experiment: a launch that would go as 64- or 32-row tiles only because 128x128 tiles leave CUs idle (the

@@ -63,6 +63,21 @@ def test_split_k_forms_of_the_plain_contraction(engine, shape, tile):
         assert rms < RMS_BOUND and mx < MAX_BOUND, (shape, tile, split_k, groups, rms, mx)
 
 
+@pytest.mark.parametrize('M,N,K', [(51712, 512, 512), (52224, 2048, 512), (51712, 256, 512), (51712, 1024, 2048)])
+def test_partial_round_of_a_big_contraction_goes_as_small_tiles_with_the_same_bits(engine, M, N, K):
+    """The train step's whole-sequence contractions (M = 51 712 / 52 224 rows; the caller leaves the launch form open): a 128x128 tile
+    grid that ends in a partial round of workgroups has the row blocks of that round launched as 32- or 64-row tiles instead
+    (gemm.hip, cut_partial_round).  Same k-ordered chain per element: the result equals the one-launch form bit for bit, with
+    and without `C +=`-free bias; and the float64 product to rounding."""
+    A, Bt, bias = _operands(M, N, K, seed=M + N)
+    one = engine.debug_contract(A, Bt, bias)                      # ksplit = 0: one block per tile, one launch
+    cut = engine.debug_contract(A, Bt, bias, split_k=True)        # ksplit = -1: the launcher may cut the partial round off
+    assert np.array_equal(one, cut)
+    if N <= 512:
+        rms, mx = _errors(cut, A, Bt, bias)
+        assert rms < RMS_BOUND and mx < MAX_BOUND, (rms, mx)
+
+
 @pytest.mark.parametrize('M,N,K', [(8192, 2048, 768), (8192, 2048, 1024), (8192, 2048, 1536), (1024, 512, 512), (333, 200, 96)])
 def test_plain_contraction_equals_float64_to_rounding(engine, M, N, K):
     """The shapes of the decoder's launches (and a ragged one), every tile shape: same bits from all of them, float64 to rounding."""
