@@ -401,6 +401,15 @@ def train_bench(args):
                        'note': 'plain whole-sequence contractions through hipBLASLt instead of csrc/gemm.hip; everything else unchanged'}
         eng.set_option('vendor_gemm', 0)
     fl, ms = pl['flops'] + pg['flops'] + ps['flops'] + pp['flops'], pl['ms'] + pg['ms'] + ps['ms'] + pp['ms']
+    traffic, traffic_source = None, None        # HBM-side bytes per train step: a committed constant from PMC passes, not measured by this run
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'c4_step_traffic.json')) as f:
+            tj = json.load(f)
+        traffic = tj.get('hbm_bytes_per_launch')
+        traffic_source = ('profiles/c4_step_traffic.json: constant from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s (commit %s) '
+                          'over this command, all kernels of a step, not a measurement of this run' % (tj.get('round', '?'), tj.get('commit', '?')))
+    except Exception:
+        pass
     emit(json.dumps({
         'metric': 'trained chars/sec (1 GPU), depth-4 width-512 teacher-forced train step, 100-char lines',
         'value': B * LENGTH * args.steps / elapsed, 'unit': 'chars/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
@@ -413,7 +422,8 @@ def train_bench(args):
         'calibration': calibration,
         'roofline': {'bound': 'mfma', 'kernel': 'all GEMMs of the step (incl. the persistent recurrences: %.1f ms in %d launches)' % (pp['ms'] / max(args.steps, 1), pp['launches'] // max(args.steps, 1)), 'achieved': fl / max(ms, 1e-9) / 1e9,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / max(ms, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS,
-                     'traffic': None, 'launches': pl['launches'] + pg['launches'] + ps['launches'] + pp['launches'],
+                     'traffic': traffic, 'traffic_per': 'train step (all kernels)', 'traffic_source': traffic_source,
+                     'launches': pl['launches'] + pg['launches'] + ps['launches'] + pp['launches'],
                      # the whole step priced with SURVEY.md section 8(d)'s ~133 MFLOP per trained character
                      'whole_path': {'flop_per_char': 133e6,
                                     'frac': B * LENGTH * args.steps / elapsed * 133e6 / 1e12 / PEAK_F32_MFMA_TFLOPS}}}))
