@@ -24,17 +24,9 @@ __device__ __forceinline__ bool wait_deps(const Dep d0, const Dep d1, const Dep 
         int good = 1;
         unsigned spins = 0;
         unsigned long long t_begin = 0;
-        // (the three counters are requested TOGETHER, without conditions between the loads: as a short-circuit chain a poll was
-        // up to three dependent round trips to the memory side -- a microsecond each behind a counter another CU has just added
-        // to -- and the hop saw its last counter flip one to two such chains late.  A dependency that is not there polls one
-        // that is, against a target of zero: no extra line is touched.)
-        const unsigned* const some = d0.c ? d0.c : d1.c ? d1.c : d2.c ? d2.c : abort_w;
-        const unsigned* const p0 = d0.c ? d0.c : some; const unsigned t0 = d0.c ? d0.target : 0u;
-        const unsigned* const p1 = d1.c ? d1.c : some; const unsigned t1 = d1.c ? d1.target : 0u;
-        const unsigned* const p2 = d2.c ? d2.c : some; const unsigned t2 = d2.c ? d2.target : 0u;
         for (;;) {
-            const unsigned v0 = ld_agent(p0), v1 = ld_agent(p1), v2 = ld_agent(p2);
-            const bool ready = (v0 >= t0) & (v1 >= t1) & (v2 >= t2);
+            const bool ready = (!d0.c || ld_agent(d0.c) >= d0.target) && (!d1.c || ld_agent(d1.c) >= d1.target) &&
+                               (!d2.c || ld_agent(d2.c) >= d2.target);
             if (ready) break;
             ++spins;
             if ((spins & 255u) == 0) {
