@@ -146,6 +146,7 @@ struct TnArgs {
     int accumulate;      // C += (gradient sums) instead of C =
     int out_zeroed;      // C = with a split K: the caller has cleared C already
     float* colsum;       // optional [Mstore]: += sum_k A[k][m] (the bias gradient that goes with a weight gradient)
+    int nsplit;          // set by launch_gemm_tn: K shares of the launch
 };
 void launch_gemm_tn(const TnArgs& g, hipStream_t stream);
 void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream);

@@ -22,6 +22,9 @@ namespace casv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CASV_TN_XCD_ORDER
+#define CASV_TN_XCD_ORDER 1         // 0: tile index fastest (the order of rounds 3-4; A/B builds)
+#endif
 constexpr int TBM = 128, TBN = 128, TBK = 16;
 constexpr int T_TILE = TBK * 128;                       // floats of one operand tile in LDS ([k][128])
 
@@ -30,12 +33,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int nbn = (g.N + TBN - 1) / TBN;
-    const int bn = blockIdx.x % nbn, bm = blockIdx.x / nbn;
+    // Workgroups are dealt round-robin over the 8 XCDs (private L2s) by their linear index.  K share fastest: the workgroups of ONE
+    // K share -- every tile of the output over the same k-rows -- then sit on as few XCDs as the share count allows (one, when it
+    // is a multiple of 8), so a k-row of an operand is fetched into ONE L2 and hit there by all the tiles that need it.  With the
+    // tile index fastest every XCD held tiles of every K share: 41.6 GB per train step at the memory side for ~11 GB of operands
+    // (profiles/r05_train_pmc.txt).  Placement changes traffic and speed only.
+    const int nsplit = g.nsplit;
+    const int tile = CASV_TN_XCD_ORDER ? (int)blockIdx.x / nsplit : (int)blockIdx.x % (gridDim.x / nsplit);
+    const int zidx = CASV_TN_XCD_ORDER ? (int)blockIdx.x % nsplit : (int)blockIdx.x / (gridDim.x / nsplit);
+    const int bn = tile % nbn, bm = tile / nbn;
     const int m0 = bm * TBM, n0 = bn * TBN;
-    const int nsplit = gridDim.z;
     const int ktiles_all = (g.K + TBK - 1) / TBK;
     const int per = (ktiles_all + nsplit - 1) / nsplit;
-    const int kt_begin = blockIdx.z * per;
+    const int kt_begin = zidx * per;
     const int ntiles = ktiles_all - kt_begin < per ? (ktiles_all - kt_begin > 0 ? ktiles_all - kt_begin : 0) : per;
     if (ntiles <= 0) return;
 
@@ -233,7 +243,9 @@ void launch_gemm_tn(const TnArgs& g, hipStream_t stream) {
         if (g.ldc == g.N) (void)hipMemsetAsync(g.C, 0, (size_t)g.Mstore * g.N * sizeof(float), stream);
         else (void)hipMemset2DAsync(g.C, (size_t)g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.Mstore, stream);
     }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, 1, ks), dim3(256), 0, stream, g);
+    TnArgs gg = g;
+    gg.nsplit = ks;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * ks), dim3(256), 0, stream, gg);
 }
 
 }  // namespace casv
