@@ -54,6 +54,22 @@ void gemm_prof_dump() {
 }
 #endif
 
+#ifndef CASV_PLAIN_WIDE
+#define CASV_PLAIN_WIDE 1           // the PLAIN kernel's full-tile epilogue stores 16 bytes per lane through an in-quad transpose (0: A/B builds)
+#endif
+#if CASV_PLAIN_WIDE
+// 4 x 4 transpose inside every quad of lanes: the caller's lane q (= lane & 3) holds column q of rows 0..3 in (v0, v1, v2, v3) and
+// gets row q's four columns back.  Two exchange stages (partner q ^ 1, then q ^ 2), each swapping the off-diagonal blocks.
+__device__ __forceinline__ f32x4 quad_transpose(float v0, float v1, float v2, float v3, const int q) {
+    const bool b0 = q & 1, b1 = q & 2;
+    const float y01 = lane_xor<1>(b0 ? v0 : v1), y23 = lane_xor<1>(b0 ? v2 : v3);
+    if (b0) { v0 = y01; v2 = y23; } else { v1 = y01; v3 = y23; }
+    const float z0 = lane_xor<2>(b1 ? v0 : v2), z1 = lane_xor<2>(b1 ? v1 : v3);
+    if (b1) { v0 = z0; v1 = z1; } else { v2 = z0; v3 = z1; }
+    return f32x4{v0, v1, v2, v3};
+}
+#endif
+
 constexpr int BM = 128, BN = 128, BK = 16, LDW = BK + 4;   // 80-B LDS rows: ds_read_b128 conflict-free
 constexpr int TILE_FLOATS = 128 * LDW;               // one operand tile
 constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;
@@ -633,6 +649,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[c][r] += cb[(long long)((r & 3) + 8 * (r >> 2)) * g.out.ld + c * 32];
             }
+#if CASV_PLAIN_WIDE
+            if (EPI == EPI_PLAIN && (g.out.ld & 3) == 0) {
+                // 16-byte stores through an in-quad transpose: 16 store instructions per wave instead of 64, same bytes and addresses.
+                // Pays where tiles are short (the train step's K = 512 contractions: c4 66.4-66.5 -> 66.0-66.3 ms per step); in the
+                // LSTM kernel -- its cell epilogue, and the query job that rides in layer 1's launch -- it measured 0.3 % slower (c3).
+                const int q = lane & 3;
+                float* cq = cb + (long long)q * g.out.ld - q;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<f32x4*>(cq + (long long)(8 * gq) * g.out.ld + c * 32) =
+                            quad_transpose(acc[c][4 * gq] + bcol[c], acc[c][4 * gq + 1] + bcol[c], acc[c][4 * gq + 2] + bcol[c], acc[c][4 * gq + 3] + bcol[c], q);
+            } else
+#endif
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
