@@ -41,6 +41,19 @@ template <class T, class Op> __device__ __forceinline__ T wave_butterfly(T v, Op
     return v;
 }
 
+// 4 x 4 transpose inside every quad of lanes: the caller's lane q (= lane & 3) holds column q of rows 0..3 in (v0, v1, v2, v3) and
+// gets row q's four columns back -- two exchange stages (partner q ^ 1, then q ^ 2), each swapping the off-diagonal blocks.  A GEMM
+// epilogue whose lanes hold one column of several rows stores 16 bytes per lane with it (gemm.hip, gemm_skinny.hip: plain epilogues).
+typedef float QuadF4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ QuadF4 quad_transpose(float v0, float v1, float v2, float v3, const int q) {
+    const bool b0 = q & 1, b1 = q & 2;
+    const float y01 = lane_xor<1>(b0 ? v0 : v1), y23 = lane_xor<1>(b0 ? v2 : v3);
+    if (b0) { v0 = y01; v2 = y23; } else { v1 = y01; v3 = y23; }
+    const float z0 = lane_xor<2>(b1 ? v0 : v2), z1 = lane_xor<2>(b1 ? v1 : v3);
+    if (b1) { v0 = z0; v1 = z1; } else { v2 = z0; v3 = z1; }
+    return QuadF4{v0, v1, v2, v3};
+}
+
 #ifdef CASV_ACCURATE_ACT       // measurement aid (profiles/r04_split_bf16.txt, section 9): libm's functions in place of the exp2/rcp forms
 __device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
 __device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

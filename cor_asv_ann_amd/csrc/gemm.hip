@@ -57,18 +57,6 @@ void gemm_prof_dump() {
 #ifndef CASV_PLAIN_WIDE
 #define CASV_PLAIN_WIDE 1           // the PLAIN kernel's full-tile epilogue stores 16 bytes per lane through an in-quad transpose (0: A/B builds)
 #endif
-#if CASV_PLAIN_WIDE
-// 4 x 4 transpose inside every quad of lanes: the caller's lane q (= lane & 3) holds column q of rows 0..3 in (v0, v1, v2, v3) and
-// gets row q's four columns back.  Two exchange stages (partner q ^ 1, then q ^ 2), each swapping the off-diagonal blocks.
-__device__ __forceinline__ f32x4 quad_transpose(float v0, float v1, float v2, float v3, const int q) {
-    const bool b0 = q & 1, b1 = q & 2;
-    const float y01 = lane_xor<1>(b0 ? v0 : v1), y23 = lane_xor<1>(b0 ? v2 : v3);
-    if (b0) { v0 = y01; v2 = y23; } else { v1 = y01; v3 = y23; }
-    const float z0 = lane_xor<2>(b1 ? v0 : v2), z1 = lane_xor<2>(b1 ? v1 : v3);
-    if (b1) { v0 = z0; v1 = z1; } else { v2 = z0; v3 = z1; }
-    return f32x4{v0, v1, v2, v3};
-}
-#endif
 
 constexpr int BM = 128, BN = 128, BK = 16, LDW = BK + 4;   // 80-B LDS rows: ds_read_b128 conflict-free
 constexpr int TILE_FLOATS = 128 * LDW;               // one operand tile
@@ -660,7 +648,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
-                        *reinterpret_cast<f32x4*>(cq + (long long)(8 * gq) * g.out.ld + c * 32) =
+                        *reinterpret_cast<QuadF4*>(cq + (long long)(8 * gq) * g.out.ld + c * 32) =
                             quad_transpose(acc[c][4 * gq] + bcol[c], acc[c][4 * gq + 1] + bcol[c], acc[c][4 * gq + 2] + bcol[c], acc[c][4 * gq + 3] + bcol[c], q);
             } else
 #endif

@@ -343,6 +343,8 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const GemmBatch bat
             // full tile, plain stores: nothing between the stores that the compiler would wait at (gemm.hip's epilogue, round 4)
             const float b = g.bias ? g.bias[n] : 0.0f;
             float* cb = cbase + (long long)(m0 + 4 * lh) * g.out.ld + n;
+            // (16-byte stores through an in-quad transpose, as in gemm.hip's plain epilogue: measured here too, round 5 -- no difference
+            // for the logits launches of c3 or the page call)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
