@@ -279,6 +279,8 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
 
     if (g < pa.g_lstm) {
         // ------------------------------------------------------------------ LSTM tiles
+        // (a static s_setprio 1 / 3 for the tile waves -- ahead of the attention / plain workgroup that shares their SIMDs on 192 of the
+        // 256 CUs -- measured in round 5: 8.25-8.30 ms per batch of configs[1] against 8.29-8.39 without, within the noise; not kept)
         const int NT = NRB * NUG;
         for (int s = 0; s <= S; ++s) {
             for (int n = 1; n <= D; ++n) {
