@@ -104,6 +104,7 @@ struct casv_model {
     bool enc_check_pending = false;                       // the persistent encoder's give-up word has not been looked at yet (engine.hip, settle_encoder)
     char* pin_in = nullptr; size_t pin_in_cap = 0;        // pinned staging of casv_encode's inputs (reused behind ev_inputs)
     char* pin_out = nullptr; size_t pin_out_cap = 0;      // pinned staging of the greedy decode's results
+    size_t pin_limit = (size_t)64 << 20;                  // larger inputs / results bypass the pinned staging (option "pin_limit_mb")
     int persist_mode = -1;                                // -1 by size, 0 never, 1 always (greedy decode of small batches)
     int persist_skip = 0, persist_penalty = 0; bool persist_told = false;   // back-off after a persistent launch gave up waiting
     int ncu = 0;

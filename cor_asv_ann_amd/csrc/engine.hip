@@ -451,6 +451,15 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
     // the function returns while they are still queued (waiting for pageable copies cost every batch of configs[1] ~40 us of idle
     // GPU) -- and the staging buffer is reused only once its previous copies have gone (ev_inputs).
     const size_t nin = BT * A * 4, nrej = BT * 4, need = 2 * nin + nrej;
+    if (need > m->pin_limit) {
+        // (very large inputs: no pinned copy of that size -- straight from the caller's buffers, and wait until they have been read)
+        HIPCHK(hipMemcpyAsync(m->d_idx.p, idx, nin, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(m->d_val.p, val, nin, hipMemcpyHostToDevice, m->stream));
+        if (src_rej) HIPCHK(hipMemcpyAsync(m->d_srcrej.p, src_rej, nrej, hipMemcpyHostToDevice, m->stream));
+        else HIPCHK(hipMemsetAsync(m->d_srcrej.p, 0xff, nrej, m->stream));
+        HIPCHK(hipEventRecord(m->ev_inputs, m->stream));
+        HIPCHK(hipEventSynchronize(m->ev_inputs));
+    } else {
     if (m->pin_in_cap < need) {
         if (m->pin_in) { HIPCHK(hipStreamSynchronize(m->stream)); (void)hipHostFree(m->pin_in); m->pin_in = nullptr; m->pin_in_cap = 0; }
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->pin_in), need, hipHostMallocDefault));
@@ -463,6 +472,7 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
     if (src_rej) HIPCHK(hipMemcpyAsync(m->d_srcrej.p, m->pin_in + 2 * nin, nrej, hipMemcpyHostToDevice, m->stream));
     else HIPCHK(hipMemsetAsync(m->d_srcrej.p, 0xff, nrej, m->stream));
     HIPCHK(hipEventRecord(m->ev_inputs, m->stream));
+    }
     m->B = B; m->T = T; m->A = A;
     m->last_decode = 0; m->has_a0 = false;
     m->enc_check_pending = false;
@@ -895,11 +905,14 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (int rc = m->d_flags.ensure(64)) return rc;
     // results and flags come back through a pinned staging buffer: three queued copies, ONE wait for the device
     const size_t nres = (size_t)B * S * 4, need = 2 * nres + 64;
-    if (m->pin_out_cap < need) {
+    const bool staged = need <= m->pin_limit;                // (very large results go straight to the caller's arrays)
+    if (m->pin_out_cap < (staged ? need : 64)) {
+        const size_t want = staged ? need : 64;
         if (m->pin_out) { (void)hipHostFree(m->pin_out); m->pin_out = nullptr; m->pin_out_cap = 0; }
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->pin_out), need, hipHostMallocDefault));
-        m->pin_out_cap = need;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->pin_out), want, hipHostMallocDefault));
+        m->pin_out_cap = want;
     }
+    unsigned* const pin_flags = reinterpret_cast<unsigned*>(staged ? m->pin_out + 2 * nres : m->pin_out);
     bool persistent = persist_applies(m, B) && !persist_backed_off(m);
     auto begin = [&](bool with_counters) -> int {        // the set-up of a run, as one launch
         SmallOps ops{};
@@ -925,11 +938,11 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
                 })) return rc;
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(m->pin_out, m->o_idx.p, nres, hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(hipMemcpyAsync(m->pin_out + nres, m->o_prob.p, nres, hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(hipMemcpyAsync(m->pin_out + 2 * nres, m->d_flags.p, 8, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(staged ? (void*)m->pin_out : (void*)out_idx, m->o_idx.p, nres, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(staged ? (void*)(m->pin_out + nres) : (void*)out_prob, m->o_prob.p, nres, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(pin_flags, m->d_flags.p, 8, hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
-        const unsigned* flags = reinterpret_cast<const unsigned*>(m->pin_out + 2 * nres);
+        const unsigned* flags = pin_flags;
         // a persistent launch whose hand-off wait ran out (its workgroups were not all resident: another process running a
         // persistent kernel on this GPU) loses nothing -- the per-step kernels compute the same values; start over with them
         const int redone = settle_encoder(m, &flags[0]);
@@ -940,7 +953,7 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
         if (!redone && !dec_aborted) break;
         if (attempt >= 2) return fail(CASV_ERR_STATE, "persistent launches keep giving up");
     }
-    memcpy(out_idx, m->pin_out, nres); memcpy(out_prob, m->pin_out + nres, nres);
+    if (staged) { memcpy(out_idx, m->pin_out, nres); memcpy(out_prob, m->pin_out + nres, nres); }
     // mode 1 stops a line at its end-of-line character (seq2seq.py:1344); np.nanargmax raises only if an all-NaN row
     // turns up BEFORE that (the device marks such a step with a NaN probability) -- rows keep stepping in lockstep
     // after their line has ended, and what they produce there is nobody's business
@@ -1312,6 +1325,10 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
     if (!strcmp(key, "eos")) {
         if (value < 0 || value >= m->V) return fail(CASV_ERR_ARG, "eos index %lld outside the vocabulary", (long long)value);
         m->eos = (int)value; return CASV_OK;
+    }
+    if (!strcmp(key, "pin_limit_mb")) {
+        if (value < 0 || value > 4096) return fail(CASV_ERR_ARG, "pin_limit_mb out of range 0..4096");
+        m->pin_limit = (size_t)value << 20; return CASV_OK;
     }
     if (!strcmp(key, "fused_backward")) { m->fused_backward = value != 0; return CASV_OK; }
     if (!strcmp(key, "vendor_gemm")) { m->vendor_gemm = value != 0; return CASV_OK; }

@@ -238,6 +238,8 @@ int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int32_t N, int3
  * "vendor_gemm" = 0 (default): every contraction runs in this library's own kernels; 1 = calibration: the train step's plain
  * whole-sequence contractions (input projections, their data gradients) go through hipBLASLt where it can be loaded at run time
  * (bench.py reports that time beside the own-kernel figure; inference never uses it);
+ * "pin_limit_mb" (default 64) = inputs of casv_encode / results of casv_decode_greedy up to this size travel through a pinned staging
+ * buffer of the handle (the call returns without waiting for its copies); larger ones are copied from / to the caller's arrays directly;
  * "eos" = vocabulary index of the end-of-line character '\n' (default 1: '' and '\n' sort first, seq2seq.py:580);
  * "tile" (process-wide; alias "skinny") = tile shape of the GEMM launches: -1 by size (default), 0 always 128x128,
  * 1 always 32x128, 2 = 64x128 wherever there is no split-K -- a measurement/test switch, the values computed are the same bit

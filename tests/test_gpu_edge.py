@@ -257,6 +257,32 @@ def test_any_width_decodes_like_the_oracle(d, W):
         assert w_back[k].shape == np.asarray(v).shape and np.array_equal(w_back[k], np.asarray(v, np.float32)), k
 
 
+def test_staged_and_direct_copies_give_the_same_results():
+    """Inputs of `casv_encode` and results of `casv_decode_greedy` go through pinned staging buffers of the handle up to
+    "pin_limit_mb", straight from / to the caller's arrays beyond: same bits either way (limit 0 forces the direct path),
+    in both greedy modes and for the beam, also when the calls alternate."""
+    cfg = ModelConfig(depth=2, width=64, voc_size=64)
+    weights = make_weights(cfg, emb_scale=12.0)
+    from cor_asv_ann_amd.engine import HipEngine
+    eng = HipEngine(cfg.depth, cfg.width, cfg.voc_size)
+    eng.set_weights(weights)
+    _, idx = make_lines(9, 14, 77, voc_size=64)
+    out = {}
+    for limit in (64, 0, 64, 0):
+        eng.set_option('pin_limit_mb', limit)
+        eng.encode(idx)
+        g0 = eng.decode_greedy(mode=0)
+        eng.encode(idx)
+        b = eng.decode_beam(batch_size=4)
+        got = (g0[0], g0[1], b['idx'], b['prob'], b['score'])
+        if 'want' in out:
+            for x, y in zip(got, out['want']):
+                assert np.array_equal(x, y, equal_nan=True)
+        out['want'] = got
+    eng.set_option('pin_limit_mb', 64)
+    eng.close()
+
+
 @pytest.mark.parametrize('mode', ['fast', 'greedy', 'beam'])
 def test_pipelined_batches_equal_one_call_per_batch(mode):
     """`correct_batches` (vectorising, device and result building of consecutive batches overlapped in three stages) returns what
