@@ -230,8 +230,26 @@ extern "C" int casv_commit_weights(casv_model* m) {
 // ------------------------------------------------------------------------------------------------
 // Persistent launches (persist.hip) are serialised inside the process: two of them together can want more workgroup slots
 // than the chip has, and workgroups that spin on peers which are not resident never make room for them.  (Across processes
-// the bounded spins catch that case: the launch aborts and the caller falls back to the per-step kernels.)
+// the bounded spins catch that case: the launch aborts and the caller falls back to the per-step kernels.)  On the host the
+// mutex orders the ENQUEUEING of such launches (round 5: no call waits for its kernel inside it any more) ...
 static std::mutex g_persist_mutex;
+// ... and on the DEVICE: a persistent launch of any handle starts behind the previous one of the process on the same device (an
+// event wait on the launching handle's stream -- the host does not wait).  Call both with g_persist_mutex held.
+static hipEvent_t g_persist_event[64];
+static bool g_persist_event_made[64] = {false}, g_persist_event_set[64] = {false};
+static void persist_order_before(casv_model* m) {
+    const int d = m->device;
+    if (d >= 0 && d < 64 && g_persist_event_set[d]) (void)hipStreamWaitEvent(m->stream, g_persist_event[d], 0);
+}
+static void persist_order_after(casv_model* m) {
+    const int d = m->device;
+    if (d < 0 || d >= 64) return;
+    if (!g_persist_event_made[d]) {
+        if (hipEventCreateWithFlags(&g_persist_event[d], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        g_persist_event_made[d] = true;
+    }
+    if (hipEventRecord(g_persist_event[d], m->stream) == hipSuccess) g_persist_event_set[d] = true;
+}
 // A persistent launch that gave up waiting (its workgroups were not all resident: the GPU is shared with another process's
 // persistent kernel, or partitioned) costs one bounded wait.  The handle then leaves the persistent path alone for a number
 // of calls that doubles with every further abort, instead of paying that wait on every call.
@@ -334,7 +352,9 @@ static int run_encoder(casv_model* m, bool try_persistent) {
 #endif
         hipEvent_t pev{};
         m->prof_begin(PC_PERSIST, 2.0 * BT * 4.0 * W * (2.0 * 2 * W + (D >= 2 ? 3.0 * W : 0.0) + (D >= 3 ? (D - 2) * 2.0 * W : 0.0)), 0.0, pev);
+        persist_order_before(m);
         if (launch_persist_encode(pa, grid, m->stream)) return fail(CASV_ERR_ARG, "persistent encoder: rows do not fit the LDS");
+        persist_order_after(m);
         m->prof_end(PC_PERSIST, pev);
         HIPCHK(hipGetLastError());
         enc_abort_word = m->p_enc_counters.as<unsigned>() + (size_t)nrb * (D + 1) * 32;
@@ -849,7 +869,9 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S) {
         const double by = 4.0 * R * (4.0 * D * W + 11.0 * (W + C) + 2.0 * m->V + 2.0 * T);
         m->prof_begin(PC_PERSIST, fl * S, by * S, pev);
     }
+    persist_order_before(m);
     if (launch_persist_decode(pa, m->stream)) return fail(CASV_ERR_ARG, "persistent decoder: rows of %d floats do not fit the LDS", kmax);
+    persist_order_after(m);
     m->prof_end(PC_PERSIST, pev);
     HIPCHK(hipGetLastError());
 #ifdef CASV_PERSIST_PROF

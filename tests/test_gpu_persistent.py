@@ -150,3 +150,45 @@ def test_handoffs_under_uneven_load():
     finally:
         stop.append(1)
         th.join()
+
+
+def test_two_handles_decoding_persistently_at_once():
+    """Two model handles on two host threads, both on the persistent encoder + decoder (each launch wants most of the chip's
+    workgroup slots and its workgroups wait for each other): the launches are ordered on the DEVICE (an event between the
+    handles' streams -- no host call waits inside the process-wide lock any more), none gives up, and every result equals the
+    handle's own results when it runs alone."""
+    import threading
+    from cor_asv_ann_amd.engine import HipEngine
+    cfg = ModelConfig(depth=2, width=128, voc_size=64)
+    weights = make_weights(cfg, emb_scale=24.0)
+    batches = [make_lines(64 + 16 * k, 20 + k, 900 + k, voc_size=64)[1] for k in range(4)]
+    alone = []
+    eng = _engine(cfg, weights)
+    eng.set_option('persistent', 1)
+    for idx in batches:
+        eng.encode(idx)
+        alone.append(eng.decode_greedy(mode=0)[:2])
+    eng.close()
+    errors = []
+
+    def worker(order):
+        try:
+            e = HipEngine(cfg.depth, cfg.width, cfg.voc_size)
+            e.set_weights(weights)
+            e.set_option('persistent', 1)
+            for rep in range(6):
+                for k in order:
+                    e.encode(batches[k])
+                    gi, gp = e.decode_greedy(mode=0)[:2]
+                    if not (np.array_equal(gi, alone[k][0]) and np.array_equal(gp, alone[k][1])):
+                        errors.append((order, rep, k))
+            e.close()
+        except Exception as err:            # reported by the main thread
+            errors.append(repr(err))
+
+    threads = [threading.Thread(target=worker, args=(o,)) for o in ([0, 1, 2, 3], [3, 2, 1, 0])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
