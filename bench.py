@@ -401,6 +401,30 @@ def train_bench(args):
                        'note': 'plain whole-sequence contractions through hipBLASLt instead of csrc/gemm.hip; everything else unchanged'}
         eng.set_option('vendor_gemm', 0)
     fl, ms = pl['flops'] + pg['flops'] + ps['flops'] + pp['flops'], pl['ms'] + pg['ms'] + ps['ms'] + pp['ms']
+    cpu = None
+    if not args.no_cpu_baseline and facade is None:
+        # the oracle's train step (numpy fp32: forward, hand-derived BPTT, clip, Adam) on a bounded sample of the same batch, host cores
+        from oracle import make_weights as oracle_weights
+        from oracle.train import forward_backward, adam_step
+
+        def one_hot(idx):
+            out = np.zeros(idx.shape + (VOC,), np.float32)
+            b, t = np.nonzero(idx >= 0)
+            out[b, t, idx[b, t]] = 1.0
+            return out
+        ow = oracle_weights(cfg, emb_scale=4.0)
+
+        def cpu_step(n):
+            mk = {'enc': masks['enc'], 'dec': masks['dec'], 'cell': masks['cell'][:n]}
+            t0 = time.perf_counter()
+            _, grads, _ = forward_backward(cfg, ow, one_hot(sidx[:n]), one_hot(dec_in[:n]), one_hot(dec_out[:n]), wts[:n], mk)
+            adam_step({k: v.copy() for k, v in ow.items()}, grads, {'t': 0, 'm': {}, 'v': {}})
+            return time.perf_counter() - t0
+        t1 = cpu_step(2)                                          # warm-up; sizes the sample
+        n = int(max(2, min(64, args.cpu_budget / 2.0 / max(t1 / 2, 1e-6))))
+        best = min(cpu_step(n) for _ in range(2))
+        cpu = {'value': n * LENGTH / best, 'unit': 'chars/s', 'cores': host_threads(), 'kind': 'port',
+               'sample': 'best of 2 train steps of the numpy fp32 oracle (forward, BPTT, clip, Adam) on the first %d lines of the same batch, %.1f s per step' % (n, best)}
     traffic, traffic_source = None, None        # HBM-side bytes per train step: a committed constant from PMC passes, not measured by this run
     try:
         with open(os.path.join(ROOT, 'profiles', 'c4_step_traffic.json')) as f:
@@ -419,7 +443,7 @@ def train_bench(args):
                    'batches': 'read from a TSV file and vectorised by the worker thread of train() (training.prefetch)' if args.facade
                               else 'one synthetic batch, resident on the host', 'last_loss': loss, 'last_grad_norm': norm,
                    'vendor_gemm': vendor_default},
-        'calibration': calibration,
+        'calibration': calibration, 'cpu_baseline': cpu,
         'roofline': {'bound': 'mfma', 'kernel': 'all GEMMs of the step (incl. the persistent recurrences: %.1f ms in %d launches)' % (pp['ms'] / max(args.steps, 1), pp['launches'] // max(args.steps, 1)), 'achieved': fl / max(ms, 1e-9) / 1e9,
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / max(ms, 1e-9) / 1e9 / PEAK_F32_MFMA_TFLOPS,
                      'traffic': traffic, 'traffic_per': 'train step (all kernels)', 'traffic_source': traffic_source,
@@ -803,7 +827,7 @@ def other_workloads(with_cpu_baseline=True):
                         # the headline's workload under the split-bf16 experiment: reported here only
                         ('c3_split_bf16', ['--steps', '5', '--warmup', '2', '--split-bf16', '2'])):
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', name.split('_')[0], '--no-others'] + extra
-        cmd += ['--cpu-budget', '8'] if name in ('c2', 'page') and with_cpu_baseline else ['--no-cpu-baseline']
+        cmd += ['--cpu-budget', '8'] if name in ('c2', 'c4', 'page') and with_cpu_baseline else ['--no-cpu-baseline']
         env = {k: v for k, v in os.environ.items() if not k.startswith('CASV_BENCH_')}
         try:
             t0 = time.perf_counter()
