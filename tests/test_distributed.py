@@ -126,6 +126,40 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert out['value'] == pytest.approx(18 * 100 * 2 / (out['ms_per_step'] * 2e-3), rel=1e-6)
 
 
+def test_bench_under_torch_distributed_run_as_the_driver_starts_it():
+    """The driver's N > 1 command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks, dry (no device; gloo carries the gather): every
+    rank takes RANK / LOCAL_RANK / WORLD_SIZE from the launcher, pins itself to CPUs of its own, and exactly ONE JSON line comes out
+    (rank 0's), with configs[4]'s shape, both ranks' own times and their host placement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CASV_BENCH_DRY_RUN='1', CASV_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    out = lines[0]
+    assert out['n_gpus'] == 2 and out['steps'] == 1 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['config']['launcher'] == 'torch.distributed.run' and 'configs[4]' in out['config']['workload']
+    assert out['config']['lines_per_gpu'] == 8192 and out['gathered_records'] == 16384
+    assert len(out['ms_per_step_by_rank']) == 2 and len(set(out['ms_per_step_by_rank'])) == 2
+    place = out['config']['host_placement_by_rank']
+    assert len(place) == 2 and all(q['threads'] >= 1 for q in place)
+    if len(os.sched_getaffinity(0)) >= 2:
+        import bench
+        a, b = (set(bench.parse_cpulist(q['cpus'])) for q in place)
+        assert a and b and not (a & b)
+
+
 def test_bench_fails_when_a_rank_fails():
     """Without the dry-run switch the ranks need a GPU: on a CPU box every rank fails and so does the launcher
     (no silent single-rank run, no fallback)."""
