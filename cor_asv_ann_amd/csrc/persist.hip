@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
     extern __shared__ __attribute__((aligned(16))) float s_a[];         // 16 staged activation rows, stride pa.lda
     __shared__ float s_gate[4][16 * 16];
     __shared__ float s_m[16], s_sum[16];
+    __shared__ float s_bias[64];                                        // the tile's bias values [gate][unit]
     __shared__ int s_nan0[16];
     __shared__ int s_ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,6 +312,10 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
                     const int erow_c = erow < R ? erow : R - 1;
                     float cprev = 0.0f;
                     if (s < S) cprev = pa.c[n - 1][(long long)s * RW + (long long)erow_c * W + eu];
+                    // the tile's bias: requested ahead of the rows, parked in LDS behind them -- read from memory behind the gate
+                    // exchange it was a cache round trip on the critical path of every cell
+                    float bias_v = 0.0f;
+                    if (tid < 64) bias_v = L.bias[(long long)ug * 64 + tid];
                     // the 16 rows of [x | ctx | h] -> LDS: x = the logits of step s-1 (layer 1; slot s) or the output of the layer
                     // below at this step (slot s+1), ctx of this step, h of step s-1 (slot s)
                     {
@@ -323,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
                         else if (top) stage_rows(s_a, lda, 0, gx, gc, gh, rb, R, tid);
                         else stage_rows(s_a, lda, 0, gx, gh, none, rb, R, tid);
                     }
+                    if (tid < 64) s_bias[tid] = bias_v;
                     __syncthreads();
                     if (first && s > 0) {
                         // softmax statistics of the 16 rows from the logits of step s-1 (unit group 0 reports the character),
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
                     for (int q = 0; q < 4; ++q) s_gate[wave][((lane >> 4) * 4 + q) * 16 + (lane & 15)] = acc[q];
                     __syncthreads();
                     const int e = tid;
-                    const float* bias = L.bias + (long long)ug * 64 + (tid & 15);
+                    const float* bias = s_bias + (tid & 15);
                     const float zi = s_gate[0][e] + bias[0], zf = s_gate[1][e] + bias[16], zg = s_gate[2][e] + bias[32], zo = s_gate[3][e] + bias[48];
                     const LstmCellOut cell = lstm_cell(zi, zf, zg, zo, cprev);
                     if (erow < R) {
@@ -471,6 +477,7 @@ constexpr int PENC_MAXT = 8;        // tiles of one phase a workgroup may own
 __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEncArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float s_a[];
     __shared__ float s_gate[4][16 * 16];
+    __shared__ float s_bias[64];
     __shared__ int s_ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = pa.B, T = pa.T, D = pa.D, W = pa.W, lda = pa.lda;
@@ -498,7 +505,10 @@ __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEnc
         PROF_T(t0);
         if (!wait_deps(dx, dh, d3, abort_w, &s_ok)) return false;
         PROF_T(t1);
+        float bias_v = 0.0f;                                        // (ahead of the rows, parked in LDS behind them: see the decoder's tiles)
+        if (tid < 64) bias_v = L.bias[(long long)ug * 64 + tid];
         stage_rows(s_a, lda, 0, RowSeg{xbase, (int)xld, kx}, RowSeg{hprev, (int)hld, first ? 0 : W}, RowSeg{nullptr, 0, 0}, rb, B, tid);
+        if (tid < 64) s_bias[tid] = bias_v;
         __syncthreads();
         PROF_T(t2);
         const f32x4 acc = k_loop(s_a, lda, b, ring, 0, nt, lane);
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void persist_encode_kernel(const PersistEnc
 #pragma unroll
         for (int q = 0; q < 4; ++q) s_gate[wave][((lane >> 4) * 4 + q) * 16 + (lane & 15)] = acc[q];
         __syncthreads();
-        const float* bias = L.bias + (long long)ug * 64 + ec;
+        const float* bias = s_bias + ec;
         const float zi = s_gate[0][tid] + bias[0], zf = s_gate[1][tid] + bias[16], zg = s_gate[2][tid] + bias[32], zo = s_gate[3][tid] + bias[48];
         const LstmCellOut c = lstm_cell(zi, zf, zg, zo, first ? 0.0f : creg);
         creg = c.c;
