@@ -147,73 +147,75 @@ __device__ __forceinline__ f32x4 k_loop(const float* s_a, const int lda, const f
     return acc;
 }
 
-// Softmax statistics + greedy pick (the arithmetic of softmax_kernel, decode_kernels.hip: per-lane partial results over
-// v = lane, lane + 64, ... in ascending order, then the same butterflies) of FOUR rows by one wave.  The rows are
-// independent, so their loads, transcendentals and shuffles interleave; every row's numbers are what the one-row kernel
-// computes.  VPL = vocabulary entries per lane held in registers (V <= 64 * VPL); FULL: V = Vp = 64 * VPL, no entry is
-// conditional.
-template <int VPL, bool FULL>
-__device__ __forceinline__ void row_stats4(float* const (&x)[4], const int V, const int Vp, const int mode, const int lane,
-                                           const bool (&emit)[4], int* const (&out_idx)[4], float* const (&out_prob)[4],
-                                           int* nan_flag, RowStat (&st)[4]) {
-    float xv[4][VPL];
+// Softmax statistics + greedy pick (the arithmetic of softmax_kernel, decode_kernels.hip) of FOUR rows by one wave, V <= 256:
+// one row per quarter of the wave, lane j of a quarter owns the entries v = j, j + 16, ..., j + 240.  The one-row kernel sums a
+// row as per-lane partial sums over v = l, l + 64, l + 128, l + 192 (lane l of 64, ascending) followed by butterflies over the
+// partners 32, 16, 8, 4, 2, 1; the entries of leaves l = j, j + 16, j + 32, j + 48 sit in ONE lane here, so the four leaf sums
+// and the first two butterfly levels -- (p[0] + p[2]) + (p[1] + p[3]), additions commute bit for bit -- are that lane's own
+// arithmetic and only the partners 8, 4, 2, 1 cross lanes: the same additions in the same tree, the same bits.  Maximum, NaN count
+// and pick do not depend on the order.  Against four rows one after another on all 64 lanes (before): a sixth of the butterfly
+// steps, the four rows' transcendentals side by side.  FULL: V = Vp = 256, no entry is conditional.
+template <class T, class Op> __device__ __forceinline__ T quarter_butterfly(T v, Op op) {
+    v = op(v, lane_xor<8>(v)); v = op(v, lane_xor<4>(v)); v = op(v, lane_xor<2>(v)); v = op(v, lane_xor<1>(v));
+    return v;
+}
+template <bool FULL>
+__device__ __forceinline__ void row_stats_quarter(float* xrow, const int V, const int Vp, const int mode, const int lane,
+                                                  const bool emit, int* out_idx, float* out_prob, int* nan_flag) {
+    const int j = lane & 15;
+    float* xp = xrow + perm16(j);                 // entry v = j + 16 i sits at position 16 i + perm16(j) of the staged row
+    float xv[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 16; ++i) xv[i] = (FULL || j + 16 * i < V) ? xp[16 * i] : 0.0f;
+    float m = -INFINITY, nan = 0.0f;
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) { const int v = lane + 64 * k; xv[i][k] = (FULL || v < V) ? x[i][permv(v)] : 0.0f; }
-    float m[4], nan[4], sum[4], best[4], p0[4];
-    int bidx[4];
+    for (int i = 0; i < 16; ++i)
+        if (FULL || j + 16 * i < V) { m = fmaxf(m, xv[i]); nan += (xv[i] != xv[i]) ? 1.0f : 0.0f; }
+    m = quarter_butterfly(m, [](float a, float b) { return fmaxf(a, b); });
+    nan = quarter_butterfly(nan, [](float a, float b) { return a + b; });
+    if (nan > 0.0f) m = __builtin_nanf("");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        m[i] = -INFINITY; nan[i] = 0.0f;
+    for (int i = 0; i < 16; ++i)
+        if (FULL || j + 16 * i < V) xv[i] = expf(xv[i] - m);                  // xv now holds exp(x - m)
+    float p[4];
 #pragma unroll
-        for (int k = 0; k < VPL; ++k)
-            if (FULL || lane + 64 * k < V) { m[i] = fmaxf(m[i], xv[i][k]); nan[i] += (xv[i][k] != xv[i][k]) ? 1.0f : 0.0f; }
+    for (int a = 0; a < 4; ++a) {
+        p[a] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (FULL || j + 16 * (a + 4 * k) < V) p[a] += xv[a + 4 * k];
     }
+    float sum = (p[0] + p[2]) + (p[1] + p[3]);
+    sum = quarter_butterfly(sum, [](float a, float b) { return a + b; });
+    float best = -INFINITY, p0 = 0.0f;
+    int bidx = 0x7fffffff;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { m[i] = wave_max(m[i]); nan[i] = wave_sum(nan[i]); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (nan[i] > 0.0f) m[i] = __builtin_nanf("");
-        sum[i] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < VPL; ++k)
-            if (FULL || lane + 64 * k < V) { xv[i][k] = expf(xv[i][k] - m[i]); sum[i] += xv[i][k]; }     // xv now holds exp(x - m)
+    for (int i = 0; i < 16; ++i) {
+        const int v = j + 16 * i;
+        const float pv = (FULL || v < V) ? xv[i] / sum : 0.0f;
+        if (v == 0) p0 = pv;
+        if (v >= 1 && (FULL || v < V) && pv > best) { best = pv; bidx = v; }
+        xv[i] = pv;                                                           // xv now holds the distribution
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sum[i] = wave_sum(sum[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        best[i] = -INFINITY; bidx[i] = 0x7fffffff; p0[i] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < VPL; ++k) {
-            const int v = lane + 64 * k;
-            const float pv = (FULL || v < V) ? xv[i][k] / sum[i] : 0.0f;
-            if (v == 0) p0[i] = pv;
-            if (v >= 1 && (FULL || v < V) && pv > best[i]) { best[i] = pv; bidx[i] = v; }
-            xv[i][k] = pv;                                        // xv now holds the distribution
-        }
+    {   // wave_argmax's rule over the quarter: larger value wins, the lower index among equals
+        auto step = [&](const float ob, const int oi) { if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; } };
+        step(lane_xor<8>(best), lane_xor<8>(bidx)); step(lane_xor<4>(best), lane_xor<4>(bidx));
+        step(lane_xor<2>(best), lane_xor<2>(bidx)); step(lane_xor<1>(best), lane_xor<1>(bidx));
     }
+    int idx = bidx, nan0 = 0;
+    float pr = best;
+    if (bidx == 0x7fffffff) {                                                 // every candidate NaN: numpy raises here
+        if (emit && j == 0 && nan_flag) atomicOr(nan_flag, 1);
+        idx = 1; pr = __builtin_nanf("");
+    } else if (mode == 1) {
+        if (p0 >= best && p0 == p0) nan0 = 1;      // seq2seq.py:1334: NaN over index 0, stays in the feedback (p0: lane j = 0, the only one that uses it)
+    }
+    if (emit && j == 0) { *out_idx = idx; *out_prob = pr; }
+    // the row becomes the fed-back distribution in place (zeros in the K padding beyond V)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wave_argmax(best[i], bidx[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float p00 = __shfl(p0[i], 0, 64);
-        st[i].m = m[i]; st[i].sum = sum[i]; st[i].nan0 = 0;
-        int idx = bidx[i]; float pr = best[i];
-        if (bidx[i] == 0x7fffffff) {                              // every candidate NaN: numpy raises here
-            if (emit[i] && lane == 0 && nan_flag) atomicOr(nan_flag, 1);
-            idx = 1; pr = __builtin_nanf("");
-        } else if (mode == 1) {
-            if (p00 >= best[i] && p00 == p00) st[i].nan0 = 1;    // seq2seq.py:1334: NaN over index 0, stays in the feedback
-        }
-        if (emit[i] && lane == 0) { *out_idx[i] = idx; *out_prob[i] = pr; }
-        // the row becomes the fed-back distribution in place (zeros in the K padding beyond V)
-#pragma unroll
-        for (int k = 0; k < VPL; ++k) {
-            const int v = lane + 64 * k;
-            if (FULL || v < Vp) x[i][permv(v)] = (v == 0 && st[i].nan0) ? __builtin_nanf("") : xv[i][k];
-        }
+    for (int i = 0; i < 16; ++i) {
+        const int v = j + 16 * i;
+        if (FULL || v < Vp) xp[16 * i] = (v == 0 && nan0) ? __builtin_nanf("") : xv[i];
     }
 }
 
@@ -333,20 +335,22 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
                     if (first && s > 0) {
                         // softmax statistics of the 16 rows from the logits of step s-1 (unit group 0 reports the character),
                         // then the rows become the fed-back distribution in place (softmax_kernel: expf(x - m) / sum)
-                        float* xr[4]; bool emit[4]; int* oi[4]; float* op[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int rr = rb * 16 + wave * 4 + i;
-                            const int r = rr < R ? rr : R - 1;
-                            xr[i] = s_a + (wave * 4 + i) * lda; emit[i] = ug == 0 && rr < R;
-                            oi[i] = pa.out_idx + (long long)r * S + (s - 1); op[i] = pa.out_prob + (long long)r * S + (s - 1);
-                        }
-                        RowStat q[4];
-                        if (V == 256 && Vp == 256) row_stats4<4, true>(xr, V, Vp, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
-                        else if (V <= 256) row_stats4<4, false>(xr, V, Vp, pa.mode, lane, emit, oi, op, pa.nan_flag, q);
+                        const int rq = rb * 16 + wave * 4 + (lane >> 4);       // this quarter-wave's row
+                        const int rqc = rq < R ? rq : R - 1;
+                        float* const xq = s_a + (wave * 4 + (lane >> 4)) * lda;
+                        const bool emit_q = ug == 0 && rq < R;
+                        int* const oi_q = pa.out_idx + (long long)rqc * S + (s - 1);
+                        float* const op_q = pa.out_prob + (long long)rqc * S + (s - 1);
+                        if (V == 256 && Vp == 256) row_stats_quarter<true>(xq, V, Vp, pa.mode, lane, emit_q, oi_q, op_q, pa.nan_flag);
+                        else if (V <= 256) row_stats_quarter<false>(xq, V, Vp, pa.mode, lane, emit_q, oi_q, op_q, pa.nan_flag);
                         else {
-                            // large vocabularies: one row at a time, values re-read in every pass, then the rows are rewritten
-                            for (int i = 0; i < 4; ++i) q[i] = row_stats(xr[i], V, Vp, pa.mode, lane, emit[i], oi[i], op[i], pa.nan_flag);
+                            // large vocabularies: one row at a time on the whole wave, values re-read in every pass, then the rows are rewritten
+                            RowStat q[4];
+                            for (int i = 0; i < 4; ++i) {
+                                const int rr = rb * 16 + wave * 4 + i, r = rr < R ? rr : R - 1;
+                                q[i] = row_stats(s_a + (wave * 4 + i) * lda, V, Vp, pa.mode, lane, ug == 0 && rr < R,
+                                                 pa.out_idx + (long long)r * S + (s - 1), pa.out_prob + (long long)r * S + (s - 1), pa.nan_flag);
+                            }
                             if (lane == 0) {
                                 for (int i = 0; i < 4; ++i) { s_m[wave * 4 + i] = q[i].m; s_sum[wave * 4 + i] = q[i].sum; s_nan0[wave * 4 + i] = q[i].nan0; }
                             }
