@@ -7,7 +7,8 @@
 //   LSTM  one tile = (layer, row block, unit group): 16 rows x 16 units x 4 gates, wave g = gate g, one
 //         v_mfma_f32_16x16x4_f32 accumulator per wave over the FULL K range [x | ctx | h], then the cell (common.h) --
 //         gate pre-activations meet in LDS, h', c' go to the slot of the next step;
-//   ATT   four rows of a row block, one wave per row: attention_row (row_kernels.h), the same code the per-step kernel runs;
+//   ATT   four rows of a row block, one wave per row: the per-step kernel's functions (row_kernels.h); a wave keeps its row for
+//         the launch, carries the next window over in registers and requests the window's rows ahead of its query;
 //   PLAIN four 16x16 column tiles of the attention query h.W_a (for the NEXT step) or of the logits h.E^T.
 // The softmax is not a phase of its own: every layer-1 tile recomputes max / sum / argmax of its 16 rows from the logits
 // (a few KB) and turns logits into the fed-back distribution while it loads them as its A operand; the tile of unit group 0
@@ -397,6 +398,54 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
     if (g < pa.g_lstm + pa.g_att) {
         // ------------------------------------------------------------------ attention rows
         const int ga = g - pa.g_lstm;
+        // query -> attention -> context is the longer of the two chains between a step's top layer and the next one's (the other:
+        // logits -> layer 1), so what a row can do ahead of its query it does: a wave keeps its row from step to step (one task
+        // per workgroup), carries the NEXT step's window over from the weights it has just normalised (att_window_next: the sum
+        // that att_window reads back from memory, from registers) and requests the <= 11 rows of u and of the encoder outputs that
+        // window attends BEFORE it waits for the query.  Behind the wait: the query row (one round trip), tanh, sums, context.
+        if (NRB * 4 <= pa.g_att && W <= 256 && C <= 256) {
+            if (ga >= NRB * 4) return;
+            const int rb = ga >> 2;
+            const int r = rb * 16 + (ga & 3) * 4 + wave;
+            const bool live = r < R;
+            const int rc = live ? r : R - 1;
+            AttnArgs a = pa.att;
+            const int ln = a.line ? a.line[rc] : rc / a.rows_per_line;
+            const float* ub = a.u + (long long)ln * a.u_line;
+            const float* eb = a.enc + (long long)ln * a.enc_line;
+            const int T = a.T, W4 = W >> 2, C4 = C >> 2;
+            const int ju = lane < W4 ? lane : 0, jc = lane < C4 ? lane : 0;     // (lanes beyond a row's width read a valid address and use nothing)
+            AttWin w = att_window(a, rc, 0, lane);                              // from the initial alignment
+            for (int s = 0; s < S; ++s) {
+                float4 uu[MAXWIN], xx[MAXWIN];
+#pragma unroll
+                for (int i = 0; i < MAXWIN; ++i) {
+                    int sr = w.s_lo + i; sr = sr < T ? sr : T - 1; sr = sr < 0 ? 0 : sr;
+                    uu[i] = reinterpret_cast<const float4*>(ub + (long long)sr * a.u_time)[ju];
+                    xx[i] = reinterpret_cast<const float4*>(eb + (long long)sr * a.enc_time)[jc];
+                }
+                PROF_T(t0);
+                if (!wait_deps(Dep{counter(rb, D + 2), (unsigned)((s + 1) * NQ4)}, Dep{nullptr, 0}, Dep{nullptr, 0}, abort_w, &s_ok)) return;
+                PROF_T(t1);
+                PROF_ADD(16, t1, t0);
+                a.wq = pa.wq + (long long)s * RW;
+                a.ctx = pa.ctx + (long long)(s + 1) * R * C;
+                float e[MAXWIN];
+#pragma unroll
+                for (int i = 0; i < MAXWIN; ++i) e[i] = 0.0f;
+                if (live) {
+                    att_weights<true, MAXWIN>(a, r, s, lane, w, [&](int sr) { return RegRows{uu, sr - w.s_lo}; }, e);
+                    att_context<true, MAXWIN>(a, r, lane, w, [&](int sr) { return RegRows{xx, sr - w.s_lo}; }, e);
+                }
+                PROF_T(t2);
+                PROF_ADD(17, t2, t1);
+                publish(counter(rb, D));
+                PROF_T(t3);
+                PROF_ADD(18, t3, t2);
+                w = att_window_next(a, w, e, lane);
+            }
+            return;
+        }
         for (int s = 0; s < S; ++s) {
             for (int t = ga; t < NRB * 4; t += pa.g_att) {
                 const int rb = t >> 2, q = t & 3;

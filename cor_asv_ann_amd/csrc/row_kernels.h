@@ -43,12 +43,10 @@ constexpr int ATT_ROWS = 8;      // rows (waves) per workgroup: the N=8 hypothes
 // a workgroup can stage the attended rows between them (attention_line_kernel); attention_row chains them on global memory.
 struct AttWin { int s_lo, cnt; };
 
-// (1) t' = sum_s a_prev[s] * s + 1 and the window |t' - s| <= window_width (attention.py:553-567)
-__device__ __forceinline__ AttWin att_window(const AttnArgs& a, const int r, const int step, const int lane) {
+// (1) t' = sum_s a_prev[s] * s + 1 and the window |t' - s| <= window_width (attention.py:553-567).  acc = this lane's share of the
+// sum: a_prev[s] * s over s = lane, lane + 64, ... in ascending order, in float64.
+__device__ __forceinline__ AttWin att_window_of(const AttnArgs& a, const double acc) {
     const int T = a.T;
-    const float* ap = a.a_base + (a.prev ? (long long)a.prev[r] : (long long)step * a.R + r) * T;
-    double acc = 0.0;
-    for (int s = lane; s < T; s += 64) acc += (double)ap[s] * (double)s;
     const float tp = (float)(wave_sum_d(acc) + 1.0);
     const float win = (float)a.window;
     int s_lo = 0, s_hi = -1;                    // empty unless t' is a number
@@ -62,35 +60,66 @@ __device__ __forceinline__ AttWin att_window(const AttnArgs& a, const int r, con
     }
     return AttWin{s_lo, s_hi - s_lo + 1};       // cnt <= MAXWIN
 }
+__device__ __forceinline__ AttWin att_window(const AttnArgs& a, const int r, const int step, const int lane) {
+    const int T = a.T;
+    const float* ap = a.a_base + (a.prev ? (long long)a.prev[r] : (long long)step * a.R + r) * T;
+    double acc = 0.0;
+    for (int s = lane; s < T; s += 64) acc += (double)ap[s] * (double)s;
+    return att_window_of(a, acc);
+}
+// ... of the NEXT step, from the weights e[] that att_weights has just normalised over the window w: the alignment row it wrote
+// (e[i] at s_lo + i, zero elsewhere, NaN everywhere for an empty window) enters the sum from registers instead of from memory --
+// the same products in the same order (a wave that keeps its row from step to step: the persistent decoder).
+__device__ __forceinline__ AttWin att_window_next(const AttnArgs& a, const AttWin w, const float (&e)[MAXWIN], const int lane) {
+    const int T = a.T;
+    double acc = 0.0;
+    for (int s = lane; s < T; s += 64) {
+        float v = 0.0f;
+        if (w.cnt <= 0) v = __builtin_nanf("");
+#pragma unroll
+        for (int i = 0; i < MAXWIN; ++i)
+            if (i < w.cnt && s == w.s_lo + i) v = e[i];
+        acc += (double)v * (double)s;
+    }
+    return att_window_of(a, acc);
+}
+// A window's rows held in registers (this lane's float4 of each), in the place of the row pointers att_weights / att_context index:
+// urow(s_lo + i)[j] -> the register of window position i.
+struct RegRows {
+    const float4* regs; int i;
+    __device__ __forceinline__ float4 operator[](int) const { return regs[i]; }
+};
 
 // (2) energies exp(tanh(wq + u[s]) . v_a + b_v) over the window, normalised; writes the alignment row and the per-row
 // by-products.  urow(s) -> the row u[line][s] as float4s (global memory, or the workgroup's staged copy).
 // HANDOFF: the query row was written by another workgroup of the same launch (read past the L2).
 // WB = window rows requested together (MAXWIN: all of them, fewest round trips; less: fewer registers, more waves per SIMD).
 // The sums per window position are independent of one another: the same values either way.
-template <bool HANDOFF, int WB, class URow>
-__device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, const int step, const int lane, const AttWin w,
-                                            URow urow, float (&e)[MAXWIN]) {
-    const int T = a.T, W = a.W;
-    const int s_lo = w.s_lo, cnt = w.cnt;
-    float* aout = const_cast<float*>(a.a_base) + ((long long)(step + 1) * a.R + r) * T;
+// In two halves, so that several waves can share the positions of one row (persist.hip): att_energy_sums leaves in e[i], for the
+// window positions i that sel(i) picks, tanh(wq + u[s_lo + i]) . v_a summed over the row (every lane holds the sum; the other
+// positions keep what they held); att_normalise turns the eleven sums into the row's weights and -- `write` -- stores the alignment
+// row and the by-products.  att_weights = the two in a row over all positions.
+template <bool HANDOFF, int WB, class URow, class Sel>
+__device__ __forceinline__ void att_energy_sums(const AttnArgs& a, const int r, const int lane, const AttWin w, URow urow, Sel sel,
+                                                float (&e)[MAXWIN]) {
+    const int W = a.W;
+    const int s_lo = w.s_lo;
     const float4* wq4 = reinterpret_cast<const float4*>(a.wq + (long long)r * W);
     const float4* va4 = reinterpret_cast<const float4*>(a.va);
-    const float bv = a.bv[0];
     const int W4 = W >> 2;
     // The kernel is latency-bound (one decoder row per wave slot), so all window rows are requested
     // together: loads are unconditional on clamped row indices, positions past the window get weight 0.
 #pragma unroll
-    for (int i = 0; i < MAXWIN; ++i) e[i] = 0.0f;
+    for (int i = 0; i < MAXWIN; ++i) if (sel(i)) e[i] = 0.0f;
 #pragma unroll
     for (int i0 = 0; i0 < MAXWIN; i0 += WB) {
         for (int j = lane; j < W4; j += 64) {
             const float4 q = HANDOFF ? load_sc1(reinterpret_cast<const float*>(wq4 + j)) : wq4[j], v = va4[j];
             float4 uu[WB];
 #pragma unroll
-            for (int i = 0; i < WB; ++i) if (i0 + i < MAXWIN) uu[i] = urow(s_lo + i0 + i)[j];
+            for (int i = 0; i < WB; ++i) if (i0 + i < MAXWIN && sel(i0 + i)) uu[i] = urow(s_lo + i0 + i)[j];
 #pragma unroll
-            for (int i = 0; i < WB; ++i) if (i0 + i < MAXWIN) {
+            for (int i = 0; i < WB; ++i) if (i0 + i < MAXWIN && sel(i0 + i)) {
                 e[i0 + i] += fast_tanh(q.x + uu[i].x) * v.x;
                 e[i0 + i] += fast_tanh(q.y + uu[i].y) * v.y;
                 e[i0 + i] += fast_tanh(q.z + uu[i].z) * v.z;
@@ -99,10 +128,19 @@ __device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, cons
         }
         if (WB < MAXWIN) __builtin_amdgcn_sched_barrier(0);            // keep the batches apart: that is where the registers go
     }
+#pragma unroll
+    for (int i = 0; i < MAXWIN; ++i) if (sel(i)) e[i] = wave_sum(e[i]);
+}
+__device__ __forceinline__ void att_normalise(const AttnArgs& a, const int r, const int step, const int lane, const AttWin w,
+                                              float (&e)[MAXWIN], const bool write = true) {
+    const int T = a.T;
+    const int s_lo = w.s_lo, cnt = w.cnt;
+    float* aout = const_cast<float*>(a.a_base) + ((long long)(step + 1) * a.R + r) * T;
+    const float bv = a.bv[0];
     float denom = 0.0f;
 #pragma unroll
     for (int i = 0; i < MAXWIN; ++i) {
-        const float sc = wave_sum(e[i]) + bv;
+        const float sc = e[i] + bv;
         e[i] = i < cnt ? expf(sc) : 0.0f;
         denom += e[i];
     }
@@ -117,6 +155,7 @@ __device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, cons
             pos += (double)e[i] * (double)(s_lo + i);
         }
     }
+    if (!write) return;
     for (int s = lane; s < T; s += 64) {
         float v = 0.0f;
         if (cnt <= 0) v = nanv;                 // 0/0 everywhere, as in the reference
@@ -131,6 +170,12 @@ __device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, cons
         if (a.win_out) a.win_out[r] = cnt > 0 ? (s_lo | (cnt << 16)) : 0;
         if (a.win_store) a.win_store[(long long)(step + 1) * a.R + r] = cnt > 0 ? (s_lo | (cnt << 16)) : -1;
     }
+}
+template <bool HANDOFF, int WB, class URow>
+__device__ __forceinline__ void att_weights(const AttnArgs& a, const int r, const int step, const int lane, const AttWin w,
+                                            URow urow, float (&e)[MAXWIN]) {
+    att_energy_sums<HANDOFF, WB>(a, r, lane, w, urow, [](int) { return true; }, e);
+    att_normalise(a, r, step, lane, w, e);
 }
 
 // (3) context = sum_s a'[s] * enc[s].  erow(s) -> the row enc[line][s] as float4s.  HANDOFF: the context vector goes out

@@ -166,6 +166,29 @@ __global__ __launch_bounds__(256, 1) void train_attention_cell_kernel(const TopR
         CASV_TOP_STAGE(g1, 12, HALF) CASV_TOP_STAGE(g0, 13, HALF) CASV_TOP_STAGE(g1, 14, HALF) CASV_TOP_STAGE(g0, 15, HALF) \
     }
 
+    // Part A's rows.  A wave keeps its row for the whole sequence, so what the row can do ahead of its query it does (as in the
+    // persistent decoder, persist.hip): the NEXT step's window is carried over from the weights just normalised (att_window_next:
+    // the sum att_window reads back from memory, from registers), and the <= 11 rows of u and of the encoder outputs that window
+    // attends are requested while the workgroup waits for the query.  At 16 unit groups a workgroup has two rows and four waves:
+    // two waves share a row, each the tanh terms of half its columns -- wave 1 continues the per-lane sums of wave 0 in the
+    // per-step kernel's order (column j = lane, then lane + 64), so the bits are attention_row's.
+    constexpr int RPW = TBM / NT;                                  // rows of the row block per workgroup
+    constexpr int WPR = RPW == 2 ? 2 : 1;                          // waves per row
+    constexpr bool FAST_A = RPW * WPR == 4 && W / 4 == 64 * WPR;   // 16 unit groups: 2 rows x 2 waves, 128 float4 columns; 8: 4 rows x 1 wave, 64
+    const int a_i = WPR == 2 ? (wave & 1) : wave, a_half = WPR == 2 ? (wave >> 1) : 0;
+    const int a_r = m0 + ug * RPW + a_i;
+    const bool a_live = FAST_A && a_r < B;
+    const int a_rc = a_r < B ? a_r : B - 1;
+    AttWin a_w{0, 0};
+    const float* a_ub = nullptr; const float* a_eb = nullptr;
+    if constexpr (FAST_A) {
+        const AttnArgs& a0 = ra.att;
+        a_w = att_window(a0, a_rc, 0, lane);
+        const int ln = a0.line ? a0.line[a_rc] : a_rc / a0.rows_per_line;
+        a_ub = a0.u + (long long)ln * a0.u_line;
+        a_eb = a0.enc + (long long)ln * a0.enc_line;
+    }
+
     for (int t = 0; t < U; ++t) {
         float* const rec = ra.RecIn + (long long)t * B * KR;            // the cell's input rows of this step: [ctx | h(t-1)]
         // x.Wx + b of this step's elements
@@ -203,10 +226,87 @@ __global__ __launch_bounds__(256, 1) void train_attention_cell_kernel(const TopR
         }
         publish(cnt_q);
 
-        // =========== A: attention rows m0 + 2 ug, + 1 (waves 0 and 1) ===========
+        // =========== A: attention rows m0 + RPW ug ... ===========
+        float4 uu[MAXWIN], xx[MAXWIN];
+        if constexpr (FAST_A) {         // the window's rows: on their way while the workgroup waits for the row block's query
+            const int Ta = ra.att.T;
+#pragma unroll
+            for (int i = 0; i < MAXWIN; ++i) {
+                int sr = a_w.s_lo + i; sr = sr < Ta ? sr : Ta - 1; sr = sr < 0 ? 0 : sr;
+                uu[i] = reinterpret_cast<const float4*>(a_ub + (long long)sr * ra.att.u_time)[lane + 64 * a_half];
+                xx[i] = reinterpret_cast<const float4*>(a_eb + (long long)sr * ra.att.enc_time)[lane + 64 * a_half];
+            }
+        }
         if (!wait_deps(Dep{cnt_q, (unsigned)(NT * (t + 1))}, Dep{nullptr, 0}, Dep{nullptr, 0}, abort_w, &s_ok)) return;
-        {
-            constexpr int RPW = TBM / NT;                              // rows of the row block per workgroup (2 at 16 unit groups)
+        if constexpr (FAST_A) {
+            AttnArgs a = ra.att;
+            a.wq = ra.WQ + (long long)t * B * W;
+            a.ctx = rec; a.ctx_ld = KR;
+            a.step_imm = t; a.step_ptr = nullptr;
+            a.win_out = ra.WIN + (long long)t * B;
+            float e[MAXWIN];
+#pragma unroll
+            for (int i = 0; i < MAXWIN; ++i) e[i] = 0.0f;
+            if constexpr (WPR == 1) {
+                if (a_live) {
+                    att_energy_sums<true, MAXWIN>(a, a_r, lane, a_w, [&](int sr) { return RegRows{uu, sr - a_w.s_lo}; }, [](int) { return true; }, e);
+                    att_normalise(a, a_r, t, lane, a_w, e);
+                    att_context<true, MAXWIN>(a, a_r, lane, a_w, [&](int sr) { return RegRows{xx, sr - a_w.s_lo}; }, e);
+                }
+            } else {
+                float (*s_part)[MAXWIN][64] = reinterpret_cast<float (*)[MAXWIN][64]>(s_stage);      // [row][position][lane]: wave 0's sums
+                float* s_sum = s_stage + RPW * MAXWIN * 64;                                           // [row][MAXWIN + 1]: the row's sums
+                const int j = lane + 64 * a_half;
+                const float4 q = load_sc1(a.wq + (long long)a_rc * W + 4 * j);
+                const float4 v = reinterpret_cast<const float4*>(a.va)[j];
+                float p[MAXWIN];
+                if (a_half == 0) {
+#pragma unroll
+                    for (int i = 0; i < MAXWIN; ++i) {
+                        p[i] = 0.0f;
+                        p[i] += fast_tanh(q.x + uu[i].x) * v.x;
+                        p[i] += fast_tanh(q.y + uu[i].y) * v.y;
+                        p[i] += fast_tanh(q.z + uu[i].z) * v.z;
+                        p[i] += fast_tanh(q.w + uu[i].w) * v.w;
+                        s_part[a_i][i][lane] = p[i];
+                    }
+                } else {        // the tanh values first: they do not wait for wave 0
+#pragma unroll
+                    for (int i = 0; i < MAXWIN; ++i) {
+                        uu[i].x = fast_tanh(q.x + uu[i].x); uu[i].y = fast_tanh(q.y + uu[i].y);
+                        uu[i].z = fast_tanh(q.z + uu[i].z); uu[i].w = fast_tanh(q.w + uu[i].w);
+                    }
+                }
+                __syncthreads();
+                if (a_half == 1) {
+#pragma unroll
+                    for (int i = 0; i < MAXWIN; ++i) {
+                        p[i] = s_part[a_i][i][lane];
+                        p[i] += uu[i].x * v.x;
+                        p[i] += uu[i].y * v.y;
+                        p[i] += uu[i].z * v.z;
+                        p[i] += uu[i].w * v.w;
+                        p[i] = wave_sum(p[i]);
+                    }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < MAXWIN; ++i) s_sum[a_i * (MAXWIN + 1) + i] = p[i];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < MAXWIN; ++i) e[i] = s_sum[a_i * (MAXWIN + 1) + i];
+                if (a_live) {
+                    att_normalise(a, a_r, t, lane, a_w, e, a_half == 1);
+                    AttnArgs a2 = a;                        // this wave's half of the context columns
+                    a2.C = C / 2; a2.ctx = a.ctx + a_half * (C / 2);
+                    if (a.ctx_mask) a2.ctx_mask = a.ctx_mask + a_half * (C / 2);
+                    att_context<true, MAXWIN>(a2, a_r, lane, a_w, [&](int sr) { return RegRows{xx, sr - a_w.s_lo}; }, e);
+                }
+            }
+            publish(cnt_c);
+            a_w = att_window_next(ra.att, a_w, e, lane);
+        } else {
             for (int i = wave; i < RPW; i += 4) {
                 const int r = m0 + ug * RPW + i;
                 if (r < B) {
@@ -218,8 +318,8 @@ __global__ __launch_bounds__(256, 1) void train_attention_cell_kernel(const TopR
                     attention_row<true, 6>(a, r, t, lane);
                 }
             }
+            publish(cnt_c);
         }
-        publish(cnt_c);
 
         // =========== C: ctx(t) . Wr_c on top, then the cell ===========
         {
