@@ -852,8 +852,9 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S) {
     if (per_cu < 1) return fail(CASV_ERR_ARG, "persistent decoder: rows of %d floats do not fit the LDS", kmax);
     const int wgslots = m->ncu * per_cu;
     pa.g_lstm = std::min(nrb * nug, wgslots * 4 / 8);
-    pa.g_att = std::min(nrb * 4, std::max(wgslots / 8, 4));
     pa.g_plain = std::min(nrb * (nq4 + nl4), std::max(wgslots * 2 / 8, 4));
+    // (attention: one workgroup per four rows where the slots the other roles leave allow it -- a wave then keeps its row, persist.hip)
+    pa.g_att = std::min(nrb * 4, std::max(std::max(wgslots / 8, 4), wgslots - pa.g_lstm - pa.g_plain));
 #ifdef CASV_PERSIST_PROF
     static DevBuf profbuf;
     if (int rc = profbuf.ensure((32 + 2048) * 8)) return rc;

@@ -22,7 +22,9 @@ def _engine(cfg, weights):
 
 
 @pytest.mark.parametrize('d,W,V,B,L,es', [(1, 32, 24, 3, 9, 8.0), (2, 64, 96, 16, 14, 12.0), (2, 256, 256, 40, 30, 64.0),
-                                          (3, 96, 100, 21, 12, 10.0), (4, 128, 257, 70, 10, 24.0), (2, 32, 640, 5, 6, 10.0)])
+                                          (3, 96, 100, 21, 12, 10.0), (4, 128, 257, 70, 10, 24.0), (2, 32, 640, 5, 6, 10.0),
+                                          # more than 256 lines: the attention rows' workgroups take the slots the other roles leave
+                                          (2, 64, 50, 300, 8, 6.0)])
 def test_persistent_equals_per_step_kernels_bit_for_bit(d, W, V, B, L, es):
     """Characters, probabilities, lengths and every alignment row: identical bits on both paths, in both greedy modes
     (mode 1 = per-line greedy with the NaN write-back; it may raise on both paths alike)."""
