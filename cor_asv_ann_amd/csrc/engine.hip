@@ -880,7 +880,7 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S) {
         unsigned long long h[32];
         HIPCHK(hipMemcpyAsync(h, profbuf.p, sizeof h, hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
-        const char* names[4] = {"layer1 (wait stats kloop cell publish)", "upper  (wait - kloop cell publish)", "att    (wait row publish)", "plain  (wait kloop publish)"};
+        const char* names[4] = {"layer1 (wait stats kloop cell publish gap)", "upper  (wait - kloop cell publish gap)", "att    (wait row publish)", "plain  (wait kloop publish)"};
         if (getenv("CASV_PERSIST_PLACEMENT")) {
             const int grid = pa.g_lstm + pa.g_att + pa.g_plain;
             std::vector<unsigned long long> hw(grid);
@@ -899,7 +899,7 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S) {
         }
         for (int r = 0; r < 4; ++r) {
             fprintf(stderr, "persist prof %s us/step:", names[r]);
-            for (int k = 0; k < 5; ++k) fprintf(stderr, " %.2f", h[r * 8 + k] * 0.01 / S);
+            for (int k = 0; k < 6; ++k) fprintf(stderr, " %.2f", h[r * 8 + k] * 0.01 / S);
             fprintf(stderr, "\n");
         }
     }

@@ -286,6 +286,10 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
         // (a static s_setprio 1 / 3 for the tile waves -- ahead of the attention / plain workgroup that shares their SIMDs on 192 of the
         // 256 CUs -- measured in round 5: 8.25-8.30 ms per batch of configs[1] against 8.29-8.39 without, within the noise; not kept)
         const int NT = NRB * NUG;
+#ifdef CASV_PERSIST_PROF
+        unsigned long long prof_prev = wall_clock64();          // slot 5 / 13: from a task's publish to the next one's wait
+        const unsigned long long prof_begin = prof_prev;
+#endif
         for (int s = 0; s <= S; ++s) {
             for (int n = 1; n <= D; ++n) {
                 if (s == S && n > 1) break;
@@ -307,6 +311,9 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
                         if (s > 0) dh = Dep{counter(rb, n - 1), (unsigned)(s * NUG)};
                     }
                     PROF_T(t0);
+#ifdef CASV_PERSIST_PROF
+                    PROF_ADD((n == 1 ? 0 : 8) + 5, t0, prof_prev);
+#endif
                     if (!wait_deps(dx, dc, dh, abort_w, &s_ok)) return;
                     PROF_T(t1);
                     PROF_ADD((n == 1 ? 0 : 8) + 0, t1, t0);
@@ -390,6 +397,9 @@ __global__ __launch_bounds__(256, 2) void persist_decode_kernel(const PersistArg
                     publish(counter(rb, n - 1));
                     PROF_T(t5);
                     PROF_ADD((n == 1 ? 0 : 8) + 4, t5, t4);
+#ifdef CASV_PERSIST_PROF
+                    prof_prev = t5;
+#endif
                 }
             }
         }
