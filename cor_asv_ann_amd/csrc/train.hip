@@ -43,6 +43,9 @@ struct TrainState {
     DevBuf dcalt;                          // second dL/dc buffers of the fused backward steps (two layers)
     DevBuf rec_cnt; int rec_launches = 0, rec_checked = 0, rec_skip = 0, rec_penalty = 0;   // persistent recurrences: counters per launch, back-off
     const unsigned* rec_abort[16] = {nullptr};    // ... and where each launch leaves its "gave up" word
+    // The attention cell's backward recurrence as TWO launches side by side (train_persist_topb.hip, split_a): the second stream and
+    // the events that tie it into the step; split_off: a step gave up with the two launches in flight -- one launch from then on.
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool split_off = false; int split_launch = -1;
     int find(const std::string& n) const { for (size_t i = 0; i < tens.size(); ++i) if (tens[i].name == n) return (int)i; return -1; }
     float* W_(int i) { return tens[i].w.as<float>(); }
     float* G_(int i) { return tens[i].g.as<float>(); }
@@ -106,6 +109,7 @@ int casv_train_release(casv_model* m) {
     TrainState* ts = m->train;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
+    if (ts->side) { (void)hipStreamSynchronize(ts->side); (void)hipStreamDestroy(ts->side); (void)hipEventDestroy(ts->ev_fork); (void)hipEventDestroy(ts->ev_join); ts->side = nullptr; }
     for (auto& t : ts->tens) { t.w.release(); t.g.release(); t.m.release(); t.v.release(); }
     for (auto& l : ts->layers) { l.wxT.release(); l.wrT.release(); l.Hown.release(); l.Cs.release(); l.Gt.release(); l.Z.release(); l.dRec.release(); }
     DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
@@ -515,7 +519,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     HIPCHK(hipMemsetAsync(ts->loss.p, 0, 16, st));
     HIPCHK(hipMemsetAsync(ts->normsq.p, 0, 16, st));
     HIPCHK(hipMemsetAsync(ts->rec_cnt.p, 0, 16 * train_recurrence_bwd_counter_bytes(B), st));
-    ts->rec_launches = ts->rec_checked = 0;
+    ts->rec_launches = ts->rec_checked = 0; ts->split_launch = -1;
     if (ts->rec_skip > 0) --ts->rec_skip;
     if (training) for (auto& t : ts->tens) HIPCHK(hipMemsetAsync(t.g.p, 0, t.n * 4, st));
 
@@ -620,7 +624,10 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         for (int i = ts->rec_checked; i < ts->rec_launches; ++i)
             HIPCHK(hipMemcpyAsync(&gave_up[i], ts->rec_abort[i], 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        for (int i = ts->rec_checked; i < ts->rec_launches; ++i) any |= gave_up[i] != 0;
+        for (int i = ts->rec_checked; i < ts->rec_launches; ++i) {
+            any |= gave_up[i] != 0;
+            if (gave_up[i] && i == ts->split_launch) ts->split_off = true;      // (the two launches were not resident together: one launch from now on)
+        }
         ts->rec_checked = ts->rec_launches;
         if (any) {
             ts->rec_penalty = ts->rec_penalty ? std::min(2 * ts->rec_penalty, 1 << 20) : 16;
@@ -687,7 +694,24 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             if (const int grid = train_attention_cell_bwd_grid(ra, m->ncu)) {
                 hipEvent_t ev{};
                 m->prof_begin(PC_PERSIST, 2.0 * B * U * ((double)4 * W * (C + W) + (double)W * W), 0.0, ev);
+                // the attention backward of the samples as a launch of its own on a second stream, resident beside the big one: it
+                // then runs under the h tiles instead of behind them (CASV_TOPB_SPLIT=0: one launch)
+                static const bool split_opt = [] { const char* e = getenv("CASV_TOPB_SPLIT"); return !(e && e[0] == '0'); }();
+                ra.split_a = split_opt && !ts->split_off && train_attention_cell_bwd_rows_fit(ra) ? 1 : 0;
+                if (ra.split_a && !ts->side) {
+                    HIPCHK(hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking));
+                    HIPCHK(hipEventCreateWithFlags(&ts->ev_fork, hipEventDisableTiming));
+                    HIPCHK(hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming));
+                }
+                if (ra.split_a) {
+                    HIPCHK(hipEventRecord(ts->ev_fork, st));
+                    HIPCHK(hipStreamWaitEvent(ts->side, ts->ev_fork, 0));
+                    launch_train_attention_cell_bwd_rows(ra, grid, ts->side);
+                    HIPCHK(hipEventRecord(ts->ev_join, ts->side));
+                    ts->split_launch = ts->rec_launches;
+                }
                 launch_train_attention_cell_bwd(ra, grid, st);
+                if (ra.split_a) HIPCHK(hipStreamWaitEvent(st, ts->ev_join, 0));
                 if (defer) {
                     AttnDeferArgs da{};
                     da.dRec = ra.dRec; da.ld_drec = kr; da.mcell = mcell; da.ld_mcell = W + C; da.mc_off = W;

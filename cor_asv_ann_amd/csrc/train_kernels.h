@@ -130,10 +130,15 @@ struct TopBwdArgs {
     AttnBwdArgs ab;              // mask, v_a, u, enc, d_enc, du, dva / dbv partial sums, sizes (dxh / a / win / wq / dwq are set per step)
     int B, U, W, C;
     unsigned* counters;
+    int split_a;                 // part A (the attention backward of the row block's samples) runs as a launch of its own beside this one
 };
 size_t train_attention_cell_bwd_counter_bytes(int B);
 int train_attention_cell_bwd_grid(const TopBwdArgs& ra, int ncu);
 void launch_train_attention_cell_bwd(const TopBwdArgs& ra, int grid, hipStream_t stream);
+// ... part A as its own launch (same grid, same counters), to be resident TOGETHER with the launch above (split_a = 1) on another
+// stream: the two hand rows to each other as the parts of one launch do.  _fits: both fit a CU at once on this device.
+bool train_attention_cell_bwd_rows_fit(const TopBwdArgs& ra);
+void launch_train_attention_cell_bwd_rows(const TopBwdArgs& ra, int grid, hipStream_t stream);
 
 void launch_axpy(float* y, const float* x, long long n, hipStream_t st);
 void launch_colsum(const float* in, long long rows, int cols, long long ld, float* out, hipStream_t st);

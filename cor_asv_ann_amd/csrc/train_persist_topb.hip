@@ -265,6 +265,9 @@ __global__ __launch_bounds__(256, 1) void train_attention_cell_bwd_kernel(const 
         }
 
         // =========== A: attention backward of samples m0 + 2 slot (+ 1), half a workgroup each ===========
+        // (split_a: the workgroups of train_attention_cell_bwd_rows_kernel do it meanwhile, on the CU's other slot -- part A needs
+        // the ctx tiles only, the h tile above and part A then overlap instead of following each other)
+        if (!ra.split_a) {
         if (!wait_deps(Dep{c_cnt, (unsigned)(NT * (i + 1))}, Dep{nullptr, 0}, Dep{nullptr, 0}, abort_w, &s_ok)) return;
         {
             constexpr int SPW = VBM / NT;                    // samples of the row block per workgroup (2 at 16 slots)
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(256, 1) void train_attention_cell_bwd_kernel(const 
             }
         }
         publish(q_cnt);
+        }
 
         // =========== Q: my 32 columns of dhatt(t) = dwq(t) . W_a ===========
         {
@@ -341,6 +345,164 @@ __global__ __launch_bounds__(256, 1) void train_attention_cell_bwd_kernel(const 
     if (row_ok) *reinterpret_cast<f32x4*>(ra.dc_out + (long long)mrow * W + u0) = dc;
 }
 
+// Part A of the kernel above as a launch of its own (TopBwdArgs.split_a): same grid, same roles by workgroup index, same counters.
+// Its workgroups wait for their row block's ctx tiles, work the attention backward of their samples and publish the dwq rows; the
+// big kernel's workgroups go from their h tile straight to the wait for those rows.  Few registers, 9 KB of LDS: a workgroup of
+// this kernel fits beside one of the big kernel on every CU.
+template <int NT>
+__global__ __launch_bounds__(256, 3) void train_attention_cell_bwd_rows_kernel(const TopBwdArgs ra) {
+    __shared__ __attribute__((aligned(16))) float s_scr[2 * 1024 + 2 * 64];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    constexpr int W = NT * 32, C = W, KR = C + W;
+    const int B = ra.B, U = ra.U;
+    const int nrb = (B + VBM - 1) / VBM;
+    const int slot = blockIdx.x % NT, rb = blockIdx.x / NT;
+    const int m0 = rb * VBM;
+    unsigned* const cbase = ra.counters + (long long)rb * 12 * 32;
+    unsigned* const abort_w = ra.counters + (long long)nrb * 12 * 32;
+    unsigned* const c_cnt = cbase + 4 * 32;
+    unsigned* const q_cnt = cbase + 9 * 32;
+    constexpr int SPW = VBM / NT;                    // samples of the row block per workgroup (2 at 16 slots)
+    constexpr int GROUPS = SPW >= 2 ? 2 : 1;         // groups working side by side
+    const int nthr = 256 / GROUPS, grp = tid / nthr, gtid = tid % nthr;
+    float* s_dx = s_scr + grp * 1024;
+    float* s_da = s_scr + 2048 + grp * 64; float* s_ds = s_da + 16; float* s_av = s_da + 32;
+    if constexpr (SPW == GROUPS) {
+        // One sample per half workgroup and step (16 slots per row block).  Everything the forward pass kept -- the window, the
+        // alignment values, the window's rows of the encoder outputs, the query, the rows of u -- is requested, and every tanh
+        // taken, BEFORE the wait for the step's dL/dctx (this kernel's workgroups have nothing else to do meanwhile); behind the
+        // wait: the dL/dctx row, eleven dot products, the score gradients, dwq from the tanh values in registers -- and the signal.
+        // What nobody waits for inside the recurrence (du / d_enc atomics, the dva / dbv sums, the kept score gradients) follows
+        // the signal.  The arithmetic is attention_bwd_sample's, sum for sum.
+        constexpr int NTHR = 256 / GROUPS, NWV = NTHR / 64, NP = (MAXWIN + NWV - 1) / NWV, NE = C / 64, NJ = W / NTHR, NC = C / NTHR;
+        const int lane = gtid & 63, gw = gtid >> 6;
+        const int b = m0 + slot * SPW + grp;
+        const bool active = b < B;
+        const int bc = active ? b : B - 1;
+        const AttnBwdArgs& ab = ra.ab;
+        const int T = ab.T, defer = ra.defer;
+        for (int i = 0; i < U; ++i) {
+            const int t = U - 1 - i;
+            // ---- ahead of the wait
+            const int wv = ra.WIN[(long long)t * B + bc];
+            const int s_lo = wv & 0xffff, cnt = wv >> 16;
+            const float av = (gtid < 16 && gtid < cnt) ? ra.Ast[((long long)(t + 1) * B + bc) * T + s_lo + gtid] : 0.0f;
+            float encv[NP][NE];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int pi = gw + k * NWV;
+                const float* es = ab.enc + (long long)bc * ab.enc_line + (long long)(s_lo + (pi < cnt ? pi : 0)) * ab.enc_time;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) encv[k][e] = es[lane + 64 * e];
+            }
+            float mcv[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) mcv[k] = ab.mcell ? ab.mcell[(long long)bc * ab.ld_mcell + ab.mc_off + gtid + NTHR * k] : 1.0f;
+            float th[NJ][MAXWIN], vv[NJ];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = gtid + NTHR * jj;
+                const float q = ra.WQ[((long long)t * B + bc) * W + j];
+                vv[jj] = ab.va[j];
+                const long long off0 = (long long)bc * ab.u_line + (long long)s_lo * ab.u_time + j;
+                float uu[MAXWIN];
+#pragma unroll
+                for (int k = 0; k < MAXWIN; ++k) uu[k] = ab.u[off0 + (long long)(k < cnt ? k : 0) * ab.u_time];
+#pragma unroll
+                for (int k = 0; k < MAXWIN; ++k) th[jj][k] = fast_tanh(q + uu[k]);
+            }
+            if (!wait_deps(Dep{c_cnt, (unsigned)(NT * (i + 1))}, Dep{nullptr, 0}, Dep{nullptr, 0}, abort_w, &s_ok)) return;
+            // ---- behind it
+            const float* dx = ra.dRec + ((long long)t * B + bc) * KR;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int c = gtid + NTHR * k;
+                s_dx[c] = __hip_atomic_load(dx + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * mcv[k];
+            }
+            if (gtid < 16) s_av[gtid] = av;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {          // da_s = dctx . enc_s
+                const int pi = gw + k * NWV;
+                if (pi < cnt) {
+                    float part = 0.f;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) part += s_dx[lane + 64 * e] * encv[k][e];
+                    part = wave_sum(part);
+                    if (lane == 0) s_da[pi] = part;
+                }
+            }
+            __syncthreads();
+            if (gtid < 16) {
+                float dot = 0.f;
+                for (int k = 0; k < cnt; ++k) dot += s_av[k] * s_da[k];
+                s_ds[gtid] = gtid < cnt ? s_av[gtid] * (s_da[gtid] - dot) : 0.0f;          // dL/dscore
+            }
+            __syncthreads();
+            float dvas[NJ];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                float dwq = 0.f, dva = 0.f;
+#pragma unroll
+                for (int k = 0; k < MAXWIN; ++k) {
+                    const float ds = s_ds[k];
+                    dva += ds * th[jj][k];
+                    dwq += ds * vv[jj] * (1.0f - th[jj][k] * th[jj][k]);
+                }
+                dvas[jj] = dva;
+                if (active) store_sc1(ra.DWQ + ((long long)t * B + b) * W + gtid + NTHR * jj, dwq);
+            }
+            publish(q_cnt);
+            // ---- behind the signal
+            if (active) {
+                if (defer && gtid < 16) ra.DS[((long long)t * B + b) * 16 + gtid] = s_ds[gtid];
+                if (!(defer & 1)) {                 // d enc_out[s] += a_s * dctx
+                    float* de = ab.d_enc + (long long)b * ab.enc_line + (long long)s_lo * ab.enc_time;
+                    for (int k = 0; k < cnt; ++k) {
+                        const float a_k = s_av[k];
+                        for (int c = gtid; c < C; c += NTHR) atomicAdd(de + (long long)k * ab.enc_time + c, a_k * s_dx[c]);
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int j = gtid + NTHR * jj;
+                    if (!(defer & 2)) {
+                        const long long off0 = (long long)b * ab.u_line + (long long)s_lo * ab.u_time + j;
+#pragma unroll
+                        for (int k = 0; k < MAXWIN; ++k)
+                            if (k < cnt) atomicAdd(ab.du + off0 + (long long)k * ab.u_time, s_ds[k] * vv[jj] * (1.0f - th[jj][k] * th[jj][k]));
+                    }
+                    ab.dva_part[(long long)b * W + j] += dvas[jj];
+                }
+                if (gtid == 0) {
+                    float dbv = 0.f;
+                    for (int k = 0; k < cnt; ++k) dbv += s_ds[k];
+                    ab.dbv_part[b] += dbv;
+                }
+            }
+        }
+        return;
+    }
+    for (int i = 0; i < U; ++i) {
+        const int t = U - 1 - i;
+        if (!wait_deps(Dep{c_cnt, (unsigned)(NT * (i + 1))}, Dep{nullptr, 0}, Dep{nullptr, 0}, abort_w, &s_ok)) return;
+        AttnBwdArgs p = ra.ab;
+        p.dxh = ra.dRec + (long long)t * B * KR; p.ld_dxh = KR; p.ctx_off = 0;
+        p.a = ra.Ast + (long long)(t + 1) * B * ra.ab.T; p.win = ra.WIN + (long long)t * B;
+        p.wq = ra.WQ + (long long)t * B * W; p.dwq = ra.DWQ + (long long)t * B * W;
+        p.ds_out = ra.DS ? ra.DS + (long long)t * B * 16 : nullptr;
+        for (int s0 = 0; s0 < SPW; s0 += GROUPS) {
+            const int b = m0 + slot * SPW + s0 + grp;
+            if (ra.defer == 3) attention_bwd_sample<true, 3>(p, b < B ? b : B - 1, b < B && s0 + grp < SPW, gtid, nthr, s_dx, s_da, s_ds, s_av);
+            else if (ra.defer == 1) attention_bwd_sample<true, 1>(p, b < B ? b : B - 1, b < B && s0 + grp < SPW, gtid, nthr, s_dx, s_da, s_ds, s_av);
+            else attention_bwd_sample<true, 0>(p, b < B ? b : B - 1, b < B && s0 + grp < SPW, gtid, nthr, s_dx, s_da, s_ds, s_av);
+            __syncthreads();
+        }
+        publish(q_cnt);
+    }
+}
+
 template <class K>
 static int topb_blocks_per_cu(K kernel) {
     static std::mutex mu;
@@ -380,6 +542,44 @@ void launch_train_attention_cell_bwd(const TopBwdArgs& ra, int grid, hipStream_t
         case 4: hipLaunchKernelGGL((train_attention_cell_bwd_kernel<4>), dim3(grid), dim3(256), 0, stream, ra); break;
         case 8: hipLaunchKernelGGL((train_attention_cell_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, ra); break;
         case 16: hipLaunchKernelGGL((train_attention_cell_bwd_kernel<16>), dim3(grid), dim3(256), 0, stream, ra); break;
+        default: break;
+    }
+}
+
+// Both launches resident at once, a workgroup of each on every CU, in whatever order the hardware takes them from their streams:
+// the big kernel's registers admit one of its workgroups per CU; the small kernel asks for ROWS_LDS_PAD bytes of LDS it never touches,
+// so that two of ITS workgroups do not fit a CU either (2 x 93 KB > 160 KB) while one fits beside the big kernel's (46 + 93 KB) --
+// no CU can fill up with workgroups of one kind and lock the other kind out.  The runtime has no query for two kernels together:
+// what is checked is each one's appetite (per SIMD one wave of each within the 512 registers, the two LDS images within the CU's
+// LDS); if a device or a co-tenant proves it wrong the bounded waits give up and train.hip goes back to the single launch.
+constexpr int ROWS_LDS_PAD = 84 * 1024;
+template <int NT> static bool topb_rows_fit() {
+    static const bool ok = [] {
+        hipFuncAttributes a{}, b{};
+        const void* fa = reinterpret_cast<const void*>(train_attention_cell_bwd_kernel<NT>);
+        const void* fb = reinterpret_cast<const void*>(train_attention_cell_bwd_rows_kernel<NT>);
+        if (hipFuncGetAttributes(&a, fa) != hipSuccess || hipFuncGetAttributes(&b, fb) != hipSuccess) return false;
+        if (hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_PAD) != hipSuccess) return false;
+        // (numRegs counts the architectural registers; the big kernel also uses accumulation registers, 34-56 of them: 320 in all)
+        const int big = 320, rows = ((b.numRegs + 7) / 8) * 8;
+        const size_t lds_rows = b.sharedSizeBytes + ROWS_LDS_PAD;
+        return b.numRegs > 0 && big + rows <= 512 && a.sharedSizeBytes + lds_rows <= 160 * 1024 && 2 * lds_rows > 160 * 1024;
+    }();
+    return ok;
+}
+bool train_attention_cell_bwd_rows_fit(const TopBwdArgs& ra) {
+    switch (ra.W / 32) {
+        case 4: return topb_rows_fit<4>();
+        case 8: return topb_rows_fit<8>();
+        case 16: return topb_rows_fit<16>();
+        default: return false;
+    }
+}
+void launch_train_attention_cell_bwd_rows(const TopBwdArgs& ra, int grid, hipStream_t stream) {
+    switch (ra.W / 32) {
+        case 4: hipLaunchKernelGGL((train_attention_cell_bwd_rows_kernel<4>), dim3(grid), dim3(256), ROWS_LDS_PAD, stream, ra); break;
+        case 8: hipLaunchKernelGGL((train_attention_cell_bwd_rows_kernel<8>), dim3(grid), dim3(256), ROWS_LDS_PAD, stream, ra); break;
+        case 16: hipLaunchKernelGGL((train_attention_cell_bwd_rows_kernel<16>), dim3(grid), dim3(256), ROWS_LDS_PAD, stream, ra); break;
         default: break;
     }
 }
