@@ -828,15 +828,24 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     }
     // ---- regulariser, clip, update ----
     launch_reg(ts->W_(ts->iE), ts->G_(ts->iE), V, W, ts->loss.as<double>(), 1, st);
-    for (auto& t : ts->tens) if (!t.frozen) launch_sumsq(t.g.as<float>(), (long long)t.n, ts->normsq.as<double>(), st);
+    // (norm and update over all parameter tensors as one launch each; lists of MULTI_MAX tensors at a time)
+    auto over_tensors = [&](int max_blocks, auto&& launch) {
+        MultiTensor mt{};
+        for (auto& t : ts->tens) {
+            if (t.frozen) continue;
+            if (mt.count == MULTI_MAX) { launch(mt); mt = MultiTensor{}; }
+            multi_add(mt, t.w.as<float>(), t.g.as<float>(), t.m.as<float>(), t.v.as<float>(), (long long)t.n, max_blocks);
+        }
+        launch(mt);
+    };
+    over_tensors(1024, [&](const MultiTensor& mt) { launch_sumsq_multi(mt, ts->normsq.as<double>(), st); });
     if (mode == 1) {
         ts->step += 1;
         const double b1 = ts->ap.beta1, b2 = ts->ap.beta2;
         const float lr_t = (float)(ts->ap.lr * sqrt(1.0 - pow(b2, (double)ts->step)) / (1.0 - pow(b1, (double)ts->step)));
-        for (auto& t : ts->tens)
-            if (!t.frozen)
-                launch_adam(t.w.as<float>(), t.g.as<float>(), t.m.as<float>(), t.v.as<float>(), (long long)t.n, ts->normsq.as<double>(),
-                            ts->ap.clipnorm, lr_t, (float)b1, (float)b2, ts->ap.epsilon, st);
+        over_tensors(2048, [&](const MultiTensor& mt) {
+            launch_adam_multi(mt, ts->normsq.as<double>(), ts->ap.clipnorm, lr_t, (float)b1, (float)b2, ts->ap.epsilon, st);
+        });
         refresh_derived(m);
     }
     double nsq = 0.0;

@@ -144,6 +144,13 @@ void launch_axpy(float* y, const float* x, long long n, hipStream_t st);
 void launch_colsum(const float* in, long long rows, int cols, long long ld, float* out, hipStream_t st);
 void launch_reg(const float* E, float* dE, int V, int W, double* loss, int want_grad, hipStream_t st);
 void launch_sumsq(const float* g, long long n, double* acc, hipStream_t st);
+// ... over a list of tensors in ONE launch each (the train step has 30-odd parameter tensors: one launch per tensor is mostly
+// launch boundaries).  first_block[k] .. first_block[k + 1] are tensor k's workgroups of the launch.
+constexpr int MULTI_MAX = 48;
+struct MultiTensor { float* w[MULTI_MAX]; float* g[MULTI_MAX]; float* m[MULTI_MAX]; float* v[MULTI_MAX]; long long n[MULTI_MAX]; int first_block[MULTI_MAX + 1]; int count; };
+bool multi_add(MultiTensor& mt, float* w, float* g, float* m, float* v, long long n, int max_blocks);      // false: the list is full
+void launch_sumsq_multi(const MultiTensor& mt, double* acc, hipStream_t st);
+void launch_adam_multi(const MultiTensor& mt, const double* normsq, float clipnorm, float lr_t, float b1, float b2, float eps, hipStream_t st);
 void launch_adam(float* w, const float* g, float* m, float* v, long long n, const double* normsq, float clipnorm, float lr_t,
                  float b1, float b2, float eps, hipStream_t st);
 

@@ -386,4 +386,56 @@ void launch_adam(float* w, const float* g, float* m, float* v, long long n, cons
                        normsq, clipnorm, lr_t, b1, b2, eps);
 }
 
+// ---- the same over a list of tensors, one launch each ----
+bool multi_add(MultiTensor& mt, float* w, float* g, float* m, float* v, long long n, int max_blocks) {
+    if (mt.count >= MULTI_MAX || n < 1) return n < 1;
+    const int k = mt.count++;
+    mt.w[k] = w; mt.g[k] = g; mt.m[k] = m; mt.v[k] = v; mt.n[k] = n;
+    if (k == 0) mt.first_block[0] = 0;
+    mt.first_block[k + 1] = mt.first_block[k] + (int)std::min<long long>((n + 255) / 256, max_blocks);
+    return true;
+}
+__device__ __forceinline__ int multi_find(const MultiTensor& mt, const int block) {      // (uniform per workgroup: scalar code)
+    int k = 0;
+    while (k + 1 < mt.count && block >= mt.first_block[k + 1]) ++k;
+    return k;
+}
+__global__ void sumsq_multi_kernel(const MultiTensor mt, double* __restrict__ acc) {
+    __shared__ double red[256];
+    const int k = multi_find(mt, blockIdx.x);
+    const float* __restrict__ g = mt.g[k];
+    const long long n = mt.n[k], stride = (long long)(mt.first_block[k + 1] - mt.first_block[k]) * blockDim.x;
+    double s = 0.0;
+    for (long long i = (long long)(blockIdx.x - mt.first_block[k]) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = g[i]; s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+}
+void launch_sumsq_multi(const MultiTensor& mt, double* acc, hipStream_t st) {
+    if (mt.count < 1) return;
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3((unsigned)mt.first_block[mt.count]), dim3(256), 0, st, mt, acc);
+}
+__global__ void adam_multi_kernel(const MultiTensor mt, const double* __restrict__ normsq, float clipnorm, float lr_t, float b1, float b2,
+                                  float eps) {
+    const int k = multi_find(mt, blockIdx.x);
+    float* __restrict__ w = mt.w[k]; const float* __restrict__ g = mt.g[k]; float* __restrict__ m = mt.m[k]; float* __restrict__ v = mt.v[k];
+    const long long n = mt.n[k], stride = (long long)(mt.first_block[k + 1] - mt.first_block[k]) * blockDim.x;
+    const float norm = (float)sqrt(*normsq);
+    const float scale = (clipnorm > 0.f && norm >= clipnorm) ? clipnorm / norm : 1.0f;
+    for (long long i = (long long)(blockIdx.x - mt.first_block[k]) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * scale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+void launch_adam_multi(const MultiTensor& mt, const double* normsq, float clipnorm, float lr_t, float b1, float b2, float eps, hipStream_t st) {
+    if (mt.count < 1) return;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)mt.first_block[mt.count]), dim3(256), 0, st, mt, normsq, clipnorm, lr_t, b1, b2, eps);
+}
+
 }  // namespace casv
