@@ -109,7 +109,7 @@ int casv_train_release(casv_model* m) {
     TrainState* ts = m->train;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
-    if (ts->side) { (void)hipStreamSynchronize(ts->side); (void)hipStreamDestroy(ts->side); (void)hipEventDestroy(ts->ev_fork); (void)hipEventDestroy(ts->ev_join); ts->side = nullptr; }
+    if (ts->side) { (void)hipStreamSynchronize(ts->side); (void)hipStreamDestroy(ts->side); if (ts->ev_fork) (void)hipEventDestroy(ts->ev_fork); if (ts->ev_join) (void)hipEventDestroy(ts->ev_join); ts->side = nullptr; }
     for (auto& t : ts->tens) { t.w.release(); t.g.release(); t.m.release(); t.v.release(); }
     for (auto& l : ts->layers) { l.wxT.release(); l.wrT.release(); l.Hown.release(); l.Cs.release(); l.Gt.release(); l.Z.release(); l.dRec.release(); }
     DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
@@ -698,10 +698,14 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
                 // then runs under the h tiles instead of behind them (CASV_TOPB_SPLIT=0: one launch)
                 static const bool split_opt = [] { const char* e = getenv("CASV_TOPB_SPLIT"); return !(e && e[0] == '0'); }();
                 ra.split_a = split_opt && !ts->split_off && train_attention_cell_bwd_rows_fit(ra) ? 1 : 0;
-                if (ra.split_a && !ts->side) {
-                    HIPCHK(hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking));
-                    HIPCHK(hipEventCreateWithFlags(&ts->ev_fork, hipEventDisableTiming));
-                    HIPCHK(hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming));
+                if (ra.split_a && !ts->side) {          // (no second stream to be had: one launch, as before)
+                    if (hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ts->side = nullptr; }
+                    else if (hipEventCreateWithFlags(&ts->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                             hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming) != hipSuccess) {
+                        (void)hipGetLastError();
+                        (void)hipStreamDestroy(ts->side); ts->side = nullptr;
+                    }
+                    if (!ts->side) { ts->split_off = true; ra.split_a = 0; }
                 }
                 if (ra.split_a) {
                     HIPCHK(hipEventRecord(ts->ev_fork, st));

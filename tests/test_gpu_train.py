@@ -1,5 +1,8 @@
 """Train step (kt:195 train_on_batch / kt:407 test_on_batch) on the device against the oracle, and the
 facade's train() end to end on a small copy task."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -421,6 +424,47 @@ def test_persistent_recurrences_under_uneven_load():
     finally:
         stop.append(1)
         th.join()
+
+
+_ONE_STEP = '''
+import sys, json
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import ModelConfig, make_weights, make_lines
+from cor_asv_ann_amd.engine import HipEngine
+d, W, V, B, L = 2, 512, 40, 70, 9
+cfg = ModelConfig(depth=d, width=W, voc_size=V)
+w = make_weights(cfg, seed=5, emb_scale=4.0)
+_, sidx = make_lines(B, L, 21, voc_size=V)
+_, tidx = make_lines(B, L, 22, voc_size=V)
+U = L + 2
+dec_in = np.full((B, U), -1, np.int32); dec_out = np.full((B, U), -1, np.int32)
+dec_in[:, 1:L + 2] = tidx; dec_out[:, :L + 1] = tidx
+wts = (dec_out >= 0).astype(np.float32)
+eng = HipEngine(d, W, V); eng.set_weights(w); eng.train_begin()
+out = [eng.train_step(sidx, None, dec_in, dec_out, wts, None, mode=2) for _ in range(2)]
+eng.train_end(); eng.close()
+print(json.dumps(out))
+'''
+
+
+def test_attention_backward_beside_the_recurrence_or_inside_it():
+    """The attention cell's backward recurrence runs as two launches side by side (the recurrence and, on a second stream, the
+    attention backward of its samples: train_persist_topb.hip, split_a) -- or, after a give-up or with CASV_TOPB_SPLIT=0, as the one
+    launch it was: the same loss and gradient norm either way (sums in the same order; the float atomics of d_enc / du may differ in
+    the last bits of the norm)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for split in ('1', '0'):
+        env = dict(os.environ, CASV_TOPB_SPLIT=split)
+        out = subprocess.run([sys.executable, '-c', _ONE_STEP % root], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[split] = json.loads(out.stdout.strip().splitlines()[-1])
+    for (l1, n1), (l0, n0) in zip(res['1'], res['0']):
+        assert np.isfinite(l1) and abs(l1 - l0) < 1e-8 * abs(l0), (l1, l0)
+        assert abs(n1 - n0) < 2e-5 * n0, (n1, n0)
 
 
 def test_two_train_sessions_share_the_gpu(capfd):
