@@ -421,8 +421,11 @@ static int layers_backward(casv_model* m, const LayerBwd* a, int count) {
 
 // Forward recurrence of up to two independent plain layers: ONE persistent launch (train_persist.hip) where the shape has
 // one and the device is ours, else one launch per step for both (the two are interchangeable bit for bit).
-struct LayerFwd { TLayer* l; const float* h0; const float* c0; };
-static int layers_forward(casv_model* m, const LayerFwd* a, int count) {
+// om / om_ld / omask: the layer's outputs once more, times the next layer's per-unit dropout mask (nullptr: times one) -- written by
+// the persistent recurrence itself; *masked tells the caller whether it was (the per-step launches leave it to launch_mul_mask).
+struct LayerFwd { TLayer* l; const float* h0; const float* c0; float* om = nullptr; long long om_ld = 0; const float* omask = nullptr; };
+static int layers_forward(casv_model* m, const LayerFwd* a, int count, bool* masked = nullptr) {
+    if (masked) *masked = false;
     TrainState* ts = m->train;
     const int W = m->W, B = ts->B;
     int maxlen = 0;
@@ -433,7 +436,7 @@ static int layers_forward(casv_model* m, const LayerFwd* a, int count) {
         for (int j = 0; j < count; ++j) {
             TLayer& l = *a[j].l;
             ra.job[j] = RecJob{ts->W_(l.iwr), l.Z.as<float>(), l.hs, l.hs_ld, l.Cs.as<float>(), l.Gt.as<float>(), a[j].h0, a[j].c0, l.len,
-                               l.reverse ? 1 : 0};
+                               l.reverse ? 1 : 0, masked ? a[j].om : nullptr, a[j].om_ld, a[j].omask};
         }
         const size_t cb = train_recurrence_bwd_counter_bytes(B);        // (one slot size for both kinds of launch)
         ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
@@ -446,6 +449,7 @@ static int layers_forward(casv_model* m, const LayerFwd* a, int count) {
             launch_train_recurrence(ra, grid, m->stream);
             m->prof_end(PC_PERSIST, ev);
             ts->rec_abort[ts->rec_launches++] = ra.counters + (train_recurrence_counter_bytes(B) / sizeof(unsigned) - 32);
+            if (masked) *masked = true;
             return 0;
         }
     }
@@ -535,11 +539,16 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     launch_embed_tm(ts->W_(ts->iE), ts->e_idx.as<int>(), enc_val ? ts->e_val.as<float>() : nullptr, ts->X0.as<float>(), B, T, A, V, W, st);
     layer_input_gemm(m, *Lfw, ts->X0.as<float>(), W);
     layer_input_gemm(m, *Lbw, ts->X0.as<float>(), W);
-    { const LayerFwd f[2] = {{Lfw, nullptr, nullptr}, {Lbw, nullptr, nullptr}}; if (int rc = layers_forward(m, f, 2)) return rc; }
+    bool masked1 = false;
+    {
+        const LayerFwd f[2] = {{Lfw, nullptr, nullptr, ts->O[1].as<float>(), 2 * W, menc_n(1)},
+                               {Lbw, nullptr, nullptr, ts->O[1].as<float>() + W, 2 * W, menc_n(1) ? menc_n(1) + W : nullptr}};
+        if (int rc = layers_forward(m, f, 2, &masked1)) return rc;
+    }
     // final states handed to the decoder: layer 1 = backward direction after t = 0 (seq2seq.py:280)
     HIPCHK(hipMemcpy2DAsync(hfin, (size_t)W * 4, Lbw->hs, (size_t)2 * W * 4, (size_t)W * 4, B, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(cfin, Lbw->Cs.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
-    launch_mul_mask(ts->H1.as<float>(), 2 * W, menc_n(1), ts->O[1].as<float>(), 2 * W, TB, 2 * W, st);
+    if (!masked1) launch_mul_mask(ts->H1.as<float>(), 2 * W, menc_n(1), ts->O[1].as<float>(), 2 * W, TB, 2 * W, st);
     launch_embed_tm(ts->W_(ts->iE), ts->d_in.as<int>(), nullptr, ts->Y0.as<float>(), B, U, 1, V, W, st);
     // Encoder layer n and decoder layer n-1 depend only on encoder layer n-1 / decoder layer n-2, so the two
     // recurrences advance in lockstep, one launch per step for both.
@@ -550,11 +559,17 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         layer_input_gemm(m, le, ts->O[n - 1].as<float>(), le.kx);
         layer_input_gemm(m, ld, y, W);
         const float* h0 = hfin + (size_t)(n - 2) * B * W; const float* c0 = cfin + (size_t)(n - 2) * B * W;
-        { const LayerFwd f[2] = {{&le, nullptr, nullptr}, {&ld, h0, c0}}; if (int rc = layers_forward(m, f, 2)) return rc; }
+        bool maskedn = false;
+        {
+            const LayerFwd f[2] = {{&le, nullptr, nullptr, ts->O[n].as<float>(), W, menc_n(n)}, {&ld, h0, c0, ts->DO[n - 1].as<float>(), W, mdec_n(n - 1)}};
+            if (int rc = layers_forward(m, f, 2, &maskedn)) return rc;
+        }
         HIPCHK(hipMemcpyAsync(hfin + (size_t)(n - 1) * B * W, le.hs + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(cfin + (size_t)(n - 1) * B * W, le.Cs.as<float>() + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
-        launch_mul_mask(le.hs, W, menc_n(n), ts->O[n].as<float>(), W, TB, W, st);
-        launch_mul_mask(ld.hs, W, mdec_n(n - 1), ts->DO[n - 1].as<float>(), W, UB, W, st);
+        if (!maskedn) {
+            launch_mul_mask(le.hs, W, menc_n(n), ts->O[n].as<float>(), W, TB, W, st);
+            launch_mul_mask(ld.hs, W, mdec_n(n - 1), ts->DO[n - 1].as<float>(), W, UB, W, st);
+        }
         y = ts->DO[n - 1].as<float>();
     }
     const float* enc_out = ts->O[D].as<float>();

@@ -23,6 +23,7 @@ struct RecJob {
     float* Cs; float* Gt;            // [len][B][W] cell states, [len][B][4W] gate activations (kept for the backward pass)
     const float* h0; const float* c0;   // [B][W] initial state or nullptr (zeros)
     int len, reverse;
+    float* om; long long om_ld; const float* omask;   // optional second copy of the outputs, times a per-unit mask [W] (the next layer's dropped-out input) or nullptr
 };
 struct RecArgs { RecJob job[2]; int njobs, B, W; unsigned* counters; int fault; };   // fault: test of the give-up path (one workgroup leaves early)
 size_t train_recurrence_counter_bytes(int B);

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256, 2) void train_recurrence_kernel(const RecArgs 
 
     // cell state of this lane's four (row, unit) elements: rows m0 + q + 8 wave + 4 lh, unit ug * 32 + l31
     const int u = ug * 32 + l31;
+    const float omask_u = job.omask ? job.omask[u] : 1.0f;
     float cst[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void train_recurrence_kernel(const RecArgs 
         float* cout = job.Cs + (long long)t * B * W;
         float* hout = job.hs + (long long)t * B * job.hs_ld;
         float* gout = job.Gt + (long long)t * B * (4 * W);
+        float* mout = job.om ? job.om + (long long)t * B * job.om_ld : nullptr;        // the outputs once more, masked: the next layer's input
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int m = m0 + q + 8 * wave + 4 * lh;
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void train_recurrence_kernel(const RecArgs 
                 cst[q] = cell.c;
                 cout[(long long)m * W + u] = cell.c;
                 __hip_atomic_store(hout + (long long)m * job.hs_ld + u, cell.h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (mout) mout[(long long)m * job.om_ld + u] = cell.h * omask_u;
                 float* gr = gout + (long long)m * (4 * W) + n0 + l31;
                 gr[0] = cell.i; gr[32] = cell.f; gr[64] = cell.g; gr[96] = cell.o;
             }
