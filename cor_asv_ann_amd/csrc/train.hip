@@ -809,22 +809,23 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     const float* dy = ts->dXtop.as<float>();        // gradient w.r.t. DO[D-1] (or Y0 when D == 1)
     const float* dO = ts->d_enc.as<float>();        // gradient w.r.t. O[D]
     long long ld_dO = C;
+    // (a pair's input gradients are the next pair's output gradients: two buffers per chain taking turns, nothing is copied)
+    float* dy_bufs[2] = {ts->dXtop.as<float>(), ts->dYl.as<float>()}; int dy_cur = 0;
+    float* do_bufs[2] = {ts->dXl.as<float>(), ts->dOin.as<float>()}; int do_out = 0;
     for (int n = D - 1; n >= 1; --n) {
         TLayer& ld = dec_layer(n);
         TLayer& le = enc_layer(n + 1);
         const float* xin = n == 1 ? ts->Y0.as<float>() : ts->DO[n - 1].as<float>();
         LayerBwd pair[2] = {
             {&ld, dy, W, mdec_n(n), nullptr, nullptr, hfin + (size_t)(n - 1) * B * W, cfin + (size_t)(n - 1) * B * W, dfin_c(n),
-             xin, W, ts->dYl.as<float>(), W, 0},
+             xin, W, dy_bufs[dy_cur ^ 1], W, 0},
             {&le, dO, ld_dO, menc_n(n + 1), dfin_h(n + 1), dfin_c(n + 1), nullptr, nullptr, ts->dcbuf.as<float>(),
-             ts->O[n].as<float>(), le.kx, ts->dXl.as<float>(), le.kx, 0}};
+             ts->O[n].as<float>(), le.kx, do_bufs[do_out], le.kx, 0}};
         if (int rc = layers_backward(m, pair, 2)) return rc;
         // dL/dh0, dL/dc0 of the decoder layer go to the encoder layer of the same index
         HIPCHK(hipMemcpyAsync(dfin_h(n), ld.dRec.as<float>(), (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(ts->dXtop.p, ts->dYl.p, UB * W * 4, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(ts->dOin.p, ts->dXl.p, TB * le.kx * 4, hipMemcpyDeviceToDevice, st));
-        dy = ts->dXtop.as<float>();
-        dO = ts->dOin.as<float>(); ld_dO = le.kx;
+        dy_cur ^= 1; dy = dy_bufs[dy_cur];
+        dO = do_bufs[do_out]; ld_dO = le.kx; do_out ^= 1;
     }
     launch_embed_scatter(ts->G_(ts->iE), ts->d_in.as<int>(), nullptr, dy, W, B, U, 1, V, W, st);
 
