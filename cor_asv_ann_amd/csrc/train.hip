@@ -323,19 +323,22 @@ static int layer_backward_finish(casv_model* m, const LayerBwd& a) {
         GemmArgs g = plain_gemm(l.Z.as<float>(), 4 * W, (int)rows, 4 * W, l.wxT.as<float>(), l.kx, nullptr, a.dX, a.ld_dx, a.dx_accumulate);
         run_plain(m, g);
     }
-    // recurrent-side inputs of every step: HP[t] = h of the previously processed step (h0 / zero at the first)
-    float* HP = ts->HP.as<float>();
-    const int t0 = time_of(l, 0);
-    if (a.h0) HIPCHK(hipMemcpyAsync(HP + (long long)t0 * B * W, a.h0, (size_t)B * W * 4, hipMemcpyDeviceToDevice, m->stream));
-    else HIPCHK(hipMemsetAsync(HP + (long long)t0 * B * W, 0, (size_t)B * W * 4, m->stream));
-    if (l.len > 1) {
-        // forward layer: HP[1..] = H[0..len-2]; reversed layer: HP[0..len-2] = H[1..]
-        const float* src = l.hs + (l.reverse ? (long long)B * l.hs_ld : 0);
-        float* dst = HP + (l.reverse ? 0 : (long long)B * W);
-        HIPCHK(hipMemcpy2DAsync(dst, (size_t)W * 4, src, (size_t)l.hs_ld * 4, (size_t)W * 4, (size_t)(l.len - 1) * B,
-                                hipMemcpyDeviceToDevice, m->stream));
+    // The recurrent-side input of a step is the h of the previously processed step (h0 / zero at the first): the layer's own
+    // outputs, one time step apart from dZ -- contracted as they lie (gemm_tn takes a row offset and a row stride; the first step's
+    // B rows against h0 as a launch of their own), not copied into a shifted image first (105 MB per layer at configs[3]).
+    if (ts->tens[l.iwx].frozen) return 0;
+    const float* dZ = l.Z.as<float>();
+    // (the bias gradient = column sums of dZ rides in the launch over the inputs)
+    run_gemm_tn(m, dZ, 4 * W, 4 * W, 4 * W, a.x, a.ldx, l.kx, rows, ts->G_(l.iwx), l.kx, ts->G_(l.ib));
+    const long long rest = (long long)(l.len - 1) * B;         // rows whose previous step is a row of hs
+    if (rest > 0) {
+        // forward layer: dZ[1..] with H[0..len-2]; reversed layer: dZ[0..len-2] with H[1..]
+        const float* dz = dZ + (l.reverse ? 0 : (long long)B * 4 * W);
+        const float* hp = l.hs + (l.reverse ? (long long)B * l.hs_ld : 0);
+        run_gemm_tn(m, dz, 4 * W, 4 * W, 4 * W, hp, l.hs_ld, W, rest, ts->G_(l.iwr), l.kr);
     }
-    return layer_weight_grads(m, l, a.x, a.ldx, HP, W);
+    if (a.h0) run_gemm_tn(m, dZ + (long long)time_of(l, 0) * B * 4 * W, 4 * W, 4 * W, 4 * W, a.h0, W, W, B, ts->G_(l.iwr), l.kr);
+    return 0;
 }
 
 // Up to two independent layers walk their sequences backwards in lockstep: one pointwise launch each and ONE data-GEMM
@@ -474,8 +477,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     TrainState* ts = m->train;
     hipStream_t st = m->stream;
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, D = m->D;
-    const int L = std::max(T, U);
-    const long long TB = (long long)T * B, UB = (long long)U * B, LB = (long long)L * B;
+    const long long TB = (long long)T * B, UB = (long long)U * B;
     ts->B = B; ts->T = T; ts->U = U; ts->A = A;
     m->encoded = false;                    // the final-state buffers are shared with the inference session
     const bool training = mode != 0;
@@ -488,7 +490,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     ENS(ts->WQ, UB * W * 4) ENS(ts->Ast, (size_t)(U + 1) * B * T * 4) ENS(ts->WIN, UB * 4)
     ENS(ts->RecIn, UB * (C + W) * 4) ENS(ts->prev, (size_t)B * 4) ENS(ts->logits, UB * Vp * 4)
     ENS(ts->dG, UB * W * 4) ENS(ts->d_enc, TB * C * 4) ENS(ts->du, TB * W * 4) ENS(ts->DWQ, UB * W * 4) ENS(ts->DSrows, UB * 16 * 4) ENS(ts->dhatt, UB * W * 4)
-    ENS(ts->dfin, (size_t)2 * D * B * W * 4) ENS(ts->dcbuf, (size_t)B * W * 4) ENS(ts->HP, LB * W * 4)
+    ENS(ts->dfin, (size_t)2 * D * B * W * 4) ENS(ts->dcbuf, (size_t)B * W * 4)
     ENS(ts->dX0, TB * W * 4) ENS(ts->dXtop, UB * W * 4) ENS(ts->dXl, TB * 2 * W * 4) ENS(ts->dYl, UB * W * 4) ENS(ts->dOin, TB * 2 * W * 4)
     ENS(ts->dcbuf2, (size_t)B * W * 4) ENS(ts->dvaP, (size_t)B * W * 4) ENS(ts->dbvP, (size_t)B * 4)
     for (auto& l : ts->layers) {
