@@ -860,7 +860,8 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         }
         launch(mt);
     };
-    over_tensors(1024, [&](const MultiTensor& mt) { launch_sumsq_multi(mt, ts->normsq.as<double>(), st); });
+    // (few workgroups per tensor: every one of them ends in an atomic add on the ONE sum -- ~12 ns each, one after the other)
+    over_tensors(64, [&](const MultiTensor& mt) { launch_sumsq_multi(mt, ts->normsq.as<double>(), st); });
     if (mode == 1) {
         ts->step += 1;
         const double b1 = ts->ap.beta1, b2 = ts->ap.beta2;
