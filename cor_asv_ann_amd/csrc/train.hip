@@ -23,6 +23,7 @@ struct TLayer {
     int iwx = -1, iwr = -1, ib = -1;
     DevBuf wxT, wrT;                       // derived: [kx][4W], [kr][4W]
     DevBuf Hown, Cs, Gt, Z, dRec;
+    bool drec_cleared = false;             // this step's forward recurrence has cleared dRec (train_persist.hip: RecJob.zero)
     float* hs = nullptr; long long hs_ld = 0;
 };
 
@@ -439,7 +440,7 @@ static int layers_forward(casv_model* m, const LayerFwd* a, int count, bool* mas
         for (int j = 0; j < count; ++j) {
             TLayer& l = *a[j].l;
             ra.job[j] = RecJob{ts->W_(l.iwr), l.Z.as<float>(), l.hs, l.hs_ld, l.Cs.as<float>(), l.Gt.as<float>(), a[j].h0, a[j].c0, l.len,
-                               l.reverse ? 1 : 0, masked ? a[j].om : nullptr, a[j].om_ld, a[j].omask};
+                               l.reverse ? 1 : 0, masked ? a[j].om : nullptr, a[j].om_ld, a[j].omask, l.kr == W ? l.dRec.as<float>() : nullptr};
         }
         const size_t cb = train_recurrence_bwd_counter_bytes(B);        // (one slot size for both kinds of launch)
         ra.counters = reinterpret_cast<unsigned*>(static_cast<char*>(ts->rec_cnt.p) + cb * ts->rec_launches);
@@ -453,6 +454,7 @@ static int layers_forward(casv_model* m, const LayerFwd* a, int count, bool* mas
             m->prof_end(PC_PERSIST, ev);
             ts->rec_abort[ts->rec_launches++] = ra.counters + (train_recurrence_counter_bytes(B) / sizeof(unsigned) - 32);
             if (masked) *masked = true;
+            for (int j = 0; j < count; ++j) a[j].l->drec_cleared = a[j].l->kr == W;
             return 0;
         }
     }
@@ -526,6 +528,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     HIPCHK(hipMemsetAsync(ts->normsq.p, 0, 16, st));
     HIPCHK(hipMemsetAsync(ts->rec_cnt.p, 0, 16 * train_recurrence_bwd_counter_bytes(B), st));
     ts->rec_launches = ts->rec_checked = 0; ts->split_launch = -1;
+    for (auto& l : ts->layers) l.drec_cleared = false;
     if (ts->rec_skip > 0) --ts->rec_skip;
     if (training) for (auto& t : ts->tens) HIPCHK(hipMemsetAsync(t.g.p, 0, t.n * 4, st));
 
@@ -678,7 +681,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     HIPCHK(hipMemsetAsync(ts->du.p, 0, TB * W * 4, st));
     HIPCHK(hipMemsetAsync(ts->dvaP.p, 0, (size_t)B * W * 4, st));
     HIPCHK(hipMemsetAsync(ts->dhatt.p, 0, UB * W * 4, st));     // split-K outputs of the per-step GEMMs
-    for (auto& l : ts->layers) HIPCHK(hipMemsetAsync(l.dRec.p, 0, (size_t)l.len * B * l.kr * 4, st));
+    for (auto& l : ts->layers) if (!l.drec_cleared) HIPCHK(hipMemsetAsync(l.dRec.p, 0, (size_t)l.len * B * l.kr * 4, st));
     HIPCHK(hipMemsetAsync(ts->dbvP.p, 0, (size_t)B * 4, st));
     float* dfin = ts->dfin.as<float>();          // [n-1][0|1][B][W]
     auto dfin_h = [&](int n) { return dfin + (size_t)(2 * (n - 1)) * B * W; };

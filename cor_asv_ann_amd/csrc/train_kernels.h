@@ -24,6 +24,7 @@ struct RecJob {
     const float* h0; const float* c0;   // [B][W] initial state or nullptr (zeros)
     int len, reverse;
     float* om; long long om_ld; const float* omask;   // optional second copy of the outputs, times a per-unit mask [W] (the next layer's dropped-out input) or nullptr
+    float* zero;                     // optional [len][B][W]: cleared tile by tile along the way (the backward pass's dL/dh accumulator of this layer)
 };
 struct RecArgs { RecJob job[2]; int njobs, B, W; unsigned* counters; int fault; };   // fault: test of the give-up path (one workgroup leaves early)
 size_t train_recurrence_counter_bytes(int B);

@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256, 2) void train_recurrence_kernel(const RecArgs 
         float* hout = job.hs + (long long)t * B * job.hs_ld;
         float* gout = job.Gt + (long long)t * B * (4 * W);
         float* mout = job.om ? job.om + (long long)t * B * job.om_ld : nullptr;        // the outputs once more, masked: the next layer's input
+        // (the layer's dL/dh accumulator of the backward pass, cleared here 16 bytes per thread and step instead of by a fill of the
+        // whole buffer in front of the backward pass: these stores cost nothing beside the epilogue's own)
+        if (job.zero && m0 + srow < B)
+            *reinterpret_cast<f32x4*>(job.zero + ((long long)t * B + m0 + srow) * W + ug * 32 + sk) = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int m = m0 + q + 8 * wave + 4 * lh;
