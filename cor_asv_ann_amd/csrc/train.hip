@@ -586,7 +586,6 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     layer_input_gemm(m, top, ts->Ym.as<float>(), W);
     const float* h0t = hfin + (size_t)(D - 1) * B * W; const float* c0t = cfin + (size_t)(D - 1) * B * W;
     HIPCHK(hipMemsetAsync(ts->Ast.p, 0, (size_t)B * T * 4, st));
-    HIPCHK(hipMemsetAsync(ts->WQ.p, 0, UB * W * 4, st));        // split-K partial sums land here
     // The cell's input rows [ctx * mask | h(t-1)] (LSTMCell(dropout) masks the cell input [y | ctx] per sample, seq2seq.py:345; the y
     // part is masked where it is precomputed) are filled where their parts are produced: the attention rows write the masked
     // context straight into them, the cell of the step before stores its h a second time.
@@ -616,6 +615,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             top_persistent = true;
         }
     }
+    if (!top_persistent) HIPCHK(hipMemsetAsync(ts->WQ.p, 0, UB * W * 4, st));      // (the per-step launches' split-K partial sums land here; the persistent kernel stores its queries)
     for (int t = 0; t < U && !top_persistent; ++t) {
         const float* hprev = t == 0 ? h0t : top.hs + (long long)(t - 1) * B * W;
         float* wq = ts->WQ.as<float>() + (long long)t * B * W;
@@ -680,7 +680,6 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     HIPCHK(hipMemsetAsync(ts->d_enc.p, 0, TB * C * 4, st));
     HIPCHK(hipMemsetAsync(ts->du.p, 0, TB * W * 4, st));
     HIPCHK(hipMemsetAsync(ts->dvaP.p, 0, (size_t)B * W * 4, st));
-    HIPCHK(hipMemsetAsync(ts->dhatt.p, 0, UB * W * 4, st));     // split-K outputs of the per-step GEMMs
     for (auto& l : ts->layers) if (!l.drec_cleared) HIPCHK(hipMemsetAsync(l.dRec.p, 0, (size_t)l.len * B * l.kr * 4, st));
     HIPCHK(hipMemsetAsync(ts->dbvP.p, 0, (size_t)B * 4, st));
     float* dfin = ts->dfin.as<float>();          // [n-1][0|1][B][W]
@@ -748,6 +747,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
                 topb_persistent = true;
             }
         }
+        if (!topb_persistent) HIPCHK(hipMemsetAsync(ts->dhatt.p, 0, UB * W * 4, st));     // (split-K outputs of the per-step GEMMs; the persistent kernel stores them)
         for (int t = U - 1; t >= 0 && !topb_persistent; --t) {
             LstmBwdArgs p{};
             p.a = ts->dG.as<float>() + (long long)t * B * W; p.lda = W;
