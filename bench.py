@@ -213,6 +213,17 @@ def format_cpulist(cpus):
 
 
 # ------------------------------------------------------------------------------------------------------
+def dtype_label(arith, beamed):
+    """The line's `dtype`: the arithmetic type the path computes in.  Operands and results are float32 everywhere; what differs is the
+    matrix instruction the products run on."""
+    split = 'f32 as three bf16 parts per operand value (exact), six bf16-MFMA products per term, fp32 accumulation'
+    if arith == 'fp32' or (arith == 'auto' and not beamed):
+        return 'f32'
+    if arith == 'split':
+        return split
+    return 'f32; beam-search decoder steps: ' + split + '; encoder: fp32-input MFMA'
+
+
 def make_model(device, depth=DEPTH, width=WIDTH, batch_size=BEAM_N, emb_scale=EMB_SCALE, voc=VOC):
     from cor_asv_ann_amd.synthetic import ModelConfig, make_weights, make_vocabulary
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
@@ -271,38 +282,121 @@ def host_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(cfg, weights, lines, batch_size, fast, length=LENGTH, budget_s=22.0, repeats=5, min_lines=4, confmat=False, **beam):
-    """The oracle in the reference's dataflow (per-character decoder call, dense-T attention, u recomputed
-    every step, per-line best-first search / batched greedy loop) on the host cores: best of `repeats`
-    samples of the same workload, each sized to a share of the time budget.
-    confmat: the lines are confusion networks, handed over as `correct_lines(lines, conf=lines)` (wrapper/transcode.py:111-115)."""
-    from oracle.decode import OracleModel, correct_lines as oracle_correct_lines
-    om = OracleModel(cfg, weights, batch_size=batch_size, recompute_u=True, **beam)
-    kw = dict(fast=True, greedy=True) if fast else dict(fast=False, greedy=False)
+def host_cores():
+    """CPUs this process may really use: its affinity mask, capped by the cgroup's CPU quota where there is one (a GPU box hands a
+    one-GPU job a share of the host -- 16 CPUs -- while the affinity mask still shows all 256)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith('cpu.max'):
+                if parts[0] != 'max':
+                    n = min(n, max(1, int(round(int(parts[0]) / float(parts[1])))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                        n = min(n, max(1, int(round(quota / float(f.read().split()[0])))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cap = os.environ.get('CASV_BENCH_CPUS')          # the operator's word where neither says it
+    return max(1, min(n, int(cap))) if cap and cap.isdigit() else n
 
-    def correct_lines(m, chunk, **k):
-        return oracle_correct_lines(m, chunk, conf=chunk, **k) if confmat else oracle_correct_lines(m, chunk, **k)
-    n0 = 8 if fast else 1
-    t0 = time.perf_counter()
-    correct_lines(om, lines[:n0], **kw)                      # warm-up (BLAS threads, page-in); also sizes the sample
-    first = time.perf_counter() - t0
-    per_line = first / n0
-    n = int(max(n0, min(len(lines), (budget_s / repeats) / max(per_line, 1e-6))))
-    if n < min_lines:                   # a sample of at least `min_lines` lines (a one- or two-line sample is noisy), fewer runs
-        n = min(min_lines, len(lines))
-    # as many runs as the budget holds (a wide search takes its whole budget for ONE line: then the warm-up run is the sample too)
-    repeats = int(min(repeats, max(budget_s / max(n * per_line, 1e-6), 0 if n == n0 else 1)))
-    best = first if n == n0 else None
-    runs = repeats + (1 if n == n0 else 0)
-    for _ in range(repeats):
+
+_CPU_MODEL = None
+
+
+def _cpu_init(depth, width, voc, emb, batch_size, beam, threads):
+    """Worker start (a fresh interpreter: `spawn`): the oracle model of this workload, BLAS threads capped at the worker's share."""
+    global _CPU_MODEL
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(threads)
+    except Exception:
+        pass
+    from oracle import ModelConfig, make_weights
+    from oracle.decode import OracleModel
+    cfg = ModelConfig(depth=depth, width=width, voc_size=voc)
+    _CPU_MODEL = OracleModel(cfg, make_weights(cfg, emb_scale=emb), batch_size=batch_size, recompute_u=True, **beam)
+
+
+def _cpu_decode(job):
+    """One worker's share of a sample: `correct_lines` of the oracle in the reference's dataflow."""
+    chunk, fast, confmat = job
+    from oracle.decode import correct_lines
+    kw = dict(fast=True, greedy=True) if fast else dict(fast=False, greedy=False)
+    if not chunk:
+        return 0
+    (correct_lines(_CPU_MODEL, chunk, conf=chunk, **kw) if confmat else correct_lines(_CPU_MODEL, chunk, **kw))
+    return len(chunk)
+
+
+def cpu_baseline(cfg, emb, lines, batch_size, fast, length=LENGTH, budget_s=60.0, repeats=5, warmups=2, min_lines=16, confmat=False, **beam):
+    """The oracle in the reference's dataflow (per-character decoder call, dense-T attention, u recomputed every step, per-line
+    best-first search / batched greedy loop) on the host cores, BASELINE.md section 3's recipe: best of `repeats` runs over the
+    same sample of >= `min_lines` lines after `warmups` warm-up runs -- as far as the time budget carries (the sample line says
+    what was run).  Lines are independent, so the sample is spread over worker processes, each with its share of the BLAS threads
+    (the search's GEMMs have 8 rows: one process does not keep 64 cores busy; the reference itself is one process whose Keras CPU
+    path would parallelise inside each op).  confmat: the lines are confusion networks, handed over as
+    `correct_lines(lines, conf=lines)` (wrapper/transcode.py:111-115)."""
+    import multiprocessing as mp
+    cores = host_cores()
+    # wide searches (the page call's 256 rows per step) get more threads per process, narrow ones more processes
+    workers = max(1, min(16, cores // (16 if batch_size >= 64 and not fast else 4), len(lines)))
+    threads = max(1, cores // workers)
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
+    for k in saved:                       # read by the workers' BLAS when THEY load it (this process has loaded its own long ago)
+        os.environ[k] = str(threads)
+    t_start = time.perf_counter()
+    try:
+        pool = mp.get_context('spawn').Pool(workers, initializer=_cpu_init,
+                                            initargs=(cfg.depth, cfg.width, cfg.voc_size, emb, batch_size, beam, threads))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def run(sample):
+        share = -(-len(sample) // workers)
+        jobs = [(sample[w * share:(w + 1) * share], fast, confmat) for w in range(workers)]
         t0 = time.perf_counter()
-        correct_lines(om, lines[:n], **kw)
-        dt = time.perf_counter() - t0
-        best = dt if best is None or dt < best else best
-    repeats = runs
-    return {'value': n * length / best, 'unit': 'chars/s', 'cores': host_threads(), 'kind': 'port',
-            'sample': 'best of %d runs over %d lines of the same workload (numpy fp32 oracle, reference dataflow: '
-                      'per-character decoder call, dense-T attention, u recomputed per step), %.1f s per run' % (repeats, n, best)}
+        done = sum(pool.map(_cpu_decode, jobs, chunksize=1))
+        assert done == len(sample)
+        return time.perf_counter() - t0
+    try:
+        n0 = workers * (8 if fast else 1)           # first warm-up: BLAS threads, page-in; also sizes the sample
+        n0 = min(n0, len(lines))
+        first = run(lines[:n0])
+        left = lambda: budget_s - (time.perf_counter() - t_start)
+        per_round = first / (n0 / float(workers))           # seconds per line of a worker's share
+        # the sample: >= min_lines lines, more if `repeats` runs of it still fit the budget
+        n = int(min(len(lines), max(min_lines, workers * int(max(1.0, left() / (repeats + warmups - 1) / per_round)))))
+        n = max(workers, n - n % workers) if n >= workers else n
+        t_run = per_round * -(-n // workers)
+        done_warm = 1
+        while done_warm < warmups and left() > (repeats + 1) * t_run:
+            run(lines[:n])
+            done_warm += 1
+        best, runs = None, 0
+        while runs < repeats and (runs == 0 or left() > t_run):
+            if runs == 0 and left() < t_run and n0 == n:
+                break                       # (a wide search takes its whole budget for one round: the warm-up run is the sample)
+            dt = run(lines[:n])
+            best = dt if best is None or dt < best else best
+            runs += 1
+        if best is None:
+            best, n, runs, done_warm = first, n0, 1, 0
+    finally:
+        pool.close()
+        pool.join()
+    return {'value': n * length / best, 'unit': 'chars/s', 'cores': workers * threads, 'kind': 'port',
+            'sample': 'best of %d runs after %d warm-up runs over %d lines of the same workload (numpy fp32 oracle, reference dataflow: '
+                      'per-character decoder call, dense-T attention, u recomputed per step), lines spread over %d worker processes x %d BLAS '
+                      'threads, %.1f s per run' % (runs, done_warm, n, workers, threads, best)}
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -487,6 +581,13 @@ def decode_bench(args):
     import numpy as np
     wl = WORKLOADS[args.workload]
     L, V = wl['length'], wl['voc']
+    # GEMM arithmetic: the library's default is by entry point -- the beam search's decoder steps on
+    # bf16x3-split operands (mode 2), everything else fp32-input; --arithmetic fp32 / split puts the handle on one of them,
+    # --split-bf16 the whole process.  split_mode = what the workload's dominant launches take.
+    arith, beamed = args.arithmetic, not wl['fast']
+    if args.split_bf16 >= 0:
+        arith = 'split' if args.split_bf16 else 'fp32'
+    split_mode = args.split_bf16 if args.split_bf16 >= 0 else {'auto': 2 if beamed else 0, 'fp32': 0, 'split': 2}[arith]
     if world != args.gpus and 'WORLD_SIZE' in os.environ:
         sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
         return 2
@@ -554,6 +655,7 @@ def decode_bench(args):
         sync_dev = lambda: None
     else:
         s2s, cfg, weights = make_model(local_rank, wl['depth'], wl['width'], wl['n'], wl['emb'], V)
+        s2s.arithmetic = args.arithmetic
         for key in ('rejection', 'beam_width_in', 'beam_threshold_in'):
             if key in wl:
                 setattr(s2s, 'rejection_threshold' if key == 'rejection' else key, wl[key])
@@ -664,7 +766,7 @@ def decode_bench(args):
                 last, out_lines = out_lines, []
         return last
 
-    dom = 'lstm_gemm' if args.workload != 'c2' else 'persist'
+    dom = 'lstm_gemm' if (args.workload != 'c2' or split_mode) else 'persist'
     run_steps(args.warmup)
     if eng:
         # HIP events around launches of the dominant kernel, on the library's stream: around every 13th of them (level 3) --
@@ -722,14 +824,17 @@ def decode_bench(args):
             'value': chars / elapsed, 'unit': 'chars/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if not args.split_bf16 else 'f32 (bf16x3 split operands on the bf16 MFMA, six products, fp32 accumulate)',
+            'dtype': dtype_label(arith, beamed),
             'data': 'dry-run (no decoding)' if dry else 'synthetic',
-            'config': {'workload': wl['text'] + ', 2T=%d steps max, synthetic weights seed 20250614 emb_scale=%g' % (S, wl['emb']),
-                       'lines_per_gpu': per_gpu, 'lines_per_decode_call': batch, 'line_length': L, 'beam_n': wl['n'],
+            'config': {'workload': wl['text'] + ', 2T=%d steps max' % S,
+                       # deviation from BASELINE.md section 3 (emb_scale 4): with 4 the softmax is flat and the search collapses to one
+                       # row x T steps per line, 16 x less work
+                       'emb_scale': wl['emb'], 'weights': 'synthetic, seed 20250614',
+                       'arithmetic': arith, 'lines_per_gpu': per_gpu, 'lines_per_decode_call': batch, 'line_length': L, 'beam_n': wl['n'],
                        'parallelism': 'lines sharded x%d' % world,
                        'gather': 'casv_comm (RCCL, C ABI)' if comm else ('torch.distributed/' + backend if dist_on else 'none'),
                        'records': (records + '-packed') if dist_on else 'none',
-                       'graph': bool(args.graph), 'alignments': want_align, 'split_bf16': args.split_bf16,
+                       'graph': bool(args.graph), 'alignments': want_align, 'split_bf16_override': args.split_bf16,
                        'steps_run': 'through correct_batches, as predict() does: host work of neighbouring steps overlaps the device'
                                     if pipelined else 'one correct_lines call after the other',
                        'launcher': 'bench.py' if os.environ.get('CASV_BENCH_CHILD') else
@@ -752,10 +857,10 @@ def decode_bench(args):
             # PMC passes over this same command (profiles/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE in separate passes), named here
             traffic, traffic_source = None, None
             tname = {'persist': 'persist_decode_traffic.json'}.get(dom) or \
-                ('page_gemm_traffic.json' if args.workload == 'page' else
-                 ('split256_gemm_traffic.json' if args.split_bf16 == 2 else (None if args.split_bf16 == 1 else 'lstm_gemm_traffic.json')))
+                (('page_split_gemm_traffic.json' if split_mode == 2 else None if split_mode else 'page_gemm_traffic.json') if args.workload == 'page' else
+                 ('split256_gemm_traffic.json' if split_mode == 2 else (None if split_mode == 1 else 'lstm_gemm_traffic.json')))
             try:
-                with open(os.path.join(ROOT, 'profiles', tname)) as f:
+                with open(os.path.join(ROOT, 'profiles', tname or 'none')) as f:
                     tj = json.load(f)
                 traffic = tj.get('hbm_bytes_per_launch')
                 traffic_source = ('profiles/%s: constant from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s (commit %s) over this '
@@ -764,9 +869,9 @@ def decode_bench(args):
                 pass
             result['roofline'] = {
                 'bound': 'mfma',
-                'kernel': ('gemm_kernel<EPI_LSTM, 1> (fused LSTM-cell GEMM, 128x128 tiles, fp32 MFMA)' if not args.split_bf16 else
+                'kernel': ('gemm_kernel<EPI_LSTM, 1> (fused LSTM-cell GEMM, 128x128 tiles, fp32 MFMA)' if not split_mode else
                            'fused LSTM-cell GEMM on v_mfma_f32_32x32x16_bf16, bf16x3-split operands: ' +
-                           ('gemm_kernel<EPI_LSTM, 1, split> 128x128 tiles' if args.split_bf16 == 1 else 'gemm_split256_kernel 256x256 tiles') +
+                           ('gemm_kernel<EPI_LSTM, 1, split> 128x128 tiles' if split_mode == 1 else 'gemm_split256_kernel 256x256 tiles') +
                            '; achieved / peak / frac are the EXECUTED bf16 FLOP (6 per algorithmic fp32 one) against the dense bf16-MFMA peak')
                           if dom == 'lstm_gemm' else 'persist_decode_kernel (all 2T greedy steps of the batch in one launch: 16x16x4 fp32-MFMA tiles, '
                                'row-block hand-offs between workgroups)',
@@ -784,7 +889,7 @@ def decode_bench(args):
                                # the other roofline of SURVEY 8(d): not the binding one at fp32
                                'hbm_bytes_per_char': qpc,
                                'hbm_frac': chars / elapsed * qpc / world / PEAK_HBM_BYTES_PER_S}}
-        if args.split_bf16 and 'roofline' in result:
+        if split_mode and dom == 'lstm_gemm' and 'roofline' in result:
             # The split kernels run on the bf16 matrix instruction: six bf16 products per algorithmic fp32 one.  Their roofline is the
             # dense bf16-MFMA peak; the algorithmic fp32 rate stays in the line as a rate, not as a fraction of a peak it is not bound by.
             rl = result['roofline']
@@ -794,14 +899,18 @@ def decode_bench(args):
             rl['bf16_mfma'] = {'achieved': rl['achieved'], 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': rl['frac']}
             for k in ('frac', 'frac_executed'):        # (whole-path prices against the fp32 peak mean nothing here either)
                 rl['whole_path'].pop(k, None)
-            rl['whole_path']['note'] = 'achieved = algorithmic fp32 TFLOP/s of the whole path; no fraction: the path is not bound by the fp32-input instruction under this option'
+            rl['whole_path']['note'] = ('achieved = algorithmic fp32 TFLOP/s of the whole path; no fraction of the fp32-input peak: the decoder steps '
+                                        'do not run on that instruction.  frac_bf16 = the FLOP the path executes, the split launches\' six-fold, against the bf16 peak')
+            # the whole path against the bf16 peak: decoder FLOP executed six-fold on the bf16 instruction; the encoder's share (fp32-input
+            # instruction under 'auto') is priced as if it ran there too -- an upper bound on what the peak allows
+            rl['whole_path']['frac_bf16'] = 6.0 * chars / elapsed * xpc / 1e12 / world / PEAK_BF16_MFMA_TFLOPS
         if others:
             result['kernel_ms_per_step'] = {k: v['ms'] for k, v in others.items()}     # from one extra untimed step
         if world == 1 and not args.no_cpu_baseline and not dry:
             beam = {('rejection_threshold' if k == 'rejection' else k): wl[k] for k in ('rejection', 'beam_width_in', 'beam_threshold_in') if k in wl}
-            result['cpu_baseline'] = cpu_baseline(cfg, weights, all_lines[:64], wl['n'] if not wl['fast'] else 256, wl['fast'], L,
+            result['cpu_baseline'] = cpu_baseline(cfg, wl['emb'], all_lines[:256], wl['n'] if not wl['fast'] else 256, wl['fast'], L,
                                                   budget_s=args.cpu_budget, confmat=bool(wl.get('confmat')),
-                                                  min_lines=1 if wl.get('confmat') else 4, **beam)
+                                                  min_lines=1 if wl.get('confmat') else 16, **beam)
     if comm:
         comm.close()
     elif dist_on:
@@ -824,8 +933,9 @@ def other_workloads(with_cpu_baseline=True):
     out = {}
     for name, extra in (('c2', ['--steps', '20', '--warmup', '3']), ('c4', ['--steps', '5', '--warmup', '2']),
                         ('page', ['--steps', '3', '--warmup', '1']),
-                        # the headline's workload under the split-bf16 experiment: reported here only
-                        ('c3_split_bf16', ['--steps', '5', '--warmup', '2', '--split-bf16', '2'])):
+                        # the headline's workload with every launch on the fp32-input matrix instruction (the library's only arithmetic
+                        # until round 5; Sequence2Sequence.arithmetic = 'fp32'): the figure beside the default's
+                        ('c3_fp32', ['--steps', '5', '--warmup', '2', '--arithmetic', 'fp32'])):
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', name.split('_')[0], '--no-others'] + extra
         cmd += ['--cpu-budget', '8'] if name in ('c2', 'c4', 'page') and with_cpu_baseline else ['--no-cpu-baseline']
         env = {k: v for k, v in os.environ.items() if not k.startswith('CASV_BENCH_')}
@@ -840,10 +950,11 @@ def other_workloads(with_cpu_baseline=True):
             keep = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype') if k in r}
             keep['workload'] = r['config']['workload']
             if 'roofline' in r:
-                keep['roofline'] = {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'launches', 'avg_launch_us', 'algorithmic_fp32_tflops')
+                keep['roofline'] = {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'launches', 'avg_launch_us', 'flops_per_launch', 'algorithmic_fp32_tflops')
                                     if k in r['roofline']}
-                if 'whole_path' in r['roofline'] and 'frac' in r['roofline']['whole_path']:
-                    keep['roofline']['whole_path_frac'] = r['roofline']['whole_path']['frac']
+                for k in ('frac', 'frac_bf16'):
+                    if k in r['roofline'].get('whole_path', {}):
+                        keep['roofline']['whole_path_' + k] = r['roofline']['whole_path'][k]
                 if 'bf16_mfma' in r['roofline']:
                     keep['roofline']['bf16_mfma'] = r['roofline']['bf16_mfma']
             for k in ('kernel_ms_per_step', 'realign_ms_per_step', 'cpu_baseline', 'calibration'):
@@ -851,12 +962,7 @@ def other_workloads(with_cpu_baseline=True):
                     keep[k] = r[k]
             if name == 'c4':
                 keep['vendor_gemm'] = r['config'].get('vendor_gemm')
-            if name == 'c3_split_bf16':
-                keep['split_bf16'] = r['config'].get('split_bf16')
-                keep['parity'] = ('experiment, off by default: every existing parity test passes unchanged with it on (the whole -m gpu suite '
-                                  'under CASV_SPLIT_BF16=2: 135 passed, 0 failed; tests/test_gpu_split.py switches it on explicitly: configs[2] '
-                                  'end to end on all 1024 lines of the committed fixture, the bench batch against the oracle fp32 and fp64 '
-                                  'searches, golden fixtures, full-width decoder steps) -- DESIGN.md section 4.7')
+            keep['arithmetic'] = r['config'].get('arithmetic')
             keep['wall_s'] = time.perf_counter() - t0
             out[name] = keep
         except Exception as err:            # a measurement aid must not take the headline down
@@ -893,7 +999,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-budget', type=float, default=22.0, help='seconds of host time for the cpu_baseline sample')
+    ap.add_argument('--cpu-budget', type=float, default=60.0, help='seconds of host time for the cpu_baseline sample')
     ap.add_argument('--no-others', action='store_true', help='do not time c2 / c4 / page after the default c3 run')
     ap.add_argument('--pipeline', type=int, default=1, help='1 GPU: 1 = the steps run through correct_batches (vectorising, device and '
                     'string building of neighbouring steps overlap, as in predict()), 0 = one correct_lines call after the other')
@@ -908,9 +1014,13 @@ def main():
     ap.add_argument('--facade', type=int, default=0,
                     help='c4 only: 1 = every batch comes the way Sequence2Sequence.train() gets it (file -> lines -> index arrays, '
                          'degradation, dropout masks), prepared by train()\'s worker thread while the device runs the step before')
-    ap.add_argument('--split-bf16', type=int, default=0, choices=[0, 1, 2],
-                    help='EXPERIMENT, never the headline: 1 / 2 = the fused LSTM GEMM contracts bf16x3-split fp32 operands on the bf16 '
-                         'matrix instruction with fp32 accumulation (library option split_bf16; 1 = 128x128 tiles, 2 = 256x256 tiles)')
+    ap.add_argument('--arithmetic', default='auto', choices=['auto', 'fp32', 'split'],
+                    help='GEMM arithmetic of the model handle (Sequence2Sequence.arithmetic): auto = the library default, by entry point '
+                         '(beam-search decoder steps: bf16x3-split fp32 operands on the bf16 matrix instruction, fp32 accumulation; encoder, '
+                         'greedy decodes: the fp32-input instruction); fp32 / split = one of them for everything the handle launches')
+    ap.add_argument('--split-bf16', type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help='A/B measurements: process-wide override of every launch of the decode path (library option split_bf16; 0 = fp32-input, '
+                         '1 = split operands on 128x128 tiles, 2 = on 256x256 tiles where they fill the chip)')
     ap.add_argument('--dump-records', default=None, help='rank 0 saves the gathered records of the last step to this .npy file (tests)')
     args = ap.parse_args()
     if args.gpus < 1:
@@ -927,8 +1037,8 @@ def main():
             argv = argv + ['--workload', args.workload]
         return launch_ranks(args.gpus, argv)
     claim_stdout()
-    if args.split_bf16:
-        os.environ['CASV_SPLIT_BF16'] = str(args.split_bf16)       # read by the library when it is loaded (process-wide switch)
+    if args.split_bf16 >= 0:
+        os.environ['CASV_SPLIT_BF16'] = str(args.split_bf16)       # read by the library when it is loaded (process-wide override)
     if args.workload == 'c4':
         return train_bench(args)
     return decode_bench(args)

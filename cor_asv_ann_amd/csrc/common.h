@@ -172,9 +172,17 @@ void vendor_gemm_release(hipStream_t stream);         // frees the vendor path's
 bool gemm_is_skinny(int epi, const GemmBatch& b);     // which tile shape launch_gemm_batch will pick
 // tile shape of the GEMM launches: -1 = by size (default), 0 = always 128x128, 1 = always 32x128 (same results)
 void set_gemm_tile_mode(int mode);
-// experiment, off by default: 128x128-tile launches contract bf16-split operands (three bf16 per fp32 value, six products, fp32
-// accumulation) on the bf16 matrix instruction -- fp32-accurate sums, not the bit pattern of the fp32-input kernels
-void set_gemm_split_bf16(int on);          // 0 off, 1 = 128x128 tiles (gemm.hip), 2 = 256x256 tiles where a job fills the chip (gemm_split.hip)
+// arithmetic of the GEMM launches (gemm.hip): 0 = fp32-input matrix instruction, 1 / 2 = bf16x3-split operands (three bf16 per fp32
+// value, six products, fp32 accumulation) on the bf16 matrix instruction -- fp32-accurate sums, another summation order
+void set_gemm_split_override(int v);       // process-wide: -1 none (every entry point's own choice), 0 / 1 / 2 = all launches of the decode path
+int gemm_split_override();
+int gemm_split_enter(int mode);            // arithmetic of the launches the calling thread enqueues from here on; returns the previous one
+struct SplitScope {                        // ... for the lifetime of a scope (the C-ABI entry points, engine.h: arithmetic_of)
+    int prev;
+    explicit SplitScope(int mode) : prev(gemm_split_enter(mode)) {}
+    ~SplitScope() { gemm_split_enter(prev); }
+    SplitScope(const SplitScope&) = delete; SplitScope& operator=(const SplitScope&) = delete;
+};
 bool gemm_split256_wants(int epi, const GemmArgs& g);
 #ifdef CASV_S2_CLOCK
 void s2_clock_dump();
@@ -182,7 +190,7 @@ void s2_clock_dump();
 void gemm_split_prepare(const float* Bt, int N, int K, hipStream_t stream);    // makes the image of a weight buffer now (ahead of a graph recording)
 void gemm_split_invalidate(const float* Bt);     // drops the pre-split image of a weight buffer (call where it changes or is released); nullptr: all
 bool launch_gemm_split256(int epi, const GemmBatch& b, hipStream_t stream);     // false: not launched (the caller takes another path)
-int gemm_split_bf16();
+int gemm_split_bf16();                     // the calling thread's current arithmetic (SplitScope)
 long gemm_split_epoch();                   // changes whenever the option or a pre-split weight image does (key of captured step graphs)
 void gemm_split_bump_epoch();
 

@@ -134,6 +134,7 @@ struct casv_model {
     // options
     int eos = 1;                                          // vocabulary index of '\n' (seq2seq.py:1255,1344,1402)
     bool use_graph = false;
+    int arith = -1;                                       // option "arithmetic": -1 by entry point (arithmetic_of), 0 fp32-input chain, 1 / 2 split-bf16 everywhere
     bool vendor_gemm = false;                             // calibration only: the train step's plain whole-sequence contractions through hipBLASLt (vendor_gemm.hip)
     bool fused_backward = true;                           // train step: cell backward fused into the step's data GEMM (gemm_bwd.hip)
     const int* skip_nact = nullptr;                       // beam decode: live rows per line, handed to the step's kernels when
@@ -162,6 +163,19 @@ struct casv_model {
     }
 };
 
+
+// Which arithmetic the GEMM launches of a C-ABI call take (gemm.hip).  The rule depends on NOTHING but the
+// entry point -- never on the batch: the decoder steps of the beam search (casv_decode_beam: R = lines x hypotheses rows per step,
+// the GEMM-bound bulk of the path) contract bf16x3-split operands on the bf16 matrix instruction (2); the encoder, the greedy
+// decodes, the explicit decoder step and the train step take the fp32-input instruction's k-ordered chain (0) -- the arithmetic the
+// persistent small-batch kernels are built on.  So a line's bits are a function of (weights, line, entry point) only: they do not
+// change with the batch it sits in, the tile shape, the launch form (persistent or per step) or the shard of a multi-GPU job.
+// A handle's "arithmetic" option (0 / 1 / 2) or the process-wide override put all of them on one arithmetic.
+inline int arithmetic_of(const casv_model* m, bool beam_steps) {
+    const int o = gemm_split_override();
+    const int a = o >= 0 ? o : m->arith;
+    return a >= 0 ? a : (beam_steps ? 2 : 0);
+}
 
 inline int upload(DevBuf& b, const std::vector<float>& v) {
     if (int rc = b.ensure(v.size() * sizeof(float))) return rc;

@@ -189,7 +189,7 @@ static int pack_dec1(casv_model* m, LstmW& dst, const std::string& prefix, int k
 extern "C" int casv_commit_weights(casv_model* m) {
     if (!m) return fail(CASV_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(m->device));
-    for (auto& l : m->dec) gemm_split_invalidate(l.wt.as<float>());          // (split-bf16 experiment: images of the old weights)
+    for (auto& l : m->dec) gemm_split_invalidate(l.wt.as<float>());          // (split arithmetic: images of the old weights)
     gemm_split_invalidate(m->WaT.as<float>()); gemm_split_invalidate(m->E.as<float>());
     for (auto& kv : m->expect)
         if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());
@@ -269,7 +269,7 @@ static void persist_note_abort(casv_model* m, const char* what) {
 static int persist_enc_lds(const casv_model* m) { return 16 * ((m->D >= 2 ? 3 * m->W : 2 * m->W) + 4) * 4; }
 static bool persist_enc_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0 || m->ncu < 64 || m->D > 8) return false;
-    if (gemm_split_bf16()) return false;
+    if (arithmetic_of(m, false)) return false;             // (the persistent kernels are fp32-input kernels)
     const int W = m->W, D = m->D;
     const int per_cu = persist_encode_blocks_per_cu((size_t)persist_enc_lds(m));            // 0: the staged rows do not fit the LDS
     if (per_cu < 1) return false;
@@ -286,6 +286,7 @@ static bool persist_enc_applies(const casv_model* m, int B) {
 // that gave up is redone with the per-step kernels then.  (Waiting here cost every batch of configs[1] a host round trip with the
 // GPU idle between its encoder and its decoder's set-up.)
 static int run_encoder(casv_model* m, bool try_persistent) {
+    SplitScope arithmetic(arithmetic_of(m, false));       // (its own scope: settle_encoder redoes an encoder from inside any entry point)
     const int B = m->B, T = m->T, A = m->A;
     const int W = m->W, C = m->C, D = m->D;
     const size_t BT = (size_t)B * T;
@@ -533,6 +534,7 @@ extern "C" int casv_set_encoder_outputs(casv_model* m, int32_t B, int32_t T, con
     m->B = B; m->T = T; m->A = 1;
     m->last_decode = 0; m->enc_check_pending = false;
     {   // u = attention_dense(enc_out) (seq2seq.py:313,459-460)
+        SplitScope arithmetic(arithmetic_of(m, false));
         GemmArgs g{};
         g.nseg = 1; g.a[0] = mkseg(m->enc_out, C, C, 0);
         g.Bt = m->UT.as<float>(); g.bias = nullptr; g.M = (int)BT; g.N = W; g.Ktot = C;
@@ -726,6 +728,7 @@ extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, 
     for (int r = 0; r < R; ++r) if (line[r] < 0 || line[r] >= m->B) return fail(CASV_ERR_ARG, "line[%d]=%d out of range", r, line[r]);
     HIPCHK(hipSetDevice(m->device));
     if (int rc = settle_encoder(m); rc < 0) return rc;
+    SplitScope arithmetic(arithmetic_of(m, false));
     const int W = m->W, V = m->V, Vp = m->Vp, T = m->T, D = m->D;
     m->last_decode = 0;         // the step overwrites slots 0 and 1 of the stores casv_get_alignments_sparse would read
     if (int rc = ensure_session(m, R, 1)) return rc;
@@ -774,7 +777,7 @@ struct StepRunner {
         if (m->use_graph && !m->prof.on) {
             if (!m->step_exec || m->step_graph_key != key) {
                 drop(m);
-                if (gemm_split_bf16() >= 2) {       // (split-bf16 experiment: the weight images are made ahead of the recording, not inside it)
+                if (gemm_split_bf16() >= 2) {       // (split arithmetic: the weight images are made ahead of the recording, not inside it)
                     const int W = m->W, C = m->C, D = m->D, Vp = m->Vp;
                     for (int n = 1; n <= D; ++n)
                         gemm_split_prepare(m->dec[n].wt.as<float>(), 4 * W, (n == 1 ? Vp : W) + W + (n == D && D > 1 ? C : 0) + (D == 1 ? C : 0), m->stream);
@@ -802,7 +805,7 @@ struct StepRunner {
 // bound by launch and memory latency.  Same results bit for bit (tested), same state / alignment / window stores.
 static bool persist_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0) return false;
-    if (gemm_split_bf16()) return false;        // (split-bf16 experiment: the persistent kernels keep the fp32-input arithmetic -- not mixed with it)
+    if (arithmetic_of(m, false)) return false;   // (the persistent kernels are fp32-input kernels: not mixed with split launches)
     if (m->ncu < 64 || m->D > 8) return false;
     int kmax = m->W;
     for (int n = 1; n <= m->D; ++n) kmax = std::max(kmax, m->dec[n].kin + m->W);
@@ -920,6 +923,7 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (mode != 0 && mode != 1) return fail(CASV_ERR_ARG, "mode must be 0 or 1");
     if (S < 1 || S > 2 * CASV_MAX_T) return fail(CASV_ERR_ARG, "S=%d out of range 1..%d", S, 2 * CASV_MAX_T);
     HIPCHK(hipSetDevice(m->device));
+    SplitScope arithmetic(arithmetic_of(m, false));
     const int B = m->B, T = m->T;
     m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, B, S)) return rc;
@@ -1019,6 +1023,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
         return fail(CASV_ERR_ARG, "search too large: S * batch_size * (beam_width_in + 1) nodes per line overflow int32 (decode fewer lines or steps per call)");
     HIPCHK(hipSetDevice(m->device));
     if (int rc = settle_encoder(m); rc < 0) return rc;
+    SplitScope arithmetic(arithmetic_of(m, true));         // the search's decoder steps: bf16x3-split operands by default (engine.h)
     const int B = m->B, T = m->T, R = B * N, MR = bp->max_results;
     m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, R, S)) return rc;
@@ -1261,6 +1266,7 @@ extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N
     if (!m || !ms_per_launch) return fail(CASV_ERR_ARG, "null argument");
     if (K % 32 || (lstm && N % 128)) return fail(CASV_ERR_ARG, "K must be a multiple of 32 (and N of 128 for lstm)");
     HIPCHK(hipSetDevice(m->device));
+    SplitScope arithmetic(arithmetic_of(m, false));
     DevBuf A, Bt, bias, C, cst, rows;
     if (int rc = A.ensure((size_t)M * K * 4)) return rc;
     if (int rc = Bt.ensure((size_t)N * K * 4)) return rc;
@@ -1281,7 +1287,7 @@ extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N
     GemmArgs g{};
     g.nseg = 1; g.a[0] = mkseg(A.as<float>(), K, K, 0, rows.as<int>());
     g.Bt = Bt.as<float>(); g.bias = bias.as<float>(); g.M = M; g.N = N; g.Ktot = K;
-    g.b_static = 1;         // (split-bf16 experiment: as the decoder's weights; the image is dropped again below)
+    g.b_static = 1;         // (split arithmetic: as the decoder's weights; the image is dropped again below)
     g.out = mkslot(C.as<float>(), lstm ? N / 4 : N);
     if (lstm) { g.c_in = mkseg(cst.as<float>(), N / 4, N / 4, 0, rows.as<int>()); g.c_out = mkslot(cst.as<float>() + (size_t)M * N / 2, N / 4); }
     hipEvent_t e0, e1;
@@ -1309,6 +1315,7 @@ extern "C" int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int3
     if (!m || !A_ || !Bt_ || !C_) return fail(CASV_ERR_ARG, "null argument");
     if (M < 1 || N < 1 || K < 32 || K % 32) return fail(CASV_ERR_ARG, "M, N positive, K a positive multiple of 32");
     HIPCHK(hipSetDevice(m->device));
+    SplitScope arithmetic(arithmetic_of(m, false));
     DevBuf A, Bt, bias, C;
     if (int rc = A.ensure((size_t)M * K * 4)) return rc;
     if (int rc = Bt.ensure((size_t)N * K * 4)) return rc;
@@ -1359,7 +1366,14 @@ extern "C" int casv_set_option(casv_model* m, const char* key, int64_t value) {
         if (value < -1 || value > 2) return fail(CASV_ERR_ARG, "tile must be -1 (by size), 0 (128x128), 1 (32x128) or 2 (64x128 where there is no split-K)");
         set_gemm_tile_mode((int)value); return CASV_OK;
     }
-    if (!strcmp(key, "split_bf16")) { set_gemm_split_bf16((int)value); return CASV_OK; }   // process-wide experiment (gemm.hip)
+    if (!strcmp(key, "arithmetic")) {           // this handle's GEMM arithmetic (engine.h, arithmetic_of)
+        if (value < -1 || value > 2) return fail(CASV_ERR_ARG, "arithmetic must be -1 (by entry point), 0 (fp32-input chain), 1 or 2 (bf16x3-split operands)");
+        m->arith = (int)value; return CASV_OK;
+    }
+    if (!strcmp(key, "split_bf16")) {           // process-wide override of every handle's choice (tests, A/B measurements)
+        if (value < -1 || value > 2) return fail(CASV_ERR_ARG, "split_bf16 must be -1 (no override), 0, 1 or 2");
+        set_gemm_split_override((int)value); return CASV_OK;
+    }
     return fail(CASV_ERR_ARG, "unknown option '%s'", key);
 }
 

@@ -786,17 +786,24 @@ static void launch_one(const GemmBatch& bb, int blocks, int ksplit, hipStream_t 
 
 static int g_tile_mode = [] { const char* e = getenv("CASV_GEMM_TILE"); return e && e[0] >= '0' && e[0] <= '2' && !e[1] ? e[0] - '0' : -1; }();   // -1 by size, 0 = 128x128, 1 = 32x128, 2 = 64x128 where possible
 void set_gemm_tile_mode(int mode) { g_tile_mode = mode; }
-// Experiment (option split_bf16 / CASV_SPLIT_BF16 = 1 or 2; off by default): launches that go as 128x128 tiles contract bf16-split
-// operands on the bf16 matrix instruction (1: gemm_tile's SPLIT variant; 2: as 256x256 tiles, gemm_split.hip, where a job fills
-// the chip that way, else as 1).  Process-wide, like the tile shape.
-static int g_split_bf16 = [] { const char* e = getenv("CASV_SPLIT_BF16"); return e && (e[0] == '1' || e[0] == '2') && !e[1] ? e[0] - '0' : 0; }();
+// Arithmetic of a GEMM launch: 0 = the fp32-input matrix instruction (k-ordered fmaf chain), 1 / 2 = bf16x3-split
+// operands on the bf16 matrix instruction with fp32 accumulation (1: gemm_tile's SPLIT variant, 128x128 tiles; 2: 256x256 tiles,
+// gemm_split.hip, where a job fills the chip that way, else as 1 -- both give the same bits).  WHICH of them a launch takes is
+// decided by the C-ABI entry point that enqueues it (engine.h, arithmetic_of: the handle's "arithmetic" option; by default the beam
+// search's decoder steps take 2 and everything else 0) and announced to the launcher for the calling thread (SplitScope).
+// The process-wide override (option "split_bf16" / CASV_SPLIT_BF16 = 0, 1 or 2 in the environment when the library is loaded)
+// puts EVERY launch of the decode path of every handle on one arithmetic: tests and A/B measurements.
+static int g_split_override = [] { const char* e = getenv("CASV_SPLIT_BF16"); return e && e[0] >= '0' && e[0] <= '2' && !e[1] ? e[0] - '0' : -1; }();
+static thread_local int t_split_bf16 = 0;
 // (a captured step graph bakes in the arithmetic and the addresses of the pre-split weight images: both are part of its key through
 // this counter -- engine.hip, StepRunner)
 static long g_split_epoch = 0;
 long gemm_split_epoch() { return g_split_epoch; }
 void gemm_split_bump_epoch() { ++g_split_epoch; }
-void set_gemm_split_bf16(int on) { const int v = on < 0 ? 0 : on > 2 ? 2 : on; if (v != g_split_bf16) ++g_split_epoch; g_split_bf16 = v; }
-int gemm_split_bf16() { return g_split_bf16; }
+void set_gemm_split_override(int v) { v = v < -1 ? -1 : v > 2 ? 2 : v; if (v != g_split_override) ++g_split_epoch; g_split_override = v; }
+int gemm_split_override() { return g_split_override; }
+int gemm_split_enter(int mode) { const int prev = t_split_bf16; t_split_bf16 = mode < 0 ? 0 : mode > 2 ? 2 : mode; return prev; }
+int gemm_split_bf16() { return t_split_bf16; }
 
 static int count_ktiles(const GemmArgs& g) {
     int ktiles = 0;
@@ -879,7 +886,7 @@ static bool splittable_launch(int epi, const GemmBatch& b) {        // (a launch
 // CASV_TAIL_CUT=0 switches it off (A/B measurements).
 static bool cut_partial_round(int epi, const GemmBatch& b, const GemmPlan& plan, hipStream_t stream) {
     static const bool enabled = [] { const char* e = getenv("CASV_TAIL_CUT"); return !(e && e[0] == '0'); }();
-    if (!enabled || epi != EPI_PLAIN || b.count != 1 || plan.ksplit != 1 || plan.skinny || g_tile_mode >= 0 || g_split_bf16) return false;
+    if (!enabled || epi != EPI_PLAIN || b.count != 1 || plan.ksplit != 1 || plan.skinny || g_tile_mode >= 0 || t_split_bf16) return false;
     const GemmArgs& g = b.g[0];
     if (g.ksplit != -1 || g.step_ptr || g.nact || g.Bimg) return false;
     for (int i = 0; i < g.nseg; ++i) if (g.a[i].rows || g.a[i].skip_first || g.a[i].first_base) return false;    // rows at base + m * ld only
@@ -915,7 +922,7 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     // decode path share ONE arithmetic (128x128 and 256x256 split tiles give the same bits), so that a row's result does not depend
     // on the batch it sits in -- the property the fp32-input kernels have among themselves.  (The train step's per-time-step launches
     // keep the fp32-input small tiles: its persistent recurrences, which they must equal, are fp32-input kernels.)
-    if (g_split_bf16 && skinny && ksplit == 1 && !splittable_launch(epi, b) && !train_launch(b)) skinny = false;
+    if (t_split_bf16 && skinny && ksplit == 1 && !splittable_launch(epi, b) && !train_launch(b)) skinny = false;
     // XCD-aware tile order: minimise (A bytes x column-splits + B bytes x row-splits) over the 8 = xr * xc splits
     GemmBatch bb = b;
     for (int j = 0; j < bb.count; ++j) {
@@ -947,8 +954,8 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     for (int j = 0; j < b.count; ++j)
         if (b.g[j].kgroups != 2 || count_ktiles(b.g[j]) / ksplit < 16) two = false;
     if (blocks * b.count * ksplit > 256) two = false;
-    if (g_split_bf16 && !two) {
-        if (g_split_bf16 >= 2 && ksplit == 1) {
+    if (t_split_bf16 && !two) {
+        if (t_split_bf16 >= 2 && ksplit == 1) {
             // jobs that fill the chip as 256x256 tiles go to gemm_split.hip; the rest of the batch follows as a launch of its own
             GemmBatch big{}, rest{};
             for (int j = 0; j < b.count; ++j) {

@@ -476,6 +476,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     if (B < 1 || T < 1 || U < 1 || A < 1) return fail(CASV_ERR_ARG, "bad shape");
     if (mode < 0 || mode > 2) return fail(CASV_ERR_ARG, "mode must be 0 (evaluate), 1 (train) or 2 (gradients only)");
     HIPCHK(hipSetDevice(m->device));
+    SplitScope arithmetic(arithmetic_of(m, false));       // (engine.h: the train step is fp32-input arithmetic unless the handle or the process says otherwise)
     TrainState* ts = m->train;
     hipStream_t st = m->stream;
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, D = m->D;

@@ -86,6 +86,10 @@ class Sequence2Sequence(object):
         self.logger = logger or logging.getLogger(__name__)
         self.progbars = progbars
         self.device = device
+        # GEMM arithmetic of the device path (csrc/engine.h, arithmetic_of): 'auto' = the beam search's decoder steps contract
+        # bf16x3-split fp32 operands on the bf16 matrix instruction (fp32-accurate sums), everything else -- encoder, greedy
+        # decodes, train step -- the fp32-input instruction; 'fp32' / 'split' = one of the two everywhere.  Never by batch size.
+        self.arithmetic = 'auto'
         self.engine = None
         self.status = 0   # empty / configured / trained (seq2seq.py:179)
         self._weights = None
@@ -433,6 +437,7 @@ class Sequence2Sequence(object):
             self._dirty = False
         self._eos = self.mapping[0].get('\n', 1)
         self.engine.set_option('eos', self._eos)
+        self.engine.set_option('arithmetic', {'auto': -1, 'fp32': 0, 'split': 2}[self.arithmetic])
         return self.engine
 
     def _codepoint_table(self):

@@ -220,8 +220,8 @@ int casv_profile_read(casv_model* m, const char* name, int64_t* launches, double
 int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K, int32_t gather,
                     int32_t iters, double* ms_per_launch);
 /* Test support: ONE plain contraction C (M,N) = A (M,K) . Bt (N,K)^T (+ bias (N) or NULL) on the caller's operands through the
- * launcher every GEMM of the path goes through -- with whatever tile shape ("tile") and arithmetic ("split_bf16") the options
- * select; K a multiple of 32.  flags: 1 = the launcher may split K over workgroups and 2 = over the two wave groups of a
+ * launcher every GEMM of the path goes through -- with whatever tile shape ("tile") and arithmetic ("arithmetic" / "split_bf16";
+ * by entry point: 0) the options select; K a multiple of 32.  flags: 1 = the launcher may split K over workgroups and 2 = over the two wave groups of a
  * workgroup (the forms the train step's contractions take: sums in another order), 4 = Bt counts as a weight (the split-bf16
  * arithmetic keeps a pre-split image of it for the call).  tests/test_gpu_gemm.py compares the result with a float64 product. */
 int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int32_t N, int32_t K, const float* A, const float* Bt,
@@ -244,14 +244,21 @@ int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int32_t N, int3
  * "tile" (process-wide; alias "skinny") = tile shape of the GEMM launches: -1 by size (default), 0 always 128x128,
  * 1 always 32x128, 2 = 64x128 wherever there is no split-K -- a measurement/test switch, the values computed are the same bit
  * for bit;
- * "split_bf16" (process-wide; EXPERIMENT, default 0 = off; also CASV_SPLIT_BF16 in the environment when the library is loaded):
- * 1 / 2 = GEMM launches that go as 128x128 tiles take every fp32 operand value apart into three bf16 values (round to
- * nearest, exact sum) and contract six products per K tile on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (1: as 128x128
- * tiles, csrc/gemm.hip; 2: as 256x256 tiles where a job fills the chip that way, csrc/gemm_split.hip).  fp32-accurate sums
- * at 6/16 of the matrix-pipe time, but another summation order than the fp32-input kernels: results agree with them (and with
- * the oracle, within the tolerances of tests/) to rounding, not bit for bit.  With the option on every GEMM launch of the decode
- * path takes this arithmetic (both tile shapes give the same bits, so a row's result does not depend on its batch) and the
- * persistent small-batch kernels, which keep the fp32-input arithmetic, are not used. */
+ * "arithmetic" (per handle; default -1) = which matrix instruction the handle's GEMM launches run on.  Operands, accumulators and
+ * results are float32 either way.  0 = the fp32-input instruction (v_mfma_f32_32x32x2_f32): every sum is ONE k-ordered fmaf
+ * chain, the arithmetic of all launches up to round 5 and of the persistent small-batch kernels.  1 / 2 = every fp32 operand value
+ * is taken apart into three bf16 values (round to nearest, exact sum) and six products per term are contracted on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (1: as 128x128 tiles, csrc/gemm.hip; 2: as 256x256 tiles where a job fills the
+ * chip that way, csrc/gemm_split.hip -- the same bits from both): all 24 mantissa bits take part, measured error against float64
+ * <= 1.1 x the fp32 chain's (tests/test_gpu_gemm.py), at 6/16 of the matrix-pipe time -- but another summation order, so results
+ * agree with arithmetic 0 (and with the oracle, within the tolerances of tests/) to rounding, not bit for bit.
+ * -1 = BY ENTRY POINT (csrc/engine.h, arithmetic_of): the decoder steps of casv_decode_beam take 2 (R = lines x hypotheses rows
+ * per step: the GEMM-bound bulk of the path); casv_encode / casv_set_encoder_outputs, casv_decode_greedy, casv_decoder_step and
+ * casv_train_step take 0.  The choice never looks at the batch: a line's bits are a function of (weights, line, entry point) --
+ * not of the batch it is decoded in, the tile shape, the launch form (persistent or per step) or the GPU of a sharded job
+ * (tests/test_gpu_arithmetic.py).  With 1 / 2 the persistent small-batch kernels (fp32-input kernels) are not used.
+ * "split_bf16" (process-wide; default -1 = none; also CASV_SPLIT_BF16 = 0 / 1 / 2 in the environment when the library is loaded):
+ * override of every handle's "arithmetic" for all launches of the decode path (tests, A/B measurements). */
 int casv_set_option(casv_model* m, const char* key, int64_t value);
 /* Statistics of the last call (tests): "beam_max_new_keys" = most child hypotheses one line created in one search
  * iteration of the last casv_decode_beam; "beam_sort_capacity" = how many of them are sorted in LDS at once (more are

@@ -18,7 +18,7 @@ def engine():
     try:
         yield eng
     finally:
-        eng.set_option('split_bf16', 0)
+        eng.set_option('split_bf16', -1)
         eng.set_option('tile', -1)
         eng.close()
 
@@ -110,4 +110,4 @@ def test_split_bf16_is_as_accurate_as_the_fp32_chain(engine, K, scale):
             C = engine.debug_contract(A, Bt, bias, weight=weight)
             rms, mx = _errors(C, A, Bt, bias)
             assert rms <= 1.1 * chain[0] and mx <= 1.1 * chain[1], (mode, weight, K, (rms, mx), chain)
-    engine.set_option('split_bf16', 0)
+    engine.set_option('split_bf16', -1)

@@ -1,7 +1,8 @@
-"""The split-bf16 EXPERIMENT (library option `split_bf16`, off by default; csrc/gemm.hip SPLIT variant = mode 1,
-csrc/gemm_split.hip = mode 2) against the oracle, on a real MI355X.
+"""The split-bf16 arithmetic on EVERY GEMM launch of the decode path (process-wide override `split_bf16`; csrc/gemm.hip SPLIT
+variant = mode 1, csrc/gemm_split.hip = mode 2) against the oracle, on a real MI355X.  (By default only the beam search's decoder
+steps take it -- tests/test_gpu_arithmetic.py; here the encoder, the greedy decodes and the explicit decoder step take it too.)
 
-With the option on, the fused LSTM GEMM takes every fp32 operand value apart into three bf16 values and contracts six
+With the override on, the fused LSTM GEMM takes every fp32 operand value apart into three bf16 values and contracts six
 products per K tile on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The sums are fp32-accurate but not the k-ordered
 fmaf chain of the fp32-input kernels, so the comparisons that can hold are the ones with the ORACLE (same tolerances as
 tests/test_gpu_parity.py: indices / strings / counts exact, probabilities and states rtol 2e-4 + atol 2e-6, scores 1e-4);
@@ -23,7 +24,8 @@ from tests import test_gpu_parity as parity
 
 @pytest.fixture
 def split_option():
-    """-> set(mode, tile=-1): switches the process-wide options; both are back at their defaults when the test ends."""
+    """-> set(mode, tile=-1): switches the process-wide options (mode 0 / 1 / 2 = every launch on that arithmetic); both are back at
+    their defaults (-1 = no override) when the test ends."""
     from cor_asv_ann_amd.engine import HipEngine
     eng = HipEngine(1, 32, 8)
 
@@ -33,7 +35,7 @@ def split_option():
     try:
         yield set_
     finally:
-        eng.set_option('split_bf16', 0)
+        eng.set_option('split_bf16', -1)
         eng.set_option('tile', -1)
         eng.close()
 
