@@ -112,7 +112,9 @@ struct casv_model {
     std::vector<LstmW> enc, dec;                         // enc[n] for layer n>=2 at index n; dec[n] n=1..D
     // encoder session
     int B = 0, T = 0, A = 0;
-    bool encoded = false;
+    bool encoded = false;                                 // inputs (casv_encode) or explicit outputs (casv_set_encoder_outputs) are on the device
+    int enc_arith = -1;                                   // arithmetic the encoder outputs on the device were computed in; -1: not computed yet (ensure_encoded)
+    bool enc_explicit = false;                            // the outputs were handed in (casv_set_encoder_outputs): only u = attention_dense(enc_out) is the library's
     DevBuf d_idx, d_val, d_srcrej, x0, H1, Ha, Hb, Hc, cfin, hfin, u;
     float* enc_out = nullptr;
     DevBuf a0; bool has_a0 = false;                       // initial alignment handed in with casv_set_encoder_outputs
@@ -165,11 +167,14 @@ struct casv_model {
 
 
 // Which arithmetic the GEMM launches of a C-ABI call take (gemm.hip).  The rule depends on NOTHING but the
-// entry point -- never on the batch: the decoder steps of the beam search (casv_decode_beam: R = lines x hypotheses rows per step,
-// the GEMM-bound bulk of the path) contract bf16x3-split operands on the bf16 matrix instruction (2); the encoder, the greedy
-// decodes, the explicit decoder step and the train step take the fp32-input instruction's k-ordered chain (0) -- the arithmetic the
-// persistent small-batch kernels are built on.  So a line's bits are a function of (weights, line, entry point) only: they do not
-// change with the batch it sits in, the tile shape, the launch form (persistent or per step) or the shard of a multi-GPU job.
+// entry point -- never on the batch: the beam search (casv_decode_beam: R = lines x hypotheses rows per step, the GEMM-bound bulk
+// of the path) contracts bf16x3-split operands on the bf16 matrix instruction (2) -- its decoder steps AND the encoder pass whose
+// outputs it consumes (casv_encode only stages the input; the encoder runs for the first entry point that needs its outputs, in
+// that entry point's arithmetic, and again if a later one needs the other: engine.hip, ensure_encoded); the greedy decodes, the
+// explicit decoder step, casv_get_encoder_outputs and the train step take the fp32-input instruction's k-ordered chain (0) -- the
+// arithmetic the persistent small-batch kernels are built on.  So a line's bits are a function of (weights, line, entry point)
+// only: they do not change with the batch it sits in, the tile shape, the launch form (persistent or per step), what was decoded
+// from the same encoding before, or the shard of a multi-GPU job.
 // A handle's "arithmetic" option (0 / 1 / 2) or the process-wide override put all of them on one arithmetic.
 inline int arithmetic_of(const casv_model* m, bool beam_steps) {
     const int o = gemm_split_override();

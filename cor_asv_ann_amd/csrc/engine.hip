@@ -269,7 +269,7 @@ static void persist_note_abort(casv_model* m, const char* what) {
 static int persist_enc_lds(const casv_model* m) { return 16 * ((m->D >= 2 ? 3 * m->W : 2 * m->W) + 4) * 4; }
 static bool persist_enc_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0 || m->ncu < 64 || m->D > 8) return false;
-    if (arithmetic_of(m, false)) return false;             // (the persistent kernels are fp32-input kernels)
+    if (m->enc_arith > 0) return false;                    // (the persistent kernels are fp32-input kernels)
     const int W = m->W, D = m->D;
     const int per_cu = persist_encode_blocks_per_cu((size_t)persist_enc_lds(m));            // 0: the staged rows do not fit the LDS
     if (per_cu < 1) return false;
@@ -286,7 +286,7 @@ static bool persist_enc_applies(const casv_model* m, int B) {
 // that gave up is redone with the per-step kernels then.  (Waiting here cost every batch of configs[1] a host round trip with the
 // GPU idle between its encoder and its decoder's set-up.)
 static int run_encoder(casv_model* m, bool try_persistent) {
-    SplitScope arithmetic(arithmetic_of(m, false));       // (its own scope: settle_encoder redoes an encoder from inside any entry point)
+    SplitScope arithmetic(m->enc_arith < 0 ? 0 : m->enc_arith);   // (set by ensure_encoded; its own scope: settle_encoder redoes an encoder from inside any entry point)
     const int B = m->B, T = m->T, A = m->A;
     const int W = m->W, C = m->C, D = m->D;
     const size_t BT = (size_t)B * T;
@@ -442,10 +442,31 @@ static int settle_encoder(casv_model* m, const unsigned* flag = nullptr) {
         HIPCHK(hipStreamSynchronize(m->stream));
     }
     m->enc_check_pending = false;
-    if (!aborted) { m->persist_penalty = 0; return 0; }
+    if (!aborted) { if (!flag) m->persist_penalty = 0; return 0; }      // (with `flag` the caller has a second launch to account for before the back-off is reset)
     persist_note_abort(m, "encoder");
     if (int rc = run_encoder(m, false)) return rc;
     return 1;
+}
+
+// The encoder outputs in the arithmetic of the entry point that is about to consume them (engine.h, arithmetic_of): computed at the
+// first such call after casv_encode / casv_set_encoder_outputs, kept for further calls of the same arithmetic, redone for the other.
+static int ensure_encoded(casv_model* m, int want) {
+    if (m->enc_arith == want) return 0;
+    m->enc_check_pending = false;
+    m->enc_arith = want;
+    if (!m->enc_explicit) {
+        if (int rc = run_encoder(m, true)) { m->enc_arith = -1; return rc; }
+        return 0;
+    }
+    // u = attention_dense(enc_out) on outputs that were handed in (seq2seq.py:313,459-460)
+    SplitScope arithmetic(want);
+    GemmArgs g{};
+    g.nseg = 1; g.a[0] = mkseg(m->enc_out, m->C, m->C, 0);
+    g.Bt = m->UT.as<float>(); g.bias = nullptr; g.M = m->B * m->T; g.N = m->W; g.Ktot = m->C;
+    g.out = mkslot(m->u.as<float>(), m->W);
+    run_gemm(m, EPI_PLAIN, g);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const int32_t* idx, const float* val,
@@ -497,7 +518,9 @@ extern "C" int casv_encode(casv_model* m, int32_t B, int32_t T, int32_t A, const
     m->B = B; m->T = T; m->A = A;
     m->last_decode = 0; m->has_a0 = false;
     m->enc_check_pending = false;
-    if (int rc = run_encoder(m, true)) return rc;
+    // The encoder itself runs for the first entry point that needs its outputs, in that entry point's arithmetic (ensure_encoded):
+    // what a search returns for a line must not depend on whether somebody looked at the encoder outputs or decoded greedily before.
+    m->enc_arith = -1; m->enc_explicit = false;
     m->encoded = true;
     return CASV_OK;
 }
@@ -533,15 +556,7 @@ extern "C" int casv_set_encoder_outputs(casv_model* m, int32_t B, int32_t T, con
     HIPCHK(hipEventSynchronize(m->ev_inputs));
     m->B = B; m->T = T; m->A = 1;
     m->last_decode = 0; m->enc_check_pending = false;
-    {   // u = attention_dense(enc_out) (seq2seq.py:313,459-460)
-        SplitScope arithmetic(arithmetic_of(m, false));
-        GemmArgs g{};
-        g.nseg = 1; g.a[0] = mkseg(m->enc_out, C, C, 0);
-        g.Bt = m->UT.as<float>(); g.bias = nullptr; g.M = (int)BT; g.N = W; g.Ktot = C;
-        g.out = mkslot(m->u.as<float>(), W);
-        run_gemm(m, EPI_PLAIN, g);
-    }
-    HIPCHK(hipGetLastError());
+    m->enc_arith = -1; m->enc_explicit = true;         // u = attention_dense(enc_out) follows in the consumer's arithmetic (ensure_encoded)
     m->encoded = true;
     return CASV_OK;
 }
@@ -550,6 +565,7 @@ extern "C" int casv_get_encoder_outputs(casv_model* m, float* enc_out, float* st
     if (!m) return fail(CASV_ERR_ARG, "null argument");
     if (!m->encoded) return fail(CASV_ERR_STATE, "nothing encoded");
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = ensure_encoded(m, arithmetic_of(m, false))) return rc;
     if (int rc = settle_encoder(m); rc < 0) return rc;
     HIPCHK(hipStreamSynchronize(m->stream));
     const size_t BW = (size_t)m->B * m->W;
@@ -727,6 +743,7 @@ extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, 
     if (R < 1) return fail(CASV_ERR_ARG, "R must be positive");
     for (int r = 0; r < R; ++r) if (line[r] < 0 || line[r] >= m->B) return fail(CASV_ERR_ARG, "line[%d]=%d out of range", r, line[r]);
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = ensure_encoded(m, arithmetic_of(m, false))) return rc;
     if (int rc = settle_encoder(m); rc < 0) return rc;
     SplitScope arithmetic(arithmetic_of(m, false));
     const int W = m->W, V = m->V, Vp = m->Vp, T = m->T, D = m->D;
@@ -923,6 +940,7 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (mode != 0 && mode != 1) return fail(CASV_ERR_ARG, "mode must be 0 or 1");
     if (S < 1 || S > 2 * CASV_MAX_T) return fail(CASV_ERR_ARG, "S=%d out of range 1..%d", S, 2 * CASV_MAX_T);
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = ensure_encoded(m, arithmetic_of(m, false))) return rc;
     SplitScope arithmetic(arithmetic_of(m, false));
     const int B = m->B, T = m->T;
     m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
@@ -972,11 +990,14 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
         const unsigned* flags = pin_flags;
         // a persistent launch whose hand-off wait ran out (its workgroups were not all resident: another process running a
         // persistent kernel on this GPU) loses nothing -- the per-step kernels compute the same values; start over with them
+        const bool enc_was_persistent = m->enc_check_pending;
         const int redone = settle_encoder(m, &flags[0]);
         if (redone < 0) return redone;
         const bool dec_aborted = persistent && flags[1] != 0;
         if (dec_aborted) { persist_note_abort(m, "decoder"); persistent = false; }
-        else if (persistent) m->persist_penalty = 0;
+        // the back-off is reset only by an attempt in which NO persistent launch gave up (an encoder that keeps losing residency
+        // must not restart its penalty at 16 because the decoder behind it happened to run through)
+        if (!redone && !dec_aborted && (persistent || enc_was_persistent)) m->persist_penalty = 0;
         if (!redone && !dec_aborted) break;
         if (attempt >= 2) return fail(CASV_ERR_STATE, "persistent launches keep giving up");
     }
@@ -1022,8 +1043,9 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     if (1LL + (long long)S * N * CM >= (1LL << 31) || (long long)(S + 1) * m->B * N >= (1LL << 31))
         return fail(CASV_ERR_ARG, "search too large: S * batch_size * (beam_width_in + 1) nodes per line overflow int32 (decode fewer lines or steps per call)");
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = ensure_encoded(m, arithmetic_of(m, true))) return rc;
     if (int rc = settle_encoder(m); rc < 0) return rc;
-    SplitScope arithmetic(arithmetic_of(m, true));         // the search's decoder steps: bf16x3-split operands by default (engine.h)
+    SplitScope arithmetic(arithmetic_of(m, true));         // the search: bf16x3-split operands by default (engine.h)
     const int B = m->B, T = m->T, R = B * N, MR = bp->max_results;
     m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, R, S)) return rc;

@@ -1,8 +1,9 @@
 """The arithmetic policy of the device path (csrc/engine.h `arithmetic_of`), on a real MI355X.
 
 Which matrix instruction a GEMM launch runs on is decided by the C-ABI ENTRY POINT that enqueues it and by nothing else:
-the decoder steps of the beam search (casv_decode_beam) contract bf16x3-split fp32 operands on the bf16 matrix instruction with
-fp32 accumulation; the encoder, the greedy decodes and the explicit decoder step run the fp32-input instruction's k-ordered chain.
+the beam search (casv_decode_beam: its decoder steps and the encoder pass it consumes) contracts bf16x3-split fp32 operands on the
+bf16 matrix instruction with fp32 accumulation; the greedy decodes, casv_get_encoder_outputs and the explicit decoder step (and the
+encoder pass THEY consume) run the fp32-input instruction's k-ordered chain.
 The invariant that makes the path shard is the one the fp32-only library had: a line's bits are a function
 of (weights, line, entry point) -- not of the batch it sits in, the tile shape its rows land in (256x256 / 128x128 split tiles,
 64- / 32-row fp32 tiles), the launch form of its encoder (persistent for <= 512 lines, per step above) or the rank that decodes it.
@@ -36,9 +37,10 @@ BEAM_KEYS = ('idx', 'len', 'n_found', 'n_steps', 'score', 'prob')
 
 def test_default_arithmetic_is_chosen_by_the_entry_point(golden_dir):
     """configs[2]'s shape (depth 4, width 512, 1024 lines, N = 8) on three handles: default, fp32-input everywhere, split everywhere.
-    The default handle's encoder and greedy decode are the fp32 handle's bit for bit; its beam search takes the decisions of the
-    fp32 handle's with scores that differ in the sixth digit (it IS the other arithmetic) and equals, bit for bit, a search run
-    with the handle switched to the split arithmetic after an fp32-input encoder."""
+    The default handle's encoder outputs (casv_get_encoder_outputs) and greedy decode are the fp32 handle's bit for bit; its beam
+    search -- encoder pass included: casv_encode only stages the input, the encoder runs for the entry point that consumes it -- is the
+    split handle's bit for bit, takes the decisions of the fp32 handle's and differs from it in the sixth digit of the scores (it IS
+    the other arithmetic).  And what a search returns does not depend on what was done with the same encoding before it."""
     idx, emb = _fixture(golden_dir)
     cfg = ModelConfig(depth=4, width=512, voc_size=256)
     weights = make_weights(cfg, emb_scale=emb)
@@ -54,25 +56,55 @@ def test_default_arithmetic_is_chosen_by_the_entry_point(golden_dir):
         assert np.array_equal(a[k], f[k], equal_nan=True), k
     assert not np.array_equal(a['enc'], s['enc'])                      # (the split handle's encoder is the other arithmetic)
     assert np.allclose(a['enc'], s['enc'], rtol=2e-4, atol=2e-6)
+    for k in BEAM_KEYS:
+        assert np.array_equal(a['beam'][k], s['beam'][k], equal_nan=True), k
     for k in ('idx', 'len', 'n_found', 'n_steps'):
         assert np.array_equal(a['beam'][k], f['beam'][k]), k
-        assert np.array_equal(a['beam'][k], s['beam'][k]), k
     assert np.allclose(a['beam']['score'], f['beam']['score'], rtol=0, atol=1e-5)
     assert not np.array_equal(a['beam']['score'], f['beam']['score'])
-    # fp32-input encoder, then the search on split operands by explicit option: the default handle's search
-    fp32.encode(idx)
-    fp32.set_option('arithmetic', 2)
-    mixed = fp32.decode_beam(batch_size=8)
+    # the search first, straight after casv_encode (above it came third): the same bits; and the greedy decode behind it as well
+    auto.encode(idx)
+    first = auto.decode_beam(batch_size=8)
+    gi, gp, _, _ = auto.decode_greedy()
     for k in BEAM_KEYS:
-        assert np.array_equal(a['beam'][k], mixed[k], equal_nan=True), k
+        assert np.array_equal(a['beam'][k], first[k], equal_nan=True), k
+    assert np.array_equal(gi, a['gi']) and np.array_equal(gp.view(np.int32), a['gp'].view(np.int32))
     for eng in (auto, fp32, split):
         eng.close()
 
 
+def test_explicit_encoder_outputs_follow_the_consumer_too(golden_dir):
+    """casv_set_encoder_outputs (the `encoder_outputs=` argument of decode_sequence_greedy / _beam, seq2seq.py:1305,1382): the one
+    product the library adds to handed-in outputs, u = attention_dense(enc_out), is computed in the consuming entry point's
+    arithmetic -- a search on the outputs of an fp32 encoder pass differs from the default search (whose encoder pass is split) only
+    by rounding, equals itself whatever ran in between, and a greedy decode on them equals the plain greedy decode bit for bit."""
+    idx, emb = _fixture(golden_dir)
+    idx = idx[:96]
+    cfg = ModelConfig(depth=4, width=512, voc_size=256)
+    eng = _engine(cfg, make_weights(cfg, emb_scale=emb))
+    eng.encode(idx)
+    enc, states = eng.encoder_outputs()
+    gi, gp, _, _ = eng.decode_greedy()
+    beam = eng.decode_beam(batch_size=8)
+    i3 = idx[:, :, None]
+    eng.set_encoder_outputs(enc, states, src_rej=eng.source_rejection(i3, np.ones(i3.shape, np.float32)))
+    b1 = eng.decode_beam(batch_size=8)
+    gi2, gp2, _, _ = eng.decode_greedy()
+    b2 = eng.decode_beam(batch_size=8)
+    assert np.array_equal(gi, gi2) and np.array_equal(gp.view(np.int32), gp2.view(np.int32))
+    for k in BEAM_KEYS:
+        assert np.array_equal(b1[k], b2[k], equal_nan=True), k
+    for k in ('idx', 'len', 'n_found', 'n_steps'):
+        assert np.array_equal(b1[k], beam[k]), k
+    assert np.allclose(b1['score'], beam['score'], rtol=0, atol=1e-5)
+    eng.close()
+
+
 def test_default_results_do_not_depend_on_the_batch_at_full_width(golden_dir):
-    """The default policy at configs[2]'s shape: 1024 lines (per-step encoder on 64-row fp32 tiles, search on 256x256 split tiles),
-    their first 600 (another tile grid), 11 from the middle (persistent encoder, 128x128 split tiles) and one line alone: every
-    line's search result -- characters, probabilities, score, step count -- and greedy result is the same bits in all of them."""
+    """The default policy at configs[2]'s shape: 1024 lines (greedy: per-step encoder on 64-row fp32 tiles; search: 256x256 split
+    tiles), their first 600 (another tile grid), 11 from the middle (greedy: persistent encoder and decoder; search: 128x128 split
+    tiles) and one line alone: every line's search result -- characters, probabilities, score, step count -- and greedy result is the
+    same bits in all of them."""
     idx, emb = _fixture(golden_dir)
     cfg = ModelConfig(depth=4, width=512, voc_size=256)
     eng = _engine(cfg, make_weights(cfg, emb_scale=emb))
