@@ -256,18 +256,20 @@ void launch_scatter_rows(const float* src, int src_ld, float* dst, int dst_ld, i
 // n = rows * width.
 struct SmallOp { void* dst; const void* src; long long n; long long src_ld, dst_ld; int width, row_mul; unsigned fill; };
 constexpr int SMALL_OPS_MAX = 28;
+static_assert(SMALL_OPS_MAX >= 10 + 2 * 8 + 2, "the greedy decode's set-up launch takes 10 + 2 * depth operations (depth <= 8) and the encoder's 1 + depth");
 struct SmallOps {
     SmallOp op[SMALL_OPS_MAX]; int count;
+    int dropped;            // operations that did not fit (sticky): launch_small_ops then launches NOTHING and says so
     bool fill(void* dst, size_t bytes, unsigned word = 0u) {
-        if (count >= SMALL_OPS_MAX || (bytes & 3)) return false;
+        if (count >= SMALL_OPS_MAX || (bytes & 3)) { ++dropped; return false; }
         op[count++] = SmallOp{dst, nullptr, (long long)(bytes / 4), 0, 0, 1, 1, word}; return true;
     }
     bool rows(const float* src, long long src_ld, float* dst, long long dst_ld, int nrows, int width, int row_mul) {
-        if (count >= SMALL_OPS_MAX) return false;
+        if (count >= SMALL_OPS_MAX) { ++dropped; return false; }
         op[count++] = SmallOp{dst, src, (long long)nrows * width, src_ld, dst_ld, width, row_mul, 0u}; return true;
     }
 };
-void launch_small_ops(const SmallOps& ops, hipStream_t stream);
+bool launch_small_ops(const SmallOps& ops, hipStream_t stream);    // false: an operation had been dropped (nothing launched)
 
 // ---- beam search (beam_kernels.hip) ----
 struct BeamParams {

@@ -229,12 +229,14 @@ __global__ void small_ops_kernel(const SmallOps ops) {
         }
     }
 }
-void launch_small_ops(const SmallOps& ops, hipStream_t stream) {
-    if (ops.count < 1) return;
+bool launch_small_ops(const SmallOps& ops, hipStream_t stream) {
+    if (ops.dropped) return false;      // (a set-up launch that silently left out a clear or a copy would hand stale memory to what follows)
+    if (ops.count < 1) return true;
     long long most = 0;
     for (int i = 0; i < ops.count; ++i) most = ops.op[i].n > most ? ops.op[i].n : most;
     const int blocks = (int)((most + 4 * 256 - 1) / (4 * 256));           // ~four words per thread for the largest operation
     hipLaunchKernelGGL(small_ops_kernel, dim3(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks, ops.count), dim3(256), 0, stream, ops);
+    return true;
 }
 
 __global__ void scatter_rows_kernel(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,

@@ -167,19 +167,24 @@ struct casv_model {
 
 
 // Which arithmetic the GEMM launches of a C-ABI call take (gemm.hip).  The rule depends on NOTHING but the
-// entry point -- never on the batch: the beam search (casv_decode_beam: R = lines x hypotheses rows per step, the GEMM-bound bulk
-// of the path) contracts bf16x3-split operands on the bf16 matrix instruction (2) -- its decoder steps AND the encoder pass whose
-// outputs it consumes (casv_encode only stages the input; the encoder runs for the first entry point that needs its outputs, in
-// that entry point's arithmetic, and again if a later one needs the other: engine.hip, ensure_encoded); the greedy decodes, the
-// explicit decoder step, casv_get_encoder_outputs and the train step take the fp32-input instruction's k-ordered chain (0) -- the
-// arithmetic the persistent small-batch kernels are built on.  So a line's bits are a function of (weights, line, entry point)
-// only: they do not change with the batch it sits in, the tile shape, the launch form (persistent or per step), what was decoded
-// from the same encoding before, or the shard of a multi-GPU job.
+// entry point -- never on the batch:
+//   ENTRY_SEARCH  casv_decode_beam (R = lines x hypotheses rows per step, the GEMM-bound bulk of the path): bf16x3-split operands on
+//                 the bf16 matrix instruction (2) -- its decoder steps AND the encoder pass whose outputs it consumes (casv_encode only
+//                 stages the input; the encoder runs for the first entry point that needs its outputs, in that entry point's
+//                 arithmetic, and again if a later one needs the other: engine.hip, ensure_encoded);
+//   ENTRY_CHAIN   the greedy decodes, the explicit decoder step, casv_get_encoder_outputs: the fp32-input instruction's k-ordered
+//                 chain (0) -- the arithmetic the persistent small-batch kernels are built on;
+//   ENTRY_TRAIN   casv_train_step: 2 -- the whole-sequence contractions that have a split form (input projections of all time
+//                 steps, their data gradients, logits: gemm_split.hip / gemm.hip's SPLIT tiles) take it; the persistent recurrences,
+//                 the per-time-step launches that must equal them and the K-major weight gradients are fp32-input kernels.
+// So a line's bits are a function of (weights, line, entry point) only: they do not change with the batch it sits in, the tile
+// shape, the launch form (persistent or per step), what was decoded from the same encoding before, or the shard of a multi-GPU job.
 // A handle's "arithmetic" option (0 / 1 / 2) or the process-wide override put all of them on one arithmetic.
-inline int arithmetic_of(const casv_model* m, bool beam_steps) {
+enum { ENTRY_CHAIN = 0, ENTRY_SEARCH = 1, ENTRY_TRAIN = 2 };
+inline int arithmetic_of(const casv_model* m, int entry) {
     const int o = gemm_split_override();
     const int a = o >= 0 ? o : m->arith;
-    return a >= 0 ? a : (beam_steps ? 2 : 0);
+    return a >= 0 ? a : (entry == ENTRY_CHAIN ? 0 : 2);
 }
 
 inline int upload(DevBuf& b, const std::vector<float>& v) {

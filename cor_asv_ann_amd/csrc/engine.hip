@@ -412,7 +412,7 @@ static int run_encoder(casv_model* m, bool try_persistent) {
         for (int n = 2; n <= D; ++n)
             ops.rows(lout[n] + (size_t)(T - 1) * W, (long long)T * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1);
         if (enc_abort_word) ops.rows(reinterpret_cast<const float*>(enc_abort_word), 1, m->d_flags.as<float>(), 1, 1, 1, 1);
-        launch_small_ops(ops, m->stream);
+        if (!launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
     }
     m->enc_check_pending = persistent;
     float* outb = lout[D];
@@ -565,7 +565,7 @@ extern "C" int casv_get_encoder_outputs(casv_model* m, float* enc_out, float* st
     if (!m) return fail(CASV_ERR_ARG, "null argument");
     if (!m->encoded) return fail(CASV_ERR_STATE, "nothing encoded");
     HIPCHK(hipSetDevice(m->device));
-    if (int rc = ensure_encoded(m, arithmetic_of(m, false))) return rc;
+    if (int rc = ensure_encoded(m, arithmetic_of(m, ENTRY_CHAIN))) return rc;
     if (int rc = settle_encoder(m); rc < 0) return rc;
     HIPCHK(hipStreamSynchronize(m->stream));
     const size_t BW = (size_t)m->B * m->W;
@@ -625,8 +625,7 @@ static int init_root(casv_model* m, int rows_per_line, SmallOps ops = SmallOps{}
         ok = ok && ops.rows(m->cfin.as<float>() + (size_t)(n - 1) * B * W, W, m->st_c[n].as<float>(), W, B, W, rows_per_line);
     }
     ok = ok && ops.fill(m->d_step.p, 16) && ops.fill(m->d_nan.p, 16);
-    if (!ok) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
-    launch_small_ops(ops, m->stream);
+    if (!ok || !launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
     return 0;
 }
 
@@ -743,9 +742,9 @@ extern "C" int casv_decoder_step(casv_model* m, int32_t R, const int32_t* line, 
     if (R < 1) return fail(CASV_ERR_ARG, "R must be positive");
     for (int r = 0; r < R; ++r) if (line[r] < 0 || line[r] >= m->B) return fail(CASV_ERR_ARG, "line[%d]=%d out of range", r, line[r]);
     HIPCHK(hipSetDevice(m->device));
-    if (int rc = ensure_encoded(m, arithmetic_of(m, false))) return rc;
+    if (int rc = ensure_encoded(m, arithmetic_of(m, ENTRY_CHAIN))) return rc;
     if (int rc = settle_encoder(m); rc < 0) return rc;
-    SplitScope arithmetic(arithmetic_of(m, false));
+    SplitScope arithmetic(arithmetic_of(m, ENTRY_CHAIN));
     const int W = m->W, V = m->V, Vp = m->Vp, T = m->T, D = m->D;
     m->last_decode = 0;         // the step overwrites slots 0 and 1 of the stores casv_get_alignments_sparse would read
     if (int rc = ensure_session(m, R, 1)) return rc;
@@ -822,7 +821,7 @@ struct StepRunner {
 // bound by launch and memory latency.  Same results bit for bit (tested), same state / alignment / window stores.
 static bool persist_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0) return false;
-    if (arithmetic_of(m, false)) return false;   // (the persistent kernels are fp32-input kernels: not mixed with split launches)
+    if (arithmetic_of(m, ENTRY_CHAIN)) return false;   // (the persistent kernels are fp32-input kernels: not mixed with split launches)
     if (m->ncu < 64 || m->D > 8) return false;
     int kmax = m->W;
     for (int n = 1; n <= m->D; ++n) kmax = std::max(kmax, m->dec[n].kin + m->W);
@@ -928,7 +927,7 @@ static int decode_greedy_persistent(casv_model* m, int mode, int S) {
     {
         SmallOps ops{};
         ops.rows(reinterpret_cast<const float*>(m->p_counters.as<unsigned>() + (size_t)nrb * (D + 3) * 32), 1, m->d_flags.as<float>() + 1, 1, 1, 1, 1);
-        launch_small_ops(ops, m->stream);
+        if (!launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
     }
     return 0;
 }
@@ -940,8 +939,8 @@ extern "C" int casv_decode_greedy(casv_model* m, int32_t mode, int32_t S, int32_
     if (mode != 0 && mode != 1) return fail(CASV_ERR_ARG, "mode must be 0 or 1");
     if (S < 1 || S > 2 * CASV_MAX_T) return fail(CASV_ERR_ARG, "S=%d out of range 1..%d", S, 2 * CASV_MAX_T);
     HIPCHK(hipSetDevice(m->device));
-    if (int rc = ensure_encoded(m, arithmetic_of(m, false))) return rc;
-    SplitScope arithmetic(arithmetic_of(m, false));
+    if (int rc = ensure_encoded(m, arithmetic_of(m, ENTRY_CHAIN))) return rc;
+    SplitScope arithmetic(arithmetic_of(m, ENTRY_CHAIN));
     const int B = m->B, T = m->T;
     m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, B, S)) return rc;
@@ -1043,9 +1042,9 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     if (1LL + (long long)S * N * CM >= (1LL << 31) || (long long)(S + 1) * m->B * N >= (1LL << 31))
         return fail(CASV_ERR_ARG, "search too large: S * batch_size * (beam_width_in + 1) nodes per line overflow int32 (decode fewer lines or steps per call)");
     HIPCHK(hipSetDevice(m->device));
-    if (int rc = ensure_encoded(m, arithmetic_of(m, true))) return rc;
+    if (int rc = ensure_encoded(m, arithmetic_of(m, ENTRY_SEARCH))) return rc;
     if (int rc = settle_encoder(m); rc < 0) return rc;
-    SplitScope arithmetic(arithmetic_of(m, true));         // the search: bf16x3-split operands by default (engine.h)
+    SplitScope arithmetic(arithmetic_of(m, ENTRY_SEARCH));         // the search: bf16x3-split operands by default (engine.h)
     const int B = m->B, T = m->T, R = B * N, MR = bp->max_results;
     m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, R, S)) return rc;
@@ -1137,7 +1136,7 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     {
         SmallOps ops{};
         ops.fill(m->bo_idx.p, OR * S * 4); ops.fill(m->bo_prob.p, OR * S * 4); ops.fill(m->bo_rej.p, OR * S * 4, 0xffffffffu);
-        launch_small_ops(ops, m->stream);
+        if (!launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
     }
 #ifdef CASV_BEAM_PROF
     { HIPCHK(hipStreamSynchronize(m->stream)); casv::beam_prof_dump(m->S); }
@@ -1282,14 +1281,26 @@ extern "C" int casv_profile_read(casv_model* m, const char* name, int64_t* launc
     return fail(CASV_ERR_ARG, "unknown kernel class '%s'", name);
 }
 
+// The operand buffers of the two debug entry points: released on EVERY way out (an early return on a failed allocation or copy
+// must not leak M*K + N*K + M*N floats), behind the stream's work, and the pre-split image a split launch made of Bt with them.
+struct DebugBuffers {
+    std::vector<DevBuf*> bufs; DevBuf* weight; hipStream_t stream;
+    ~DebugBuffers() {
+        (void)hipStreamSynchronize(stream);
+        if (weight && weight->p) gemm_split_invalidate(weight->as<float>());
+        for (DevBuf* b : bufs) b->release();
+    }
+};
+
 // Measurement aid: time `iters` launches of one GEMM shape in isolation (random operands).
 extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K, int32_t gather,
                                int32_t iters, double* ms_per_launch) {
     if (!m || !ms_per_launch) return fail(CASV_ERR_ARG, "null argument");
     if (K % 32 || (lstm && N % 128)) return fail(CASV_ERR_ARG, "K must be a multiple of 32 (and N of 128 for lstm)");
     HIPCHK(hipSetDevice(m->device));
-    SplitScope arithmetic(arithmetic_of(m, false));
+    SplitScope arithmetic(arithmetic_of(m, ENTRY_CHAIN));
     DevBuf A, Bt, bias, C, cst, rows;
+    DebugBuffers release_on_exit{{&A, &Bt, &bias, &C, &cst, &rows}, &Bt, m->stream};
     if (int rc = A.ensure((size_t)M * K * 4)) return rc;
     if (int rc = Bt.ensure((size_t)N * K * 4)) return rc;
     if (int rc = bias.ensure((size_t)N * 4)) return rc;
@@ -1322,11 +1333,9 @@ extern "C" int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N
     float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
     *ms_per_launch = t / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    gemm_split_invalidate(Bt.as<float>());
 #ifdef CASV_S2_CLOCK
     s2_clock_dump();
 #endif
-    A.release(); Bt.release(); bias.release(); C.release(); cst.release(); rows.release();
     return CASV_OK;
 }
 
@@ -1337,8 +1346,9 @@ extern "C" int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int3
     if (!m || !A_ || !Bt_ || !C_) return fail(CASV_ERR_ARG, "null argument");
     if (M < 1 || N < 1 || K < 32 || K % 32) return fail(CASV_ERR_ARG, "M, N positive, K a positive multiple of 32");
     HIPCHK(hipSetDevice(m->device));
-    SplitScope arithmetic(arithmetic_of(m, false));
+    SplitScope arithmetic(arithmetic_of(m, ENTRY_CHAIN));
     DevBuf A, Bt, bias, C;
+    DebugBuffers release_on_exit{{&A, &Bt, &bias, &C}, &Bt, m->stream};
     if (int rc = A.ensure((size_t)M * K * 4)) return rc;
     if (int rc = Bt.ensure((size_t)N * K * 4)) return rc;
     if (int rc = bias.ensure((size_t)N * 4)) return rc;
@@ -1358,8 +1368,6 @@ extern "C" int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int3
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(C_, C.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    gemm_split_invalidate(Bt.as<float>());
-    A.release(); Bt.release(); bias.release(); C.release();
     return CASV_OK;
 }
 

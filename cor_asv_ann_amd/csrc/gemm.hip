@@ -910,6 +910,40 @@ static bool cut_partial_round(int epi, const GemmBatch& b, const GemmPlan& plan,
     return true;
 }
 
+// Split arithmetic, 256x256 tiles (gemm_split.hip: ONE workgroup per CU): a grid of more than one round of workgroups that ends in
+// a partial round -- the page call's 10 240 rows x 2048 gate columns = 320 tiles on 256 CUs: the second round occupies a quarter
+// of the chip for the time of a whole one -- keeps its whole rounds; the rows of the partial round (and a ragged last row block)
+// go as 128x128 split tiles, which contract every element with the same instruction sequence (same bits: tests/test_gpu_split.py).
+// The tail job addresses its rows through offset pointers (no kernel knows about the cut).  false: the job stays as it is.
+static bool split256_cut_rows(int epi, const GemmArgs& g, GemmArgs& head, GemmArgs& tail) {
+    static const bool enabled = [] { const char* e = getenv("CASV_SPLIT_TAIL_CUT"); return !(e && e[0] == '0'); }();
+    static const int ncu = [] { hipDeviceProp_t pr{}; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+    if (!enabled || g.N <= 0 || g.N % 256 || g.M < 256) return false;
+    const int nbn = g.N / 256, nbm = g.M / 256, tiles = nbm * nbn;
+    const int rounds = tiles / ncu, rem = tiles % ncu;
+    int main_bm;
+    if (rounds >= 1 && rem > 0 && rem * 4 <= ncu * 3) main_bm = (rounds * ncu) / nbn;      // (a last round that is three quarters full is left alone)
+    else if (g.M % 256) main_bm = nbm;                                                      // ragged last row block only
+    else return false;
+    if (main_bm < 1 || (long long)main_bm * 256 >= g.M) return false;
+    const int m_off = main_bm * 256;
+    if (g.nact && (g.nact_group <= 0 || m_off % g.nact_group)) return false;
+    head = g; tail = g;
+    head.M = m_off; tail.M = g.M - m_off;
+    auto shift = [&](Seg& sg) {
+        if (!sg.base && !sg.first_base) return;
+        if (sg.rows) sg.rows += m_off; else if (sg.base) sg.base += (long long)m_off * sg.ld;
+        if (sg.first_base) sg.first_base += (long long)m_off * sg.ld;
+    };
+    for (int i = 0; i < g.nseg; ++i) shift(tail.a[i]);
+    shift(tail.c_in);
+    for (SlotPtr* sp : {&tail.out, &tail.c_out, &tail.zinit, &tail.gates_out, &tail.out2})
+        if (sp->base) sp->base += (long long)m_off * sp->ld;
+    if (g.nact) tail.nact += m_off / g.nact_group;
+    (void)epi;
+    return true;
+}
+
 void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
     const GemmPlan plan = plan_gemm(epi, b);
     if (cut_partial_round(epi, b, plan, stream)) return;
@@ -959,8 +993,17 @@ void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream) {
             // jobs that fill the chip as 256x256 tiles go to gemm_split.hip; the rest of the batch follows as a launch of its own
             GemmBatch big{}, rest{};
             for (int j = 0; j < b.count; ++j) {
-                if (gemm_split256_wants(epi, b.g[j])) big.g[big.count++] = b.g[j];
-                else { rest.g[rest.count] = b.g[j]; if (epi == EPI_PLAIN) rest.g[rest.count].epi_plain = 0; ++rest.count; }
+                GemmArgs head = b.g[j], tail{};
+                // (a job whose 256x256 grid ends in a partial round of workgroups, or in a ragged row block: whole rounds here, the
+                // remaining rows as 128x128 split tiles -- the same bits -- in the launch of the rest)
+                const bool cut = split256_cut_rows(epi, b.g[j], head, tail);
+                if (gemm_split256_wants(epi, head)) {
+                    big.g[big.count++] = head;
+                    if (cut && rest.count < GEMM_MAX_JOBS) { rest.g[rest.count++] = tail; continue; }
+                    if (cut) { big.g[big.count - 1] = b.g[j]; }      // (no room for the tail job: the job stays whole)
+                    continue;
+                }
+                rest.g[rest.count] = b.g[j]; if (epi == EPI_PLAIN) rest.g[rest.count].epi_plain = 0; ++rest.count;
             }
             if (big.count && launch_gemm_split256(epi, big, stream)) {
                 if (rest.count) launch_gemm_batch(epi, rest, stream);

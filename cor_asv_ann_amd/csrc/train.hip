@@ -476,7 +476,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     if (B < 1 || T < 1 || U < 1 || A < 1) return fail(CASV_ERR_ARG, "bad shape");
     if (mode < 0 || mode > 2) return fail(CASV_ERR_ARG, "mode must be 0 (evaluate), 1 (train) or 2 (gradients only)");
     HIPCHK(hipSetDevice(m->device));
-    SplitScope arithmetic(arithmetic_of(m, false));       // (engine.h: the train step is fp32-input arithmetic unless the handle or the process says otherwise)
+    SplitScope arithmetic(arithmetic_of(m, ENTRY_TRAIN));       // (engine.h: the whole-sequence contractions with a split form take the bf16x3-split arithmetic)
     TrainState* ts = m->train;
     hipStream_t st = m->stream;
     const int W = m->W, V = m->V, Vp = m->Vp, C = m->C, D = m->D;
@@ -647,7 +647,11 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         HIPCHK(hipStreamSynchronize(st));
         for (int i = ts->rec_checked; i < ts->rec_launches; ++i) {
             any |= gave_up[i] != 0;
-            if (gave_up[i] && i == ts->split_launch) ts->split_off = true;      // (the two launches were not resident together: one launch from now on)
+            if (gave_up[i] && i == ts->split_launch && !ts->split_off) {        // (the two launches were not resident together: one launch from now on)
+                ts->split_off = true;
+                fprintf(stderr, "cor_asv_ann_hip: the two launches of the attention cell's backward were not resident together (serialised "
+                                "dispatch, or the GPU is shared): ONE launch from now on\n");
+            }
         }
         ts->rec_checked = ts->rec_launches;
         if (any) {
@@ -716,7 +720,22 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
                 m->prof_begin(PC_PERSIST, 2.0 * B * U * ((double)4 * W * (C + W) + (double)W * W), 0.0, ev);
                 // the attention backward of the samples as a launch of its own on a second stream, resident beside the big one: it
                 // then runs under the h tiles instead of behind them (CASV_TOPB_SPLIT=0: one launch)
-                static const bool split_opt = [] { const char* e = getenv("CASV_TOPB_SPLIT"); return !(e && e[0] == '0'); }();
+                // Two launches that hand rows to each other must be resident TOGETHER: where the runtime serialises kernel dispatch
+                // (rocprofv3 --pmc sets ROCPROF_COUNTERS; AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING) the side launch would never see
+                // the main one's counters -- one launch there, said once on stderr (profiles taken that way describe that form).
+                static const bool split_opt = [] {
+                    const char* e = getenv("CASV_TOPB_SPLIT");
+                    if (e && e[0] == '0') return false;
+                    auto on = [](const char* name) { const char* v = getenv(name); return v && v[0] && !(v[0] == '0' && !v[1]); };
+                    const char* why = getenv("ROCPROF_COUNTERS") ? "ROCPROF_COUNTERS (counter collection)" : on("AMD_SERIALIZE_KERNEL") ? "AMD_SERIALIZE_KERNEL" :
+                                      on("HIP_LAUNCH_BLOCKING") ? "HIP_LAUNCH_BLOCKING" : nullptr;
+                    if (why && !(e && e[0] == '1')) {       // (CASV_TOPB_SPLIT=1 insists)
+                        fprintf(stderr, "cor_asv_ann_hip: kernel dispatch is serialised (%s): the attention cell's backward runs as ONE launch "
+                                        "(the two-launch form needs both resident together)\n", why);
+                        return false;
+                    }
+                    return true;
+                }();
                 ra.split_a = split_opt && !ts->split_off && train_attention_cell_bwd_rows_fit(ra) ? 1 : 0;
                 if (ra.split_a && !ts->side) {          // (no second stream to be had: one launch, as before)
                     if (hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ts->side = nullptr; }

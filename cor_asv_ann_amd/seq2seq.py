@@ -652,7 +652,7 @@ class Sequence2Sequence(object):
         closing, in_call = threading.Event(), threading.Event()
 
         def decoded():
-            for k, (lines, prep) in enumerate(prefetch(prepared(), depth=2, cancel=closing)):
+            for k, (lines, prep) in enumerate(prefetch(prepared(), depth=2, cancel=closing, detach_after=5.0)):
                 if closing.is_set():            # (the consumer has left: no further call on the engine)
                     return
                 in_call.set()
@@ -671,7 +671,7 @@ class Sequence2Sequence(object):
         # is pure Python and gives the lock up once per switch interval (5 ms by default: up to half a millisecond of idle GPU
         # between two batches of configs[1], rocprofv3 trace of round 4).  A short interval while THIS generator runs -- not
         # while it is suspended at a yield or abandoned: the setting is process-wide (_ShortSwitchInterval counts its users).
-        stage = prefetch(decoded(), depth=1, in_call=in_call)
+        stage = prefetch(decoded(), depth=1, in_call=in_call, detach_after=5.0)
         try:
             while True:
                 with _ShortSwitchInterval():

@@ -10,16 +10,18 @@ import numpy as np
 from . import keras_h5
 
 
-def prefetch(iterable, depth=2, cancel=None, in_call=None, detach_after=5.0):
+def prefetch(iterable, depth=2, cancel=None, in_call=None, detach_after=None):
     """Run `iterable` in a worker thread, `depth` items ahead of the consumer -- the reference feeds `train_on_batch` from a
     `GeneratorEnqueuer` worker (keras_train.py:133-145) so that vectorising the next batch overlaps the device step; here the
     C ABI call releases the GIL for the whole step, so a thread does.  Exceptions of the producer surface in the consumer;
     a consumer that stops early (NaN loss, stop signal) releases the producer.
 
-    Leaving early: the worker is joined.  While `in_call` (an Event the producer sets around its C-ABI calls) is set the
-    wait is unbounded -- the caller must not get the engine back while a call runs on it, the handle is not thread-safe --;
-    a worker that is merely blocked in `next(iterable)` (a user generator reading a pipe, a nested stage) is left behind
-    after `detach_after` seconds (a daemon thread; its next put() sees `stop`).  `cancel`: an Event of the caller that ends
+    Leaving early: the worker is joined, however long its current `next(iterable)` takes (the default: train()'s producers draw
+    from the model's random generator and read its state -- a worker left behind would keep doing so beside whatever the caller
+    does next).  Stages whose producer may block for good on something outside this process (correct_batches: a user generator
+    reading a pipe, a nested stage) pass `detach_after`: such a worker is left behind after that many seconds (a daemon thread; its
+    next put() sees `stop`) -- except while `in_call` (an Event the producer sets around its C-ABI calls) is set: the caller must
+    not get the engine back while a call runs on it, the handle is not thread-safe.  `cancel`: an Event of the caller that ends
     the consumer loop as well (a nested stage's consumer is another stage's worker: it must not sit in q.get() for good)."""
     q = queue.Queue(maxsize=max(1, depth))
     done, stop = object(), threading.Event()
@@ -69,7 +71,7 @@ def prefetch(iterable, depth=2, cancel=None, in_call=None, detach_after=5.0):
             if in_call is not None and in_call.is_set():
                 continue                        # a device call of the worker is in flight: wait it out, however long it takes
             waited += 0.1
-            if waited >= detach_after:
+            if detach_after is not None and waited >= detach_after:
                 break
 
 

@@ -38,7 +38,11 @@ def main():
     out = {'hbm_bytes_per_launch': total, 'unit_of_launch': 'one bench step (all kernels)', 'steps_profiled': steps, 'kernels': kernels,
            'round': int(os.environ.get('CASV_PROFILE_ROUND', '0')) or None, 'commit': os.environ.get('CASV_PROFILE_COMMIT'),
            'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH doubled for kernels whose reads are 16 B per lane '
-                   '(the gfx950 correction), other kernels as read'}
+                   '(the gfx950 correction), other kernels as read',
+           # counter collection serialises kernel dispatch: launches that must be resident TOGETHER take their one-launch form under it
+           # (the train step's attention-cell backward: csrc/train.hip says so on stderr) -- the bytes are that form's
+           'launch_forms': 'as under serialised dispatch (ROCPROF_COUNTERS set): the attention cell backward of the train step as ONE launch, '
+                           'not the two co-resident launches of an unprofiled run'}
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), outname), 'w') as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != 'kernels'}))

@@ -93,6 +93,24 @@ def test_plain_contraction_equals_float64_to_rounding(engine, M, N, K):
         assert np.array_equal(first, C), 'tile shape %d changes the bits' % tile
 
 
+@pytest.mark.parametrize('M', [10240, 10300, 16640, 8448, 300])
+def test_split_tile_shapes_and_the_partial_round_cut_give_the_same_bits(engine, M):
+    """The split arithmetic's two tile shapes contract an element with the same instruction sequence, so a launch may mix them:
+    256x256 tiles for the whole rounds of workgroups, 128x128 tiles for the rows of a partial last round (the page call: 10 240 rows
+    x 2048 columns = 320 tiles on 256 CUs) or a ragged last row block (gemm.hip, split256_cut_rows).  Mode 2 (with the cut) equals
+    mode 1 (128x128 tiles only) bit for bit, and float64 to rounding."""
+    N, K = 2048, 768
+    A, Bt, bias = _operands(M, N, K, seed=M)
+    engine.set_option('split_bf16', 1)
+    one = engine.debug_contract(A, Bt, bias, weight=True)
+    engine.set_option('split_bf16', 2)
+    two = engine.debug_contract(A, Bt, bias, weight=True)
+    engine.set_option('split_bf16', -1)
+    assert np.array_equal(one, two)
+    rms, mx = _errors(two, A, Bt, bias)
+    assert rms < RMS_BOUND and mx < MAX_BOUND, (rms, mx)
+
+
 @pytest.mark.parametrize('K', [768, 1024, 1536])
 @pytest.mark.parametrize('scale', [1.0, 37.0])
 def test_split_bf16_is_as_accurate_as_the_fp32_chain(engine, K, scale):

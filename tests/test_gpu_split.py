@@ -111,6 +111,29 @@ def test_split_and_fp32_kernels_take_the_same_decisions(split_option, golden_dir
         assert np.array_equal(outs[1][k], outs[2][k], equal_nan=True), k
 
 
+@pytest.mark.parametrize('B,N', [(40, 256), (103, 100)])
+def test_partial_round_of_a_wide_search_goes_as_small_split_tiles_with_the_same_bits(B, N, split_option):
+    """The OCR-D page call's shape (depth 2, width 512, 40 lines x 256 hypotheses = 10 240 rows per step: 320 tiles of 256x256 on
+    256 CUs) and a ragged one (103 x 100 = 10 300 rows): under mode 2 the rows of the partial round go as 128x128 split tiles
+    (gemm.hip, split256_cut_rows; the gathered state rows, the cell state, the outputs and the live-row counts of the tail job
+    through offset pointers) -- the whole search returns the bits of mode 1, where every launch is 128x128 tiles."""
+    from cor_asv_ann_amd.engine import HipEngine
+    from oracle import make_lines
+    cfg = ModelConfig(depth=2, width=512, voc_size=96)
+    _, idx = make_lines(B, 14, 31, voc_size=96)
+    eng = HipEngine(cfg.depth, cfg.width, cfg.voc_size)
+    eng.set_weights(make_weights(cfg, emb_scale=64.0))
+    outs = []
+    for mode in (1, 2):
+        split_option(mode)
+        eng.encode(idx)
+        outs.append(eng.decode_beam(batch_size=N, beam_width_in=15, rejection_threshold=0.5))
+    eng.close()
+    assert outs[0]['n_steps'].max() > 3
+    for k in ('idx', 'len', 'n_found', 'n_steps', 'score', 'prob'):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+
+
 def test_split_kernels_do_not_depend_on_what_else_runs_on_the_gpu(split_option, golden_dir):
     """Two model handles decode the configs[2]-shaped fixture at the same time on two streams (the 256x256 split kernel wants the
     whole LDS of a CU and hands tiles over through LDS-DMA: foreign workgroups in between must change nothing), and a third run

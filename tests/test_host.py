@@ -259,6 +259,28 @@ def test_batch_prefetch_runs_ahead_keeps_order_and_hands_errors_over():
     assert not any(t.name == 'casv-batch-prefetch' and t.is_alive() for t in threading.enumerate())
 
 
+def test_prefetch_joins_its_worker_by_default():
+    """without `detach_after` (train()'s stages: their producers draw from the model's shared random generator) a
+    consumer that leaves early waits for the worker, however slow its current next() is -- no thread is left behind."""
+    import threading
+    import time
+    from cor_asv_ann_amd.training import prefetch
+    state = {'after_close': False, 'closed': False}
+
+    def slow():
+        yield 0
+        time.sleep(0.8)                     # "loads a pickle at epoch start"
+        state['after_close'] = state['closed']
+        yield 1
+
+    gen = prefetch(slow(), depth=1)
+    assert next(gen) == 0
+    gen.close()
+    state['closed'] = True
+    assert not any(t.name == 'casv-batch-prefetch' and t.is_alive() for t in threading.enumerate())
+    assert state['after_close'] is False    # the producer's slow step ended BEFORE close() returned
+
+
 def test_prefetch_leaves_a_blocked_producer_behind_but_waits_for_a_device_call():
     """a consumer that leaves early must not hang on a worker that is blocked in next(iterable) (a user
     generator reading a pipe, a nested stage waiting on q.get()), but it must wait as long as it takes while the worker is
