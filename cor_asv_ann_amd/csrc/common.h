@@ -197,6 +197,7 @@ void gemm_split_bump_epoch();
 // ---- small kernels (decode_kernels.hip) ----
 struct AttnArgs {
     const float* wq;        // [R][W]  h_d . W_a + b_UW
+    const int* wq_rows;     // optional [R]: row r's query is row wq_rows[r] of `wq` (beam search: the query of the parent expansion, computed once per expansion)
     const float* u;         // [B][T][W]
     const float* enc;       // [B][T][C]
     const float* va;        // [W]

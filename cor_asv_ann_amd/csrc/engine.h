@@ -122,6 +122,7 @@ struct casv_model {
     int R = 0, S = 0;
     std::vector<DevBuf> st_h, st_c;
     DevBuf st_a, st_p, ctx, wq, logits, prev, pin, apos, amax1, d_step, d_line, d_nan;
+    DevBuf st_q;                                          // beam search: the attention query of every expansion, [(S+1)*R][W] (engine.hip, launch_step)
     DevBuf o_idx, o_prob, o_align, st_win, sp_lo, sp_w;
     // what the last decode call left on the device (casv_get_alignments_sparse): 0 nothing, 1 greedy, 2 beam
     int last_decode = 0, last_S = 0, last_rows = 0, last_mode = 0; unsigned long long last_signature = 0;

@@ -67,7 +67,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     DevBuf* bufs[] = {&m->E, &m->WaT, &m->bUW, &m->va, &m->bv, &m->UT, &m->enc_fw.wt, &m->enc_fw.bias,
         &m->enc_bw.wt, &m->enc_bw.bias, &m->d_idx, &m->d_val, &m->d_srcrej, &m->x0, &m->H1, &m->Ha, &m->Hb, &m->Hc, &m->cfin,
         &m->hfin, &m->u, &m->st_a, &m->st_p, &m->ctx, &m->wq, &m->logits, &m->prev, &m->pin, &m->apos, &m->amax1,
-        &m->d_step, &m->d_line, &m->d_nan, &m->o_idx, &m->o_prob, &m->o_align, &m->a0, &m->rec, &m->st_win, &m->sp_lo, &m->sp_w, &m->b_parent, &m->b_chr, &m->b_prob,
+        &m->d_step, &m->d_line, &m->d_nan, &m->st_q, &m->o_idx, &m->o_prob, &m->o_align, &m->a0, &m->rec, &m->st_win, &m->sp_lo, &m->sp_w, &m->b_parent, &m->b_chr, &m->b_prob,
         &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos, &m->b_pos, &m->b_is1, &m->b_count, &m->b_created,
         &m->b_gkey, &m->b_gid, &m->b_qkey, &m->b_qid, &m->b_qn, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_beamnode, &m->b_nact,
         &m->b_done, &m->b_steps, &m->b_active, &m->bo_idx, &m->bo_prob, &m->bo_len, &m->bo_score,
@@ -583,7 +583,7 @@ extern "C" int casv_get_encoder_outputs(casv_model* m, float* enc_out, float* st
 // raw pointers kept in last_beam): changes whenever one of them has been reallocated.
 static unsigned long long decode_buffers_signature(const casv_model* m) {
     unsigned long long h = 1469598103934665603ull;
-    for (const DevBuf* b : {&m->st_a, &m->st_win, &m->b_parent, &m->b_chr, &m->b_prob, &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos,
+    for (const DevBuf* b : {&m->st_a, &m->st_q, &m->st_win, &m->b_parent, &m->b_chr, &m->b_prob, &m->b_cum, &m->b_len, &m->b_exp, &m->b_k, &m->b_rejpos,
                             &m->b_count, &m->b_fkey, &m->b_fid, &m->b_fn, &m->b_ftotal, &m->b_created, &m->bo_idx, &m->bo_prob, &m->bo_len,
                             &m->bo_score, &m->o_idx, &m->o_prob, &m->d_idx, &m->d_val})
         h = (h ^ (unsigned long long)(uintptr_t)b->p) * 1099511628211ull;
@@ -653,10 +653,15 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
     auto xwidth = [&](int n) { return n == 1 ? Vp : W; };
     // attention query of this step: h_{t-1} . W_a + b_UW (attention.py:539) -- depends only on the previous step, so it
     // shares the launch of layer 1 (a job with the plain epilogue) instead of waiting behind the lower layers
+    // The beam search computes it AHEAD, once per expansion instead of once per child row: the query of step s + 1's rows is a
+    // function of their parent's h_D alone, so it rides in step s's output projection (same A operand: the new h_D rows, ungathered)
+    // into a store indexed like the state stores, and the attention rows fetch their parent's query through `prev` -- one launch
+    // less per step (the same contraction per row: the same bits).
+    const bool query_ahead = beam;
     GemmArgs gq{};
-    gq.nseg = 1; gq.a[0] = hseg(m->st_h[D].as<float>(), 0);
+    gq.nseg = 1; gq.a[0] = query_ahead ? mkseg(m->st_h[D].as<float>(), W, W, 0, nullptr, RW, 1, 1) : hseg(m->st_h[D].as<float>(), 0);
     gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W; gq.b_static = 1;
-    gq.out = mkslot(m->wq.as<float>(), W);
+    gq.out = query_ahead ? mkslot(m->st_q.as<float>(), W, RW, 1, 1) : mkslot(m->wq.as<float>(), W);
     gq.step_ptr = step_ptr; gq.step_imm = step_imm;
     gq.nact = live; gq.nact_group = m->skip_group;
     auto lower = [&](int n) {               // layer n < D on [x | h]
@@ -675,14 +680,16 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
     };
     if (D >= 2) {
         GemmBatch b{};
-        b.g[0] = lower(1); b.g[1] = gq; b.g[1].epi_plain = 1; b.count = 2;
+        b.g[0] = lower(1); b.count = 1;
+        if (!query_ahead) { b.g[1] = gq; b.g[1].epi_plain = 1; b.count = 2; }
         run_gemm_batch(m, EPI_LSTM, b);
-    } else {
+    } else if (!query_ahead) {
         run_gemm(m, EPI_PLAIN, gq);
     }
     {   // the attention rows need only the query: ahead of the remaining layers, which can then share one launch
         AttnArgs a{};
-        a.wq = m->wq.as<float>(); a.u = m->u.as<float>(); a.enc = m->enc_out; a.va = m->va.as<float>(); a.bv = m->bv.as<float>();
+        a.wq = query_ahead ? m->st_q.as<float>() : m->wq.as<float>(); a.wq_rows = query_ahead ? prev : nullptr;
+        a.u = m->u.as<float>(); a.enc = m->enc_out; a.va = m->va.as<float>(); a.bv = m->bv.as<float>();
         a.a_base = m->st_a.as<float>(); a.prev = prev; a.line = line; a.rows_per_line = rows_per_line;
         a.ctx = m->ctx.as<float>(); a.R = R; a.T = T; a.W = W; a.C = C; a.window = m->cfg.window_width;
         a.step_ptr = step_ptr; a.step_imm = step_imm; a.apos = m->apos.as<double>(); a.amax1 = m->amax1.as<int>(); a.nrows = nullptr;
@@ -719,7 +726,11 @@ static void launch_step(casv_model* m, bool beam, int mode, const int* line, int
         g.out = mkslot(m->logits.as<float>(), Vp);
         g.step_ptr = step_ptr; g.step_imm = step_imm;
         g.nact = live; g.nact_group = m->skip_group;
-        run_gemm(m, EPI_PLAIN, g);
+        if (query_ahead) {
+            GemmBatch b{};
+            b.g[0] = g; b.g[1] = gq; b.count = 2;
+            run_gemm_batch(m, EPI_PLAIN, b);
+        } else run_gemm(m, EPI_PLAIN, g);
     }
     if (softmax) {       // (the beam step kernel computes the rows it reads itself)
         SoftmaxArgs a{};
@@ -1048,7 +1059,16 @@ extern "C" int casv_decode_beam(casv_model* m, const casv_beam_params* bp, int32
     const int B = m->B, T = m->T, R = B * N, MR = bp->max_results;
     m->last_decode = 0;         // until this call has succeeded there is nothing to take alignments from
     if (int rc = ensure_session(m, R, S)) return rc;
+    if (int rc = m->st_q.ensure((size_t)(S + 1) * R * m->W * 4)) return rc;
     if (int rc = init_root(m, N)) return rc;
+    {   // the root expansions' attention query (slot 0: the encoder's final h_D), as every later step's output projection leaves it
+        const int W = m->W, D = m->D;
+        GemmArgs gq{};
+        gq.nseg = 1; gq.a[0] = mkseg(m->st_h[D].as<float>(), W, W, 0);
+        gq.Bt = m->WaT.as<float>(); gq.bias = m->bUW.as<float>(); gq.M = R; gq.N = W; gq.Ktot = W; gq.b_static = 1;
+        gq.out = mkslot(m->st_q.as<float>(), W);
+        run_gemm(m, EPI_PLAIN, gq);
+    }
     BeamState s{};
     s.B = B; s.T = T; s.V = m->V; s.S = S; s.R = R;
     s.node_cap = 1 + S * N * CM; s.q_cap = 2 * T * N; s.f_cap = 64; s.g_cap = N * CM;

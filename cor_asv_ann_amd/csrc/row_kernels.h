@@ -104,7 +104,7 @@ __device__ __forceinline__ void att_energy_sums(const AttnArgs& a, const int r, 
                                                 float (&e)[MAXWIN]) {
     const int W = a.W;
     const int s_lo = w.s_lo;
-    const float4* wq4 = reinterpret_cast<const float4*>(a.wq + (long long)r * W);
+    const float4* wq4 = reinterpret_cast<const float4*>(a.wq + (long long)(a.wq_rows ? a.wq_rows[r] : r) * W);
     const float4* va4 = reinterpret_cast<const float4*>(a.va);
     const int W4 = W >> 2;
     // The kernel is latency-bound (one decoder row per wave slot), so all window rows are requested

@@ -723,7 +723,7 @@ class Sequence2Sequence(object):
         # lines are independent, so chunking does not change any result.
         # plus the trie: up to min(beam_width_in, V) + 1 child records of 60 bytes per expansion
         children = min(self.beam_width_in, self.voc_size) + 1
-        per_line = 2 * T * self.batch_size * ((2 * self.depth * self.width + self.voc_size + 32 + T) * 4 + 60 * children)
+        per_line = 2 * T * self.batch_size * (((2 * self.depth + 1) * self.width + self.voc_size + 32 + T) * 4 + 60 * children)
         budget = float(os.environ.get('CASV_BEAM_MEMORY_GB', '96')) * 2 ** 30
         chunk = int(max(1, min(B, budget // max(per_line, 1))))
         out = []

@@ -17,7 +17,7 @@
  * hypotheses per line and step (batch_size) <= 1024, beam_width_in >= 1 (values above the vocabulary size act like
  * the vocabulary size), at most 64 results per line, and S * batch_size * (min(beam_width_in, V) + 1) < 2^31
  * hypotheses per line.  A search keeps every expansion's state on the device: casv_decode_beam needs about
- * 2T * batch_size * (8 * depth * width + 4 * (V + T) + 60 * (beam_width_in + 1)) bytes per line
+ * 2T * batch_size * ((8 * depth + 4) * width + 4 * (V + T) + 60 * (beam_width_in + 1)) bytes per line
  * (CASV_ERR_NOMEM if the device cannot hold them -- decode fewer lines per call; the Python facade does that).  A handle is bound to one HIP device and is not
  * thread-safe (the reference runs single-threaded: wrapper/transcode.py:46 max_workers=1).
  * No C++ exceptions and no callbacks cross this boundary.
