@@ -517,7 +517,7 @@ def train_bench(args):
         t1 = cpu_step(2)                                          # warm-up; sizes the sample
         n = int(max(2, min(64, args.cpu_budget / 2.0 / max(t1 / 2, 1e-6))))
         best = min(cpu_step(n) for _ in range(2))
-        cpu = {'value': n * LENGTH / best, 'unit': 'chars/s', 'cores': host_threads(), 'kind': 'port',
+        cpu = {'value': n * LENGTH / best, 'unit': 'chars/s', 'cores': min(host_threads(), host_cores()), 'kind': 'port',
                'sample': 'best of 2 train steps of the numpy fp32 oracle (forward, BPTT, clip, Adam) on the first %d lines of the same batch, %.1f s per step' % (n, best)}
     traffic, traffic_source = None, None        # HBM-side bytes per train step: a committed constant from PMC passes, not measured by this run
     try:

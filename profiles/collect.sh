@@ -34,8 +34,9 @@ for what in $WHAT; do
     python3 profiles/pmc_traffic.py $(f c3_fetch) $(f c3_write) gemm_split256_kernel split256_gemm_traffic.json 2 > $OUT/c3_traffic.txt 2>&1
     python3 profiles/pmc_traffic.py $(f page_fetch) $(f page_write) gemm_split256_kernel page_split_gemm_traffic.json 2 > $OUT/page_traffic.txt 2>&1
     python3 profiles/pmc_traffic.py $(f c2_fetch) $(f c2_write) persist_ persist_decode_traffic.json 1 > $OUT/c2_traffic.txt 2>&1
-    python3 profiles/pmc_traffic_step.py $(f c4_fetch) $(f c4_write) 2 c4_step_traffic.json gemm_ > $OUT/c4_traffic.txt 2>&1
+    python3 profiles/pmc_traffic_step.py $(f c4_fetch) $(f c4_write) 3 c4_step_traffic.json gemm_ > $OUT/c4_traffic.txt 2>&1
     cat $OUT/*_traffic.txt
+    cp profiles/split256_gemm_traffic.json profiles/page_split_gemm_traffic.json profiles/persist_decode_traffic.json profiles/c4_step_traffic.json $OUT/   # (only gpurun_out travels back)
   fi
 done
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
