@@ -3,6 +3,7 @@
 // little helpers that move per-step state.  One 64-lane wave owns one decoder row throughout, so all
 // row reductions are DPP/shuffle butterflies with a fixed order (results do not depend on batch size).
 #include "common.h"
+#include <algorithm>
 #include "row_kernels.h"
 #include <math.h>
 
@@ -237,6 +238,26 @@ bool launch_small_ops(const SmallOps& ops, hipStream_t stream) {
     const int blocks = (int)((most + 4 * 256 - 1) / (4 * 256));           // ~four words per thread for the largest operation
     hipLaunchKernelGGL(small_ops_kernel, dim3(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks, ops.count), dim3(256), 0, stream, ops);
     return true;
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<float4*>(dst)[i]; const float4 b = reinterpret_cast<const float4*>(src)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        reinterpret_cast<float4*>(dst)[i] = a;
+    }
+}
+void launch_add_inplace(float* dst, const float* src, long long n, hipStream_t stream) {
+    const long long n4 = n / 4;                  // (callers pass multiples of the hidden width: a multiple of 32)
+    const int blocks = (int)std::min<long long>((n4 + 255) / 256, 4096);
+    if (n4 > 0) hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, n4);
+}
+__global__ void tanh_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = fast_tanh(src[i]);
+}
+void launch_tanh(const float* src, float* dst, long long n, hipStream_t stream) {
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    if (n > 0) hipLaunchKernelGGL(tanh_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n);
 }
 
 __global__ void scatter_rows_kernel(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,

@@ -23,6 +23,12 @@ static std::map<std::string, size_t> expected_shapes(const casv_config& c) {
     m["att_Wa"] = W * W; m["att_va"] = W; m["att_bUW"] = W; m["att_bv"] = 1;
     const std::string p = "dec" + std::to_string(D);
     m[p + "_K"] = (W + C) * 4 * W; m[p + "_R"] = W * 4 * W; m[p + "_b"] = 4 * W;
+    if (c.bridge_dense)          // Dense(width, tanh) on the final h / c of every encoder layer (seq2seq.py:299-301)
+        for (size_t n = 1; n <= D; ++n)
+            for (const char* s : {"h", "c"}) {
+                const std::string b = "bridge" + std::to_string(n) + "_" + s;
+                m[b + "_K"] = W * W; m[b + "_b"] = W;
+            }
     return m;
 }
 
@@ -32,9 +38,8 @@ extern "C" int casv_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) !=
 
 extern "C" int casv_model_create(const casv_config* cfg, int device_id, casv_model** out) {
     if (!cfg || !out) return fail(CASV_ERR_ARG, "null argument");
-    if (cfg->residual_connections || cfg->deep_bidirectional_encoder || cfg->bridge_dense || cfg->lm || cfg->stateful)
-        return fail(CASV_ERR_ARG, "only the default topology is implemented (residual_connections, "
-                    "deep_bidirectional_encoder, bridge_dense, lm_loss/lm_predict, stateful must be off)");
+    if (cfg->deep_bidirectional_encoder || cfg->lm || cfg->stateful)
+        return fail(CASV_ERR_ARG, "deep_bidirectional_encoder, lm_loss/lm_predict and stateful are not implemented (must be off)");
     if (cfg->depth < 1 || cfg->depth > 8) return fail(CASV_ERR_ARG, "depth %d out of range 1..8", cfg->depth);
     if (cfg->width < 32 || cfg->width % 32) return fail(CASV_ERR_ARG, "width %d must be a positive multiple of 32", cfg->width);
     if (cfg->voc_size < 2 || cfg->voc_size > 4096) return fail(CASV_ERR_ARG, "voc_size %d out of range 2..4096", cfg->voc_size);
@@ -54,6 +59,7 @@ extern "C" int casv_model_create(const casv_config* cfg, int device_id, casv_mod
     e = hipEventCreateWithFlags(&m->ev_inputs, hipEventDisableTiming);
     if (e != hipSuccess) { (void)hipStreamDestroy(m->stream); delete m; return fail(CASV_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     m->enc.resize(m->D + 1); m->dec.resize(m->D + 1); m->st_h.resize(m->D + 1); m->st_c.resize(m->D + 1);
+    m->br_hT.resize(m->D + 1); m->br_hb.resize(m->D + 1); m->br_cT.resize(m->D + 1); m->br_cb.resize(m->D + 1);
     *out = m;
     return CASV_OK;
 }
@@ -81,6 +87,8 @@ extern "C" void casv_model_destroy(casv_model* m) {
     if (m->pin_out) (void)hipHostFree(m->pin_out);
     for (auto& b : m->st_h) b.release();
     for (auto& b : m->st_c) b.release();
+    for (auto* v : {&m->br_hT, &m->br_hb, &m->br_cT, &m->br_cb}) for (auto& b : *v) b.release();
+    m->br_tmp.release();
     (void)casv_train_release(m);
     vendor_gemm_release(m->stream);
     (void)casv_comm_destroy(m);
@@ -223,6 +231,16 @@ extern "C" int casv_commit_weights(casv_model* m) {
     if (int rc = upload(m->bUW, m->host["att_bUW"])) return rc;
     if (int rc = upload(m->va, m->host["att_va"])) return rc;
     if (int rc = upload(m->bv, m->host["att_bv"])) return rc;
+    if (m->cfg.bridge_dense)
+        for (int n = 1; n <= D; ++n)
+            for (int s = 0; s < 2; ++s) {
+                const std::string b = "bridge" + std::to_string(n) + (s ? "_c" : "_h");
+                const auto& K = m->host[b + "_K"];
+                std::vector<float> kt((size_t)W * W);           // Bt[j][k] = K[k][j]
+                for (int j = 0; j < W; ++j) for (int k = 0; k < W; ++k) kt[(size_t)j * W + k] = K[(size_t)k * W + j];
+                if (int rc = upload(s ? m->br_cT[n] : m->br_hT[n], kt)) return rc;
+                if (int rc = upload(s ? m->br_cb[n] : m->br_hb[n], m->host[b + "_b"])) return rc;
+            }
     m->committed = true;
     return CASV_OK;
 }
@@ -270,6 +288,7 @@ static int persist_enc_lds(const casv_model* m) { return 16 * ((m->D >= 2 ? 3 * 
 static bool persist_enc_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0 || m->ncu < 64 || m->D > 8) return false;
     if (m->enc_arith > 0) return false;                    // (the persistent kernels are fp32-input kernels)
+    if (m->cfg.residual_connections && m->D >= 3) return false;   // (the layers' sums of seq2seq.py:284-291 have no persistent form)
     const int W = m->W, D = m->D;
     const int per_cu = persist_encode_blocks_per_cu((size_t)persist_enc_lds(m));            // 0: the staged rows do not fit the LDS
     if (per_cu < 1) return false;
@@ -394,7 +413,18 @@ static int run_encoder(casv_model* m, bool try_persistent) {
         g.step_imm = t;
         return g;
     };
-    for (int n0 = 2; n0 <= D && !persistent; n0 += GEMM_MAX_JOBS) {
+    // residual_connections (seq2seq.py:284-291): from layer 3 on a layer's output sequence is its LSTM output plus its input sequence
+    // -- no wavefront across such layers: they run one after the other, the sum is taken in place over the whole sequence once a
+    // layer has finished (its final h -- the LSTM's own -- set aside first)
+    const bool residual = m->cfg.residual_connections && D >= 3;
+    for (int n = 2; n <= D && residual && !persistent; ++n) {
+        for (int t = 0; t < T; ++t) { GemmArgs g = layer_job(n, t); run_gemm(m, EPI_LSTM, g); }
+        SmallOps ops{};
+        ops.rows(lout[n] + (size_t)(T - 1) * W, (long long)T * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1);
+        if (!launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
+        if (n >= 3) launch_add_inplace(lout[n], lout[n - 1], (long long)BT * W, m->stream);
+    }
+    for (int n0 = 2; n0 <= D && !persistent && !residual; n0 += GEMM_MAX_JOBS) {
         const int n1 = std::min(D, n0 + GEMM_MAX_JOBS - 1);
         for (int k = 0; k < T + (n1 - n0); ++k) {
             GemmBatch b{};
@@ -409,12 +439,27 @@ static int run_encoder(casv_model* m, bool try_persistent) {
         // backward final h of layer 1 = its output at time 0 (seq2seq.py:280); layers n >= 2: the output at the last position
         SmallOps ops{};
         ops.rows(H1 + W, (long long)T * 2 * W, m->hfin.as<float>(), W, B, W, 1);
-        for (int n = 2; n <= D; ++n)
+        for (int n = 2; n <= D && !residual; ++n)
             ops.rows(lout[n] + (size_t)(T - 1) * W, (long long)T * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1);
         if (enc_abort_word) ops.rows(reinterpret_cast<const float*>(enc_abort_word), 1, m->d_flags.as<float>(), 1, 1, 1, 1);
         if (!launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
     }
     m->enc_check_pending = persistent;
+    if (m->cfg.bridge_dense) {      // bridge_dense (seq2seq.py:299-301): the final states through Dense(width, tanh) on their way to the decoder
+        const size_t BW = (size_t)B * W;
+        if (int rc = m->br_tmp.ensure(BW * 4)) return rc;
+        for (int n = 1; n <= D; ++n)
+            for (int s = 0; s < 2; ++s) {
+                float* st = (s ? m->cfin.as<float>() : m->hfin.as<float>()) + (size_t)(n - 1) * BW;
+                GemmArgs g{};
+                g.nseg = 1; g.a[0] = mkseg(st, W, W, 0);
+                g.Bt = (s ? m->br_cT[n] : m->br_hT[n]).as<float>(); g.bias = (s ? m->br_cb[n] : m->br_hb[n]).as<float>();
+                g.M = B; g.N = W; g.Ktot = W;
+                g.out = mkslot(m->br_tmp.as<float>(), W);
+                run_gemm(m, EPI_PLAIN, g);
+                launch_tanh(m->br_tmp.as<float>(), st, (long long)BW, m->stream);
+            }
+    }
     float* outb = lout[D];
     m->enc_out = D == 1 ? H1 : outb;
     // u = attention_dense(enc_out) once per line (seq2seq.py:313; the reference redoes it every step)

@@ -141,6 +141,8 @@ static void refresh_derived(casv_model* m) {
 extern "C" int casv_train_begin(casv_model* m, const casv_adam_params* ap, const char* frozen_csv) {
     if (!m || !ap) return fail(CASV_ERR_ARG, "null argument");
     if (m->W > 1024) return fail(CASV_ERR_ARG, "training supports width <= 1024");
+    if (m->cfg.residual_connections || m->cfg.bridge_dense)
+        return fail(CASV_ERR_ARG, "the train step is implemented for the default topology only (residual_connections / bridge_dense models decode, they do not train yet)");
     HIPCHK(hipSetDevice(m->device));
     for (auto& kv : m->expect)
         if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());

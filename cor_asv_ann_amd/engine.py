@@ -11,9 +11,9 @@ import numpy as np
 from . import _native as nv
 
 
-def weight_shapes(depth, width, voc_size):
+def weight_shapes(depth, width, voc_size, bridge_dense=False):
     """Ordered {name: shape} of the model's tensors in Keras layout (layer creation
-    order of seq2seq.py:239-350 and attention.py:598-609)."""
+    order of seq2seq.py:239-350 and attention.py:598-609; the bridge_dense layers of seq2seq.py:299-301 last)."""
     d, W, V = depth, width, voc_size
     C = 2 * W if d == 1 else W
     shapes = {'E': (V, W)}
@@ -37,6 +37,11 @@ def weight_shapes(depth, width, voc_size):
     shapes['dec%d_K' % d] = (W + C, 4 * W)
     shapes['dec%d_R' % d] = (W, 4 * W)
     shapes['dec%d_b' % d] = (4 * W,)
+    if bridge_dense:
+        for n in range(1, d + 1):
+            for part in ('h', 'c'):
+                shapes['bridge%d_%s_K' % (n, part)] = (W, W)
+                shapes['bridge%d_%s_b' % (n, part)] = (W,)
     return shapes
 
 
@@ -71,6 +76,8 @@ def _width_blocks(name, depth):
     top = 'dec%d_' % d
     if name == 'E':
         return (None, 1)
+    if name.startswith('bridge'):
+        return (1, 1) if name.endswith('_K') else (1, None)
     if name in ('att_va', 'att_bUW'):
         return (1, None)
     if name == 'att_bv':
@@ -117,8 +124,9 @@ class HipEngine(object):
         handle = c_void_p()
         nv.check(self.lib.casv_model_create(byref(cfg), int(device), byref(handle)))
         self.handle = handle
-        self.shapes = weight_shapes(self.depth, self.width, self.voc_size)
-        self.pshapes = weight_shapes(self.depth, self.pwidth, self.voc_size)
+        self.residual_connections, self.bridge_dense = bool(residual_connections), bool(bridge_dense)
+        self.shapes = weight_shapes(self.depth, self.width, self.voc_size, self.bridge_dense)
+        self.pshapes = weight_shapes(self.depth, self.pwidth, self.voc_size, self.bridge_dense)
         self.B = self.T = 0
 
     # -- dead-unit padding (class docstring) ---------------------------------------------------

@@ -23,14 +23,25 @@ import numpy as np
 from . import hdf5
 
 
-def layer_tensors(depth):
+def _bridge(out, n, names):
+    """The bridge_dense layers of encoder layer n (seq2seq.py:299-301): Dense(width, tanh) 'bridge_h_<n>', 'bridge_c_<n>'."""
+    for part in ('h', 'c'):
+        out['bridge_%s_%d' % (part, n)] = (['bridge_%s_%d/kernel:0' % (part, n), 'bridge_%s_%d/bias:0' % (part, n)] if names
+                                            else ['bridge%d_%s_K' % (n, part), 'bridge%d_%s_b' % (n, part)])
+
+
+def layer_tensors(depth, bridge_dense=False):
     """Ordered {keras layer name: [tensor names in layer.weights order]} (seq2seq.py:239-350, attention.py:418-421,598-609)."""
     d = int(depth)
     out = OrderedDict()
     out['char_input_projection'] = ['E']
     out['encoder_lstm_1'] = ['enc1_%s_%s' % (direction, part) for direction in ('fw', 'bw') for part in 'KRb']
+    if bridge_dense:
+        _bridge(out, 1, False)
     for n in range(2, d + 1):
         out['encoder_lstm_%d' % n] = ['enc%d_%s' % (n, part) for part in 'KRb']
+        if bridge_dense:
+            _bridge(out, n, False)
     out['attention_dense'] = ['att_U']
     for n in range(1, d):
         out['decoder_lstm_%d' % n] = ['dec%d_%s' % (n, part) for part in 'KRb']
@@ -38,7 +49,7 @@ def layer_tensors(depth):
     return out
 
 
-def _keras_weight_names(depth):
+def _keras_weight_names(depth, bridge_dense=False):
     """Variable names keras/TF1 gives the weights (`<scope>/<name>:0`), per layer, in order."""
     d = int(depth)
     lstm = ['kernel:0', 'recurrent_kernel:0', 'bias:0']
@@ -46,8 +57,12 @@ def _keras_weight_names(depth):
     out['char_input_projection'] = ['char_input_projection/kernel:0']
     out['encoder_lstm_1'] = ['encoder_lstm_1/%s_encoder_lstm_1/%s' % (direction, w)
                              for direction in ('forward', 'backward') for w in lstm]
+    if bridge_dense:
+        _bridge(out, 1, True)
     for n in range(2, d + 1):
         out['encoder_lstm_%d' % n] = ['encoder_lstm_%d/%s' % (n, w) for w in lstm]
+        if bridge_dense:
+            _bridge(out, n, True)
     out['attention_dense'] = ['attention_dense/kernel:0']
     for n in range(1, d):
         out['decoder_lstm_%d' % n] = ['decoder_lstm_%d/%s' % (n, w) for w in lstm]
@@ -140,6 +155,14 @@ def layers_to_tensors(layers, logger=None):
         if lname in ('char_input_projection', 'attention_dense') and len(arrays) == 1:
             out[lname] = OrderedDict([('E' if lname == 'char_input_projection' else 'att_U', arrays[0])])
             continue
+        if (lname.startswith('bridge_h_') or lname.startswith('bridge_c_')) and len(arrays) == 2:
+            try:
+                n = int(lname.rsplit('_', 1)[1])
+            except ValueError:
+                continue
+            part = lname[len('bridge_')]
+            out[lname] = OrderedDict([('bridge%d_%s_K' % (n, part), arrays[0]), ('bridge%d_%s_b' % (n, part), arrays[1].reshape(-1))])
+            continue
         if not (lname.startswith('encoder_lstm_') or lname.startswith('decoder_lstm_')):
             continue
         try:
@@ -176,7 +199,8 @@ def read_model(filename, logger=None):
 def write_model(filename, config, weights):
     """Write `weights` ({tensor name: array}, all tensors of the model) and `config` in the reference's layout."""
     depth = int(config['depth'])
-    table, knames = layer_tensors(depth), _keras_weight_names(depth)
+    bridge = bool(np.asarray(config.get('bridge_dense', False)).item()) if 'bridge_dense' in config else False
+    table, knames = layer_tensors(depth, bridge), _keras_weight_names(depth, bridge)
     w = hdf5.Writer()
     w.set_attr('/', 'layer_names', np.array([n.encode('utf-8') for n in table], dtype='S'))
     w.set_attr('/', 'backend', np.bytes_(b'tensorflow'))

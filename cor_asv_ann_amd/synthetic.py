@@ -18,6 +18,8 @@ class ModelConfig:
     width: int = 512
     voc_size: int = 256
     window: int = 5          # attention.py:515, seq2seq.py:347
+    residual_connections: bool = False       # seq2seq.py:125,284-291,359-360
+    bridge_dense: bool = False               # seq2seq.py:132,299-301
 
     @property
     def ctx_width(self):
@@ -57,6 +59,12 @@ def weight_names(cfg):
         names += [('dec%d_K' % n, (W, 4 * W)), ('dec%d_R' % n, (W, 4 * W)), ('dec%d_b' % n, (4 * W,))]
     names += [('att_Wa', (W, W)), ('att_va', (W,)), ('att_bUW', (W,)), ('att_bv', (1,)),
               ('dec%d_K' % d, (W + C, 4 * W)), ('dec%d_R' % d, (W, 4 * W)), ('dec%d_b' % d, (4 * W,))]
+    if getattr(cfg, 'bridge_dense', False):
+        # Dense(width, activation='tanh') on the final h and c of every encoder layer (seq2seq.py:299-301: 'bridge_h_<n>', 'bridge_c_<n>');
+        # listed (and drawn) LAST so that the default topology's tensors are the same with and without the flag
+        for n in range(1, d + 1):
+            for s in ('h', 'c'):
+                names += [('bridge%d_%s_K' % (n, s), (W, W)), ('bridge%d_%s_b' % (n, s), (W,))]
     return names
 
 
@@ -73,6 +81,8 @@ def make_weights(cfg, seed=WEIGHT_SEED, dtype=np.float32, emb_scale=4.0):
         elif name == 'att_va':
             lim = np.sqrt(6.0 / (W + 1))          # Keras shape (W, 1)
             w = rng.uniform(-lim, lim, shape)
+        elif name.startswith('bridge') and name.endswith('_b'):
+            w = rng.uniform(-0.1, 0.1, shape)     # (Keras: zeros; drawn here so that a dropped bias shows in the parity tests)
         elif name.endswith('_b'):
             w = np.zeros(shape)
             w[W:2 * W] = 1.0                      # unit_forget_bias, gate order i,f,c,o

@@ -45,22 +45,36 @@ def _run_lstm(x_seq, K, R, b, reverse=False):
     return out, h, c
 
 
+def bridge(cfg, w, n, h, c):
+    """bridge_dense (seq2seq.py:299-301): the final states of encoder layer n pass through Dense(width, activation='tanh') layers
+    'bridge_h_<n>' / 'bridge_c_<n>' on their way to decoder layer n."""
+    if not getattr(cfg, 'bridge_dense', False):
+        return h, c
+    return (np.tanh(h @ w['bridge%d_h_K' % n] + w['bridge%d_h_b' % n]).astype(h.dtype),
+            np.tanh(c @ w['bridge%d_c_K' % n] + w['bridge%d_c_b' % n]).astype(c.dtype))
+
+
 def encode(cfg, w, x):
     """encoder_model (seq2seq.py:403-406): x (B,T,V) dense rows (one-hot / confidences / zeros
     for padding) -> [enc_out (B,T,C), h1, c1, ..., hd, cd, a0 (B,T)].
 
     Layer 1 is bidirectional and hands its BACKWARD final state to decoder layer 1
     (seq2seq.py:280-281); layers n>=2 are forward LSTMs handing over their final state after
-    the last (possibly padded) position (seq2seq.py:283,302)."""
+    the last (possibly padded) position (seq2seq.py:283,302).
+
+    residual_connections (seq2seq.py:284-291): from the third layer on a layer's output sequence is its LSTM output PLUS its
+    input sequence (the second layer's input is 2W wide: no sum there); the states handed over are the LSTM's own.
+    bridge_dense: see `bridge`."""
     dt = w['E'].dtype
     x0 = x.astype(dt) @ w['E']
     fw, _, _ = _run_lstm(x0, w['enc1_fw_K'], w['enc1_fw_R'], w['enc1_fw_b'])
     bw, hb, cb = _run_lstm(x0, w['enc1_bw_K'], w['enc1_bw_R'], w['enc1_bw_b'], reverse=True)
     out = np.concatenate([fw, bw], axis=2)
-    states = [hb, cb]
+    states = list(bridge(cfg, w, 1, hb, cb))
     for n in range(2, cfg.depth + 1):
-        out, h, c = _run_lstm(out, w['enc%d_K' % n], w['enc%d_R' % n], w['enc%d_b' % n])
-        states += [h, c]
+        out2, h, c = _run_lstm(out, w['enc%d_K' % n], w['enc%d_R' % n], w['enc%d_b' % n])
+        out = out2 + out if (getattr(cfg, 'residual_connections', False) and n >= 3) else out2
+        states += list(bridge(cfg, w, n, h, c))
     a0 = np.zeros(out.shape[:2], dt)          # attention_state_init, seq2seq.py:307-309
     return [out] + states + [a0]
 
@@ -91,7 +105,10 @@ def decoder_step(cfg, w, p_in, enc_out, states, u=None):
     p_in (R,V): zeros at step 0, otherwise the fed-back distribution.  enc_out (R or 1,T,C).
     states = [h1,c1,...,hd,cd,a].  u = enc_out.U_a; the reference recomputes it inside every
     step (seq2seq.py:459-460) -- pass u=None to do the same.
-    Returns (probs (R,V), new_states)."""
+    Returns (probs (R,V), new_states).
+
+    residual_connections: the reference's INFERENCE decoder has none (seq2seq.py:421-436 builds `decoder_model` layer by layer
+    without the `add` of the training graph, seq2seq.py:359-360) -- restated as it is; the training graph's sums are in train.py."""
     d = cfg.depth
     dt = w['E'].dtype
     with np.errstate(invalid='ignore', divide='ignore', over='ignore'):

@@ -258,3 +258,28 @@ def test_libver_latest_is_refused_clearly(tmp_path):
     assert f['config/width'][()] == 7 and list(f.attrs['layer_names']) == [b'a']
     with pytest.raises(hdf5.H5Error):
         hdf5.File(wide).keys()
+
+
+def test_bridge_dense_layers_in_the_container(tmp_path):
+    """A bridge_dense model (seq2seq.py:299-301,1135-1137): the written file lists Dense layers 'bridge_h_<n>' / 'bridge_c_<n>'
+    (kernel:0, bias:0) behind each encoder layer, the config group carries the flags, and reading gives the tensors back."""
+    from cor_asv_ann_amd.synthetic import ModelConfig, make_weights
+    cfg = ModelConfig(depth=3, width=32, voc_size=12, residual_connections=True, bridge_dense=True)
+    weights = make_weights(cfg)
+    config = {'width': np.array(32), 'depth': np.array(3), 'stateful': np.array(False), 'residual_connections': np.array(True),
+              'deep_bidirectional_encoder': np.array(False), 'bridge_dense': np.array(True),
+              'mapping': np.arange(12, dtype=np.uint32)}
+    path = str(tmp_path / 'bridged.h5')
+    keras_h5.write_model(path, config, weights)
+    got_cfg, layers = keras_h5.read_model(path)
+    assert bool(got_cfg['bridge_dense']) and bool(got_cfg['residual_connections'])
+    table = keras_h5.layer_tensors(3, True)
+    assert list(layers) == list(table)
+    assert list(table)[1:4] == ['encoder_lstm_1', 'bridge_h_1', 'bridge_c_1'] and 'bridge_c_3' in table
+    for lname, tensors in layers.items():
+        assert list(tensors) == table[lname]
+        for name, arr in tensors.items():
+            assert np.array_equal(np.asarray(arr).reshape(weights[name].shape), weights[name]), name
+    with hdf5.File(path) as f:
+        names = [n.decode() for n in f['bridge_h_2'].attrs['weight_names']]
+        assert names == ['bridge_h_2/kernel:0', 'bridge_h_2/bias:0'] and f['bridge_h_2/bridge_h_2/kernel:0'].shape == (32, 32)

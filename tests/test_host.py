@@ -84,12 +84,19 @@ def test_vectorize_lines_equals_oracle_layouts():
 
 
 def test_unsupported_topology_is_refused():
-    for flag in ('residual_connections', 'deep_bidirectional_encoder', 'bridge_dense', 'lm_loss', 'lm_predict',
-                 'stateful'):
+    for flag in ('deep_bidirectional_encoder', 'lm_loss', 'lm_predict', 'stateful'):
         s2s = Sequence2Sequence()
         setattr(s2s, flag, True)
         with pytest.raises(NotImplementedError):
             s2s.configure()
+    # residual_connections / bridge_dense (seq2seq.py:284-301) are built since round 6: configure() takes them, and a bridged
+    # model has the Dense layers' tensors
+    s2s = Sequence2Sequence()
+    s2s.residual_connections = s2s.bridge_dense = True
+    s2s.depth, s2s.width, s2s.voc_size = 3, 32, 12
+    s2s.configure()
+    w = s2s.get_weights()
+    assert w['bridge3_c_K'].shape == (32, 32) and w['bridge1_h_b'].shape == (32,) and not w['bridge1_h_b'].any()
     s2s = Sequence2Sequence()
     s2s.scheduled_sampling = 'linear'
     with pytest.raises(NotImplementedError):

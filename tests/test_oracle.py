@@ -69,6 +69,39 @@ def test_encoder_matches_torch_lstm_stack():
     assert out[7].shape == (5, 18) and not out[7].any()
 
 
+def test_encoder_with_residual_connections_and_bridge_matches_torch():
+    """The optional topologies of seq2seq.py:284-301 against an independent implementation (torch LSTM stack, float64): from the third
+    layer on a layer's output sequence is LSTM output + input sequence (the second layer's 2W-wide input is not summed), the states
+    handed to the decoder are the LSTM's own final states -- through Dense(width, tanh) layers when bridge_dense is set."""
+    cfg = ModelConfig(depth=4, width=32, voc_size=40, residual_connections=True, bridge_dense=True)
+    w = make_weights(cfg, dtype=np.float64, emb_scale=8.0)
+    rng = np.random.default_rng(1)
+    for k in w:
+        if k.endswith('_b'):
+            w[k] = rng.normal(size=w[k].shape) * 0.3
+    lines, idx = make_lines(5, 17, 3, voc_size=40)
+    x = np.eye(40)[idx]
+    out = encode(cfg, w, x)
+    with torch.no_grad():
+        x0 = torch.tensor(x @ w['E'])
+        l1 = _torch_lstm(w['enc1_fw_K'], w['enc1_fw_R'], w['enc1_fw_b'], True,
+                         w['enc1_bw_K'], w['enc1_bw_R'], w['enc1_bw_b'])
+        y1, (h1, c1) = l1(x0)
+        y2, (h2, c2) = _torch_lstm(w['enc2_K'], w['enc2_R'], w['enc2_b'])(y1)
+        o3, (h3, c3) = _torch_lstm(w['enc3_K'], w['enc3_R'], w['enc3_b'])(y2)
+        y3 = o3 + y2
+        o4, (h4, c4) = _torch_lstm(w['enc4_K'], w['enc4_R'], w['enc4_b'])(y3)
+        y4 = o4 + y3
+    assert np.allclose(out[0], y4.numpy(), atol=1e-10)
+    br = lambda n, part, v: np.tanh(v.numpy() @ w['bridge%d_%s_K' % (n, part)] + w['bridge%d_%s_b' % (n, part)])
+    assert np.allclose(out[1], br(1, 'h', h1[1]), atol=1e-10) and np.allclose(out[2], br(1, 'c', c1[1]), atol=1e-10)
+    assert np.allclose(out[5], br(3, 'h', h3[0]), atol=1e-10) and np.allclose(out[8], br(4, 'c', c4[0]), atol=1e-10)
+    # the default topology's tensors are the same with and without the flags (the bridge tensors are drawn last)
+    w0 = make_weights(ModelConfig(depth=4, width=32, voc_size=40), dtype=np.float64, emb_scale=8.0)
+    w1 = make_weights(cfg, dtype=np.float64, emb_scale=8.0)
+    assert all(np.array_equal(w0[k], w1[k]) for k in w0) and len(w1) == len(w0) + 16
+
+
 def test_attention_window_edges():
     cfg = ModelConfig(depth=2, width=32, voc_size=16)
     w = make_weights(cfg, dtype=np.float64)
