@@ -36,6 +36,12 @@ struct TrainState {
     std::vector<TLayer> layers;            // enc1_fw, enc1_bw, enc2.., dec1..decD
     int iE = -1, iUT = -1, iWaT = -1, ibUW = -1, iva = -1, ibv = -1;
     DevBuf ETp, WaN, UaN;                  // derived: E^T padded [W][Vp], W_a [W][W], U_a [C][W]
+    // bridge_dense (seq2seq.py:299-301): per encoder layer n (index n - 1) and state s (0 = h, 1 = c) the Dense kernel transposed
+    // [W out][W in] (the B operand of the forward product), its bias, and -- derived -- the kernel as Keras holds it [W in][W out]
+    // (the B operand of the data gradient); the bridged states, and the tanh' products of the backward pass
+    struct Bridge { int ikt = -1, ib = -1; DevBuf kn; };
+    std::vector<Bridge> bridge;            // [2 * (n - 1) + s]
+    DevBuf hbr, cbr, brtmp, Ytop;          // [D][B][W] bridged final states; scratch [B][W]; residual_connections: top output + its input [U*B][W]
     int B = 0, T = 0, U = 0, A = 0;
     DevBuf e_idx, e_val, d_in, d_out, d_w, m_enc, m_dec, m_cell;
     DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, RecIn, prev, logits, dG, d_enc, du, DWQ, DSrows, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
@@ -113,6 +119,8 @@ int casv_train_release(casv_model* m) {
     if (ts->side) { (void)hipStreamSynchronize(ts->side); (void)hipStreamDestroy(ts->side); if (ts->ev_fork) (void)hipEventDestroy(ts->ev_fork); if (ts->ev_join) (void)hipEventDestroy(ts->ev_join); ts->side = nullptr; }
     for (auto& t : ts->tens) { t.w.release(); t.g.release(); t.m.release(); t.v.release(); }
     for (auto& l : ts->layers) { l.wxT.release(); l.wrT.release(); l.Hown.release(); l.Cs.release(); l.Gt.release(); l.Z.release(); l.dRec.release(); }
+    for (auto& b : ts->bridge) b.kn.release();
+    for (DevBuf* b : {&ts->hbr, &ts->cbr, &ts->brtmp, &ts->Ytop}) b->release();
     DevBuf* bufs[] = {&ts->ETp, &ts->WaN, &ts->UaN, &ts->e_idx, &ts->e_val, &ts->d_in, &ts->d_out, &ts->d_w, &ts->m_enc, &ts->m_dec,
         &ts->m_cell, &ts->X0, &ts->H1, &ts->u, &ts->Y0, &ts->Ym, &ts->WQ, &ts->Ast, &ts->WIN, &ts->RecIn, &ts->prev,
         &ts->logits, &ts->dG, &ts->d_enc, &ts->du, &ts->DWQ, &ts->DSrows, &ts->dhatt, &ts->dfin, &ts->dcbuf, &ts->HP, &ts->dX0, &ts->dXtop, &ts->dXl, &ts->dYl, &ts->dOin, &ts->dcbuf2, &ts->dvaP, &ts->dbvP,
@@ -136,13 +144,12 @@ static void refresh_derived(casv_model* m) {
     launch_transpose(ts->W_(ts->iE), V, W, W, ts->ETp.as<float>(), Vp, m->stream);
     launch_transpose(ts->W_(ts->iWaT), W, W, W, ts->WaN.as<float>(), W, m->stream);
     launch_transpose(ts->W_(ts->iUT), W, C, C, ts->UaN.as<float>(), W, m->stream);
+    for (auto& b : ts->bridge) launch_transpose(ts->W_(b.ikt), W, W, W, b.kn.as<float>(), W, m->stream);
 }
 
 extern "C" int casv_train_begin(casv_model* m, const casv_adam_params* ap, const char* frozen_csv) {
     if (!m || !ap) return fail(CASV_ERR_ARG, "null argument");
     if (m->W > 1024) return fail(CASV_ERR_ARG, "training supports width <= 1024");
-    if (m->cfg.residual_connections || m->cfg.bridge_dense)
-        return fail(CASV_ERR_ARG, "the train step is implemented for the default topology only (residual_connections / bridge_dense models decode, they do not train yet)");
     HIPCHK(hipSetDevice(m->device));
     for (auto& kv : m->expect)
         if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());
@@ -180,6 +187,20 @@ extern "C" int casv_train_begin(casv_model* m, const casv_adam_params* ap, const
     ts->ibUW = add_tensor(ts, "att_bUW", m->host["att_bUW"], false);
     ts->iva = add_tensor(ts, "att_va", m->host["att_va"], false);
     ts->ibv = add_tensor(ts, "att_bv", m->host["att_bv"], false);
+    if (m->cfg.bridge_dense)
+        for (int n = 1; n <= D; ++n)
+            for (int s = 0; s < 2; ++s) {
+                const std::string b = "bridge" + std::to_string(n) + (s ? "_c" : "_h");
+                const auto& K = m->host[b + "_K"];
+                std::vector<float> kt((size_t)W * W);
+                for (int j = 0; j < W; ++j) for (int k = 0; k < W; ++k) kt[(size_t)j * W + k] = K[(size_t)k * W + j];
+                TrainState::Bridge br;
+                const bool frozen = is_frozen(b + "_", fz);
+                br.ikt = add_tensor(ts, b + "_KT", kt, frozen);
+                br.ib = add_tensor(ts, b + "_b", m->host[b + "_b"], frozen);
+                if (br.ikt < 0 || br.ib < 0 || br.kn.ensure((size_t)W * W * 4)) rc |= -1;
+                ts->bridge.push_back(std::move(br));
+            }
     if (rc || ts->iE < 0 || ts->iUT < 0 || ts->iWaT < 0 || ts->ibUW < 0 || ts->iva < 0 || ts->ibv < 0) {
         casv_train_release(m);
         return fail(CASV_ERR_NOMEM, "could not allocate the training tensors");
@@ -508,6 +529,9 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         else { ENS(l.Hown, rows * W * 4) l.hs = l.Hown.as<float>(); l.hs_ld = W; }
     }
     ENS(ts->rec_cnt, 16 * train_recurrence_bwd_counter_bytes(B)) ENS(ts->dcalt, (size_t)2 * B * W * 4)
+    const bool residual = m->cfg.residual_connections != 0, bridged = m->cfg.bridge_dense != 0;
+    if (bridged) { ENS(ts->hbr, (size_t)D * B * W * 4) ENS(ts->cbr, (size_t)D * B * W * 4) ENS(ts->brtmp, (size_t)B * W * 4) }
+    if (residual && D >= 2) ENS(ts->Ytop, UB * W * 4)
     for (int n = 1; n <= D; ++n) ENS(ts->O[n], TB * (n == 1 ? 2 * W : W) * 4)
     for (int n = 1; n < D; ++n) ENS(ts->DO[n], UB * W * 4)
 #undef ENS
@@ -556,6 +580,21 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     // final states handed to the decoder: layer 1 = backward direction after t = 0 (seq2seq.py:280)
     HIPCHK(hipMemcpy2DAsync(hfin, (size_t)W * 4, Lbw->hs, (size_t)2 * W * 4, (size_t)W * 4, B, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(cfin, Lbw->Cs.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+    // bridge_dense (seq2seq.py:299-301): the decoder starts from tanh(state . K + b) of every encoder layer's final h and c
+    const float* h0base = bridged ? ts->hbr.as<float>() : hfin; const float* c0base = bridged ? ts->cbr.as<float>() : cfin;
+    auto bridge_forward = [&](int n) {              // encoder layer n (1-based): hfin / cfin slot n - 1 -> hbr / cbr slot n - 1
+        if (!bridged) return;
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const TrainState::Bridge& br = ts->bridge[2 * (n - 1) + s_];
+            const float* src = (s_ ? cfin : hfin) + (size_t)(n - 1) * B * W;
+            float* dst = (s_ ? ts->cbr.as<float>() : ts->hbr.as<float>()) + (size_t)(n - 1) * B * W;
+            GemmArgs g = plain_gemm(src, W, B, W, ts->W_(br.ikt), W, ts->W_(br.ib), ts->brtmp.as<float>(), W);
+            g.ksplit = 0; g.kgroups = 0;            // (one k-ordered chain per element, no atomics into an uncleared buffer)
+            run_gemm(m, EPI_PLAIN, g);
+            launch_tanh(ts->brtmp.as<float>(), dst, (long long)B * W, st);
+        }
+    };
+    bridge_forward(1);
     if (!masked1) launch_mul_mask(ts->H1.as<float>(), 2 * W, menc_n(1), ts->O[1].as<float>(), 2 * W, TB, 2 * W, st);
     launch_embed_tm(ts->W_(ts->iE), ts->d_in.as<int>(), nullptr, ts->Y0.as<float>(), B, U, 1, V, W, st);
     // Encoder layer n and decoder layer n-1 depend only on encoder layer n-1 / decoder layer n-2, so the two
@@ -566,15 +605,23 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         TLayer& ld = dec_layer(n - 1);
         layer_input_gemm(m, le, ts->O[n - 1].as<float>(), le.kx);
         layer_input_gemm(m, ld, y, W);
-        const float* h0 = hfin + (size_t)(n - 2) * B * W; const float* c0 = cfin + (size_t)(n - 2) * B * W;
+        const float* h0 = h0base + (size_t)(n - 2) * B * W; const float* c0 = c0base + (size_t)(n - 2) * B * W;
+        // residual_connections: encoder layer n >= 3 / decoder layer n - 1 >= 2 hand on LSTM output + input sequence (seq2seq.py:284-291,
+        // 359-360) -- the sum and the next layer's dropout mask in one pass behind the recurrences (which then write no masked copy)
+        const bool res_n = residual && n >= 3;
         bool maskedn = false;
         {
-            const LayerFwd f[2] = {{&le, nullptr, nullptr, ts->O[n].as<float>(), W, menc_n(n)}, {&ld, h0, c0, ts->DO[n - 1].as<float>(), W, mdec_n(n - 1)}};
+            const LayerFwd f[2] = {{&le, nullptr, nullptr, res_n ? nullptr : ts->O[n].as<float>(), W, menc_n(n)},
+                                   {&ld, h0, c0, res_n ? nullptr : ts->DO[n - 1].as<float>(), W, mdec_n(n - 1)}};
             if (int rc = layers_forward(m, f, 2, &maskedn)) return rc;
         }
         HIPCHK(hipMemcpyAsync(hfin + (size_t)(n - 1) * B * W, le.hs + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(cfin + (size_t)(n - 1) * B * W, le.Cs.as<float>() + (long long)(T - 1) * B * W, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
-        if (!maskedn) {
+        bridge_forward(n);
+        if (res_n) {
+            launch_add_mul_mask(le.hs, W, ts->O[n - 1].as<float>(), W, menc_n(n), ts->O[n].as<float>(), W, TB, W, st);
+            launch_add_mul_mask(ld.hs, W, y, W, mdec_n(n - 1), ts->DO[n - 1].as<float>(), W, UB, W, st);
+        } else if (!maskedn) {
             launch_mul_mask(le.hs, W, menc_n(n), ts->O[n].as<float>(), W, TB, W, st);
             launch_mul_mask(ld.hs, W, mdec_n(n - 1), ts->DO[n - 1].as<float>(), W, UB, W, st);
         }
@@ -587,7 +634,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     TLayer& top = dec_layer(D);
     launch_mul_rowmask(y, W, mcell, W + C, ts->Ym.as<float>(), W, UB, B, W, st);
     layer_input_gemm(m, top, ts->Ym.as<float>(), W);
-    const float* h0t = hfin + (size_t)(D - 1) * B * W; const float* c0t = cfin + (size_t)(D - 1) * B * W;
+    const float* h0t = h0base + (size_t)(D - 1) * B * W; const float* c0t = c0base + (size_t)(D - 1) * B * W;
     HIPCHK(hipMemsetAsync(ts->Ast.p, 0, (size_t)B * T * 4, st));
     // The cell's input rows [ctx * mask | h(t-1)] (LSTMCell(dropout) masks the cell input [y | ctx] per sample, seq2seq.py:345; the y
     // part is masked where it is precomputed) are filled where their parts are produced: the attention rows write the masked
@@ -634,7 +681,14 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         run_gemm(m, EPI_LSTM, g);
     }
     // ================= loss =================
-    { GemmArgs g = plain_gemm(top.hs, W, (int)UB, W, ts->W_(ts->iE), V, nullptr, ts->logits.as<float>(), Vp); run_plain(m, g); }
+    // (residual_connections: the projection reads the cell's outputs PLUS the cell's input sequence, seq2seq.py:359-360 at the top layer)
+    const bool res_top = residual && D >= 2;
+    const float* proj_in = top.hs; long long proj_ld = W;
+    if (res_top) {
+        launch_add_mul_mask(top.hs, top.hs_ld, y, W, nullptr, ts->Ytop.as<float>(), W, UB, W, st);
+        proj_in = ts->Ytop.as<float>();
+    }
+    { GemmArgs g = plain_gemm(proj_in, proj_ld, (int)UB, W, ts->W_(ts->iE), V, nullptr, ts->logits.as<float>(), Vp); run_plain(m, g); }
     launch_softmax_ce(ts->logits.as<float>(), ts->d_out.as<int>(), ts->d_w.as<float>(), B, U, V, Vp, inv_count, ts->loss.as<double>(),
                       training ? 1 : 0, st);
     // Did every persistent recurrence so far run to its end?  (A launch gives up when its workgroups wait too long for each
@@ -680,7 +734,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     float* dlog = ts->logits.as<float>();
     // tied projection: dE += dlogits^T . G ; dG = dlogits . E
     {
-        run_gemm_tn(m, dlog, Vp, Vp, V, top.hs, W, W, UB, ts->G_(ts->iE), W);      // (the padding columns of dlogits are zero)
+        run_gemm_tn(m, dlog, Vp, Vp, V, proj_in, proj_ld, W, UB, ts->G_(ts->iE), W);      // (the padding columns of dlogits are zero)
         GemmArgs g2 = plain_gemm(dlog, Vp, (int)UB, Vp, ts->ETp.as<float>(), W, nullptr, ts->dG.as<float>(), W);
         run_plain(m, g2);
     }
@@ -820,6 +874,7 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         GemmArgs g = plain_gemm(top.Z.as<float>(), 4 * W, (int)UB, 4 * W, top.wxT.as<float>(), W, nullptr, ts->dXtop.as<float>(), W);
         run_plain(m, g);
         launch_mul_rowmask(ts->dXtop.as<float>(), W, mcell, W + C, ts->dXtop.as<float>(), W, UB, B, W, st);
+        if (res_top) launch_axpy(ts->dXtop.as<float>(), ts->dG.as<float>(), UB * W, st);       // the sum's other branch: dL/d(cell input sequence) += dL/d(projection input)
         if (int rc = layer_weight_grads(m, top, ts->Ym.as<float>(), W, ts->RecIn.as<float>(), kr)) return rc;
         // attention parameters: dWaT = DWQ^T . Hprev ; dbUW = colsum(DWQ) ; u path
         if (!ts->tens[ts->iWaT].frozen) {
@@ -832,6 +887,24 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
             run_plain(m, gd);
         }
     }
+    // bridge_dense backward: dfin_h(n) / dfin_c(n) arrive as gradients w.r.t. the BRIDGED states; through tanh' and the Dense layer
+    // they become the gradients w.r.t. encoder layer n's own final states (in place), and leave the Dense layers' gradients
+    auto bridge_backward = [&](int n) {
+        if (!bridged) return;
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const TrainState::Bridge& br = ts->bridge[2 * (n - 1) + s_];
+            float* d = s_ ? dfin_c(n) : dfin_h(n);
+            const float* raw = (s_ ? cfin : hfin) + (size_t)(n - 1) * B * W;
+            const float* post = (s_ ? ts->cbr.as<float>() : ts->hbr.as<float>()) + (size_t)(n - 1) * B * W;
+            launch_tanh_bwd(d, post, (long long)B * W, st);
+            if (!ts->tens[br.ikt].frozen) run_gemm_tn(m, d, W, W, W, raw, W, W, B, ts->G_(br.ikt), W, ts->G_(br.ib));
+            GemmArgs g = plain_gemm(d, W, B, W, br.kn.as<float>(), W, nullptr, ts->brtmp.as<float>(), W);
+            g.ksplit = 0; g.kgroups = 0;
+            run_gemm(m, EPI_PLAIN, g);
+            (void)hipMemcpyAsync(d, ts->brtmp.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st);
+        }
+    };
+    bridge_backward(D);
     // ---- decoder layer n with encoder layer n+1 (the mirror of the forward pairing) ----
     const float* dy = ts->dXtop.as<float>();        // gradient w.r.t. DO[D-1] (or Y0 when D == 1)
     const float* dO = ts->d_enc.as<float>();        // gradient w.r.t. O[D]
@@ -843,14 +916,20 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         TLayer& ld = dec_layer(n);
         TLayer& le = enc_layer(n + 1);
         const float* xin = n == 1 ? ts->Y0.as<float>() : ts->DO[n - 1].as<float>();
+        // residual_connections: decoder layer n >= 2 / encoder layer n + 1 >= 3 pass their output gradient (times the mask) straight on to
+        // their input as well: the input-gradient buffers start from it and the layers' data gradients are added
+        const bool res_d = residual && n >= 2, res_e = residual && n + 1 >= 3;
+        if (res_d) launch_mul_mask(dy, W, mdec_n(n), dy_bufs[dy_cur ^ 1], W, UB, W, st);
+        if (res_e) launch_mul_mask(dO, ld_dO, menc_n(n + 1), do_bufs[do_out], le.kx, TB, W, st);
         LayerBwd pair[2] = {
-            {&ld, dy, W, mdec_n(n), nullptr, nullptr, hfin + (size_t)(n - 1) * B * W, cfin + (size_t)(n - 1) * B * W, dfin_c(n),
-             xin, W, dy_bufs[dy_cur ^ 1], W, 0},
+            {&ld, dy, W, mdec_n(n), nullptr, nullptr, h0base + (size_t)(n - 1) * B * W, c0base + (size_t)(n - 1) * B * W, dfin_c(n),
+             xin, W, dy_bufs[dy_cur ^ 1], W, res_d ? 1 : 0},
             {&le, dO, ld_dO, menc_n(n + 1), dfin_h(n + 1), dfin_c(n + 1), nullptr, nullptr, ts->dcbuf.as<float>(),
-             ts->O[n].as<float>(), le.kx, do_bufs[do_out], le.kx, 0}};
+             ts->O[n].as<float>(), le.kx, do_bufs[do_out], le.kx, res_e ? 1 : 0}};
         if (int rc = layers_backward(m, pair, 2)) return rc;
         // dL/dh0, dL/dc0 of the decoder layer go to the encoder layer of the same index
         HIPCHK(hipMemcpyAsync(dfin_h(n), ld.dRec.as<float>(), (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+        bridge_backward(n);
         dy_cur ^= 1; dy = dy_bufs[dy_cur];
         dO = do_bufs[do_out]; ld_dO = le.kx; do_out ^= 1;
     }
@@ -934,6 +1013,15 @@ static int keras_view(casv_model* m, int which, std::map<std::string, std::vecto
     if (int rc = fetch(ts->ibUW, out["att_bUW"])) return rc;
     if (int rc = fetch(ts->iva, out["att_va"])) return rc;
     if (int rc = fetch(ts->ibv, out["att_bv"])) return rc;
+    for (size_t i = 0; i < ts->bridge.size(); ++i) {
+        const std::string b = "bridge" + std::to_string(i / 2 + 1) + (i % 2 ? "_c" : "_h");
+        std::vector<float> kt;
+        if (int rc = fetch(ts->bridge[i].ikt, kt)) return rc;
+        auto& K = out[b + "_K"];
+        K.resize((size_t)W * W);
+        for (int j = 0; j < W; ++j) for (int k = 0; k < W; ++k) K[(size_t)k * W + j] = kt[(size_t)j * W + k];
+        if (int rc = fetch(ts->bridge[i].ib, out[b + "_b"])) return rc;
+    }
     (void)D;
     return 0;
 }

@@ -10,6 +10,11 @@ void launch_embed_tm(const float* E, const int* idx, const float* val, float* ou
 void launch_embed_scatter(float* dE, const int* idx, const float* val, const float* dX, long long ld_dx, int B, int T, int A,
                           int V, int W, hipStream_t st);
 void launch_mul_mask(const float* in, long long ld_in, const float* mask, float* out, long long ld_out, long long rows, int F, hipStream_t st);
+// residual_connections (seq2seq.py:284-291,359-360): out[r][f] = (a[r][f] + b[r][f]) * mask[f] (mask nullptr: times one)
+void launch_add_mul_mask(const float* a, long long lda, const float* b, long long ldb, const float* mask, float* out, long long ld_out,
+                         long long rows, int F, hipStream_t st);
+// bridge_dense backward (seq2seq.py:299-301): dy[i] *= 1 - y[i]^2
+void launch_tanh_bwd(float* dy, const float* y, long long n, hipStream_t st);
 void launch_mul_rowmask(const float* in, long long ld_in, const float* mask, long long ld_mask, float* out, long long ld_out,
                         long long rows, int B, int F, hipStream_t st);
 void launch_softmax_ce(float* logits, const int* target, const float* weight, int B, int U, int V, int Vp, float inv_count,

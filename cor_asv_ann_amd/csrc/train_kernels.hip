@@ -84,6 +84,28 @@ void launch_mul_mask(const float* in, long long ld_in, const float* mask, float*
     hipLaunchKernelGGL(mul_mask_kernel, dim3(blocks), dim3(256), 0, st, in, ld_in, mask, out, ld_out, rows, F);
 }
 
+__global__ void add_mul_mask_kernel(const float* __restrict__ a, long long lda, const float* __restrict__ b, long long ldb,
+                                    const float* __restrict__ mask, float* __restrict__ out, long long ld_out, long long rows, int F) {
+    const long long n = rows * F;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / F; const int f = (int)(i % F);
+        out[r * ld_out + f] = (a[r * lda + f] + b[r * ldb + f]) * (mask ? mask[f] : 1.0f);
+    }
+}
+void launch_add_mul_mask(const float* a, long long lda, const float* b, long long ldb, const float* mask, float* out, long long ld_out,
+                         long long rows, int F, hipStream_t st) {
+    const long long n = rows * F;
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(add_mul_mask_kernel, dim3(blocks), dim3(256), 0, st, a, lda, b, ldb, mask, out, ld_out, rows, F);
+}
+__global__ void tanh_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dy[i] *= 1.0f - y[i] * y[i];
+}
+void launch_tanh_bwd(float* dy, const float* y, long long n, hipStream_t st) {
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, y, n);
+}
+
 // ---- out[(t*B+b)][f] = in[(t*B+b)][f] * mask[b][f]: per-sample, time-constant mask ----
 __global__ void mul_rowmask_kernel(const float* __restrict__ in, long long ld_in, const float* __restrict__ mask, long long ld_mask,
                                    float* __restrict__ out, long long ld_out, long long rows, int B, int F) {

@@ -97,12 +97,22 @@ def forward_backward(cfg, w, enc_in, dec_in, dec_out, weights, masks=None, want_
     O = [H[0] * m_enc[0]]
     enc_caches = [None]
     fin = [(hb, cb)]
+    res = bool(getattr(cfg, 'residual_connections', False))
     for n in range(2, d + 1):
         Hn, h, c, cache = lstm_forward(O[-1], w['enc%d_K' % n], w['enc%d_R' % n], w['enc%d_b' % n])
         enc_caches.append(cache)
-        H.append(Hn); O.append(Hn * m_enc[n - 1]); fin.append((h, c))
+        # residual_connections (seq2seq.py:284-291): output sequence = LSTM output + the layer's (already dropped-out) input
+        # sequence, from the third layer on
+        Yn = Hn + O[-1] if (res and n >= 3) else Hn
+        H.append(Hn); O.append(Yn * m_enc[n - 1]); fin.append((h, c))
     enc_out = O[-1]
     u = enc_out @ w['att_U']
+    # bridge_dense (seq2seq.py:299-301): the final states through Dense(width, tanh) on their way to the decoder
+    bridged = bool(getattr(cfg, 'bridge_dense', False))
+    fin_raw = fin
+    if bridged:
+        fin = [(np.tanh(h @ w['bridge%d_h_K' % (n + 1)] + w['bridge%d_h_b' % (n + 1)]),
+                np.tanh(c @ w['bridge%d_c_K' % (n + 1)] + w['bridge%d_c_b' % (n + 1)])) for n, (h, c) in enumerate(fin_raw)]
 
     # ---------------- decoder ----------------
     Yd = dec_in.astype(dt)
@@ -113,7 +123,8 @@ def forward_backward(cfg, w, enc_in, dec_in, dec_out, weights, masks=None, want_
         G, _, _, cache = lstm_forward(Y[-1], w['dec%d_K' % n], w['dec%d_R' % n], w['dec%d_b' % n],
                                       h0=fin[n - 1][0], c0=fin[n - 1][1])
         dec_caches.append(cache)
-        Y.append(G * m_dec[n - 1])
+        # (seq2seq.py:359-360: `if n > 0 and residual_connections` with n counted from 0 -- from the second decoder layer on)
+        Y.append((G + Y[-1] if (res and n >= 2) else G) * m_dec[n - 1])
     # attention cell (top layer)
     Kd, Rd, bd = w['dec%d_K' % d], w['dec%d_R' % d], w['dec%d_b' % d]
     Wa, va, bUW, bv = w['att_Wa'], w['att_va'], w['att_bUW'], w['att_bv'][0]
@@ -141,6 +152,8 @@ def forward_backward(cfg, w, enc_in, dec_in, dec_out, weights, masks=None, want_
         for k, v in (('i', i), ('f', f), ('g', g), ('o', o), ('c', c), ('h', h)):
             top[k][:, t] = v
     G = top['h']
+    if res and d >= 2:          # the top layer's sum: cell output + the cell's input sequence (before the cell's own input dropout)
+        G = G + Y[-1]
     logits = G @ E.T
     logits = logits - logits.max(axis=2, keepdims=True)
     P = np.exp(logits)
@@ -207,6 +220,8 @@ def forward_backward(cfg, w, enc_in, dec_in, dec_out, weights, masks=None, want_
         g_['att_Wa'] += h_prev.T @ dwq
         dh = dh + dwq @ Wa.T
     g_['dec%d_K' % d], g_['dec%d_R' % d], g_['dec%d_b' % d] = dKd, dRd, dbd
+    if res and d >= 2:
+        dYtop = dYtop + dG
     dfin = [[np.zeros((B, W), dt), np.zeros((B, W), dt)] for _ in range(d)]
     dfin[d - 1] = [dh, dc]
     # decoder-independent half of the attention: u = enc_out . U_a
@@ -219,15 +234,22 @@ def forward_backward(cfg, w, enc_in, dec_in, dec_out, weights, masks=None, want_
         dX, dK, dR, db, dh0, dc0 = lstm_backward(dec_caches[n - 1], dGn)
         g_['dec%d_K' % n], g_['dec%d_R' % n], g_['dec%d_b' % n] = dK, dR, db
         dfin[n - 1][0] += dh0; dfin[n - 1][1] += dc0
-        dYn = dX
+        dYn = dX + dGn if (res and n >= 2) else dX
     g_['E'] += np.einsum('buv,buw->vw', Yd, dYn)
+    if bridged:                 # back through the bridges: tanh', the Dense layers' gradients, the encoder's own final states
+        for n in range(d):
+            for k, part in enumerate('hc'):
+                dpre = dfin[n][k] * (1 - fin[n][k] ** 2)
+                g_['bridge%d_%s_K' % (n + 1, part)] += fin_raw[n][k].T @ dpre
+                g_['bridge%d_%s_b' % (n + 1, part)] += dpre.sum(axis=0)
+                dfin[n][k] = dpre @ w['bridge%d_%s_K' % (n + 1, part)].T
     # encoder
     dO = d_enc_out
     for n in range(d, 1, -1):
         dHn = dO * m_enc[n - 1]
         dX, dK, dR, db, _, _ = lstm_backward(enc_caches[n - 1], dHn, dfin[n - 1][0], dfin[n - 1][1])
         g_['enc%d_K' % n], g_['enc%d_R' % n], g_['enc%d_b' % n] = dK, dR, db
-        dO = dX
+        dO = dX + dHn if (res and n >= 3) else dX
     dH1 = dO * m_enc[0]
     dXf, g_['enc1_fw_K'], g_['enc1_fw_R'], g_['enc1_fw_b'], _, _ = lstm_backward(cf, dH1[:, :, :W])
     dXb, g_['enc1_bw_K'], g_['enc1_bw_R'], g_['enc1_bw_b'], _, _ = lstm_backward(cbw, dH1[:, :, W:], dfin[0][0], dfin[0][1])

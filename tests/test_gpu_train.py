@@ -30,8 +30,24 @@ def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks, path):
     """fused: the recurrences as one launch per pair of layers (train_persist.hip; backward: train_persist_bwd.hip at widths of
     whole 128-unit column tiles, else the cell's backward inside each step's data GEMM, gemm_bwd.hip); stepwise: one launch per
     time step and per operation."""
+    _train_step_case(d, W, V, B, L, es, with_masks, path, {})
+
+
+@pytest.mark.parametrize('flags', [dict(residual_connections=True), dict(bridge_dense=True),
+                                   dict(residual_connections=True, bridge_dense=True)])
+@pytest.mark.parametrize('d,W,V,B,L,es,with_masks', [(4, 64, 96, 6, 10, 8.0, True), (3, 128, 40, 37, 7, 4.0, True), (2, 50, 40, 4, 9, 4.0, True),
+                                                     (1, 32, 40, 4, 9, 3.0, False), (5, 96, 40, 5, 8, 4.0, False)])
+@pytest.mark.parametrize('path', ['fused', 'stepwise'])
+def test_train_step_with_optional_topologies_matches_oracle(d, W, V, B, L, es, with_masks, path, flags):
+    """residual_connections (seq2seq.py:284-291: encoder layers >= 3; :359-360: decoder layers >= 2 and the projection's input) and
+    bridge_dense (:299-301) in the train step: loss, every gradient (the Dense layers' included), test_on_batch and three Adam
+    updates against the oracle, whose backward is checked against torch autograd with the same flags (tests/test_oracle_train.py)."""
+    _train_step_case(d, W, V, B, L, es, with_masks, path, flags)
+
+
+def _train_step_case(d, W, V, B, L, es, with_masks, path, flags):
     from cor_asv_ann_amd.engine import HipEngine
-    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    cfg = ModelConfig(depth=d, width=W, voc_size=V, **flags)
     w = make_weights(cfg, emb_scale=es)
     rng = np.random.default_rng(4)
     for k in w:
@@ -49,7 +65,7 @@ def test_train_step_matches_oracle(d, W, V, B, L, es, with_masks, path):
         masks = {'enc': [keep(2 * W if n == 0 else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
                  'cell': keep((B, W + C))}
     loss, grads, aux = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, masks)
-    eng = HipEngine(d, W, V)
+    eng = HipEngine(d, W, V, **flags)
     eng.set_weights(w)
     eng.set_option('persistent', -1 if path == 'fused' else 0)
     eng.set_option('fused_backward', 1 if path == 'fused' else 0)

@@ -35,15 +35,23 @@ def torch_loss(cfg, w, enc_in, dec_in, dec_out, weights, masks):
     bseq, hb, cb = _lstm(x0, w['enc1_bw_K'], w['enc1_bw_R'], w['enc1_bw_b'], W, reverse=True)
     out = torch.cat([f, bseq], 2) * masks['enc'][0]
     fin = [(hb, cb)]
+    res, bridged = cfg.residual_connections, cfg.bridge_dense
     for n in range(2, d + 1):
         hs, h, c = _lstm(out, w['enc%d_K' % n], w['enc%d_R' % n], w['enc%d_b' % n], W)
+        if res and n >= 3:                  # the training graph of seq2seq.py:284-291, written as the Keras layers are
+            hs = hs + out
         out = hs * masks['enc'][n - 1]
         fin.append((h, c))
+    if bridged:                             # seq2seq.py:299-301
+        fin = [(torch.tanh(h @ w['bridge%d_h_K' % (n + 1)] + w['bridge%d_h_b' % (n + 1)]),
+                torch.tanh(c @ w['bridge%d_c_K' % (n + 1)] + w['bridge%d_c_b' % (n + 1)])) for n, (h, c) in enumerate(fin)]
     enc_out = out
     u = enc_out @ w['att_U']
     y = dec_in @ E
     for n in range(1, d):
         hs, _, _ = _lstm(y, w['dec%d_K' % n], w['dec%d_R' % n], w['dec%d_b' % n], W, fin[n - 1][0], fin[n - 1][1])
+        if res and n >= 2:                  # seq2seq.py:359-360 (n > 0 counted from 0)
+            hs = hs + y
         y = hs * masks['dec'][n - 1]
     h, c = fin[d - 1]
     B, T = enc_in.shape[:2]
@@ -62,7 +70,10 @@ def torch_loss(cfg, w, enc_in, dec_in, dec_out, weights, masks):
         x = torch.cat([y[:, t], ctx], 1) * masks['cell']
         h, c = _cell(x, h, c, w['dec%d_K' % d], w['dec%d_R' % d], w['dec%d_b' % d], W)
         outs.append(h)
-    P = torch.softmax(torch.stack(outs, 1) @ E.T, dim=2)
+    top = torch.stack(outs, 1)
+    if res and d >= 2:
+        top = top + y
+    P = torch.softmax(top @ E.T, dim=2)
     P = P / P.sum(2, keepdim=True)
     ce = -(dec_out * torch.log(torch.clamp(P, EPS, 1 - EPS))).sum(2)
     cnt = max(int((weights != 0).sum()), 1)
@@ -72,10 +83,13 @@ def torch_loss(cfg, w, enc_in, dec_in, dec_out, weights, masks):
     return loss + reg
 
 
-@pytest.mark.parametrize('d,with_masks', [(1, False), (2, True), (3, False)])
-def test_backward_matches_autograd(d, with_masks):
+@pytest.mark.parametrize('d,with_masks,flags', [(1, False, {}), (2, True, {}), (3, False, {}),
+                                                (4, True, dict(residual_connections=True)), (2, True, dict(residual_connections=True)),
+                                                (3, True, dict(bridge_dense=True)), (1, False, dict(bridge_dense=True)),
+                                                (4, True, dict(residual_connections=True, bridge_dense=True))])
+def test_backward_matches_autograd(d, with_masks, flags):
     W, V = 16, 12
-    cfg = ModelConfig(depth=d, width=W, voc_size=V)
+    cfg = ModelConfig(depth=d, width=W, voc_size=V, **flags)
     w = make_weights(cfg, dtype=np.float64, emb_scale=3.0)
     rng = np.random.default_rng(4)
     for k in w:
