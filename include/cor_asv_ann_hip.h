@@ -40,9 +40,12 @@ typedef enum {
     CASV_ERR_NAN = -5       /* numpy would have raised "All-NaN slice" (seq2seq.py:1329,1335) */
 } casv_status;
 
-/* Topology of seq2seq.py:108-157.  The optional variants (residual_connections,
- * deep_bidirectional_encoder, bridge_dense, lm_loss/lm_predict, stateful) must be 0:
- * both published models use the default topology (wrapper/ocrd-tool.json:61-74). */
+/* Topology of seq2seq.py:108-157.  residual_connections (seq2seq.py:284-291, 359-360) and bridge_dense (seq2seq.py:299-301) are
+ * built: encoder layers >= 3 hand on LSTM output + input sequence, the final h / c of every encoder layer pass through
+ * Dense(width, tanh) layers "bridge<n>_h_K|b", "bridge<n>_c_K|b" ((W,W) kernel, (W) bias) on their way to the decoder; the train
+ * step adds the training graph's decoder sums (layers >= 2 and the projection's input) -- which the reference's inference decoder
+ * does not have (seq2seq.py:421-436), restated as it is.  deep_bidirectional_encoder, lm_loss/lm_predict and stateful must be 0
+ * (both published models use the default topology, wrapper/ocrd-tool.json:61-74). */
 typedef struct {
     int32_t depth;          /* seq2seq.py:117 */
     int32_t width;          /* seq2seq.py:115; must be a multiple of 32 (any other width: pad with dead units, as
@@ -75,7 +78,8 @@ void casv_model_destroy(casv_model* m);
 
 /* Keras set_weights/get_weights per tensor (seq2seq.py:1172, 509-523).  Names and shapes are
  * those of SURVEY.md A.2: "E" (V,W); "enc1_fw_K|R|b", "enc1_bw_K|R|b"; "enc<n>_K|R|b";
- * "att_U" (C,W); "dec<n>_K|R|b"; "att_Wa" (W,W), "att_va" (W), "att_bUW" (W), "att_bv" (1).
+ * "att_U" (C,W); "dec<n>_K|R|b"; "att_Wa" (W,W), "att_va" (W), "att_bUW" (W), "att_bv" (1); with bridge_dense also
+ * "bridge<n>_h_K" (W,W), "bridge<n>_h_b" (W), "bridge<n>_c_K", "bridge<n>_c_b" for n = 1..depth (Keras Dense: y = x.K + b).
  * Layout is Keras': kernels (in,4W) with gate blocks i,f,c,o; row-major float32. */
 int casv_set_weight(casv_model* m, const char* name, const float* data, int64_t count);
 int casv_get_weight(casv_model* m, const char* name, float* out, int64_t capacity);

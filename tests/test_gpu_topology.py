@@ -108,3 +108,41 @@ def test_model_file_round_trip_with_bridge_layers(tmp_path):
     got = again.correct_lines(lines, fast=False, greedy=False)
     assert got[0] == want[0] and np.allclose(got[2], want[2], atol=1e-6)
     again.engine.close()
+
+
+def test_facade_trains_a_model_with_both_flags(tmp_path):
+    """cor-asv-ann-train's path (`Sequence2Sequence.train()`, seq2seq.py:590-649) on a small copy task with residual_connections and
+    bridge_dense set: the validation loss falls, the trained model -- bridges included -- decodes like the oracle on its weights and
+    survives the reference's container."""
+    import os
+    from cor_asv_ann_amd.seq2seq import Sequence2Sequence
+    rng = np.random.default_rng(5)
+    alphabet = 'abcdefghijklmnop '
+    lines = [''.join(rng.choice(list(alphabet), size=int(rng.integers(6, 14)))) for _ in range(640)]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        (tmp_path / 'train.tsv').write_text(''.join('%s\t%s\n' % (l, l) for l in lines))
+        s2s = Sequence2Sequence()
+        s2s.depth, s2s.width, s2s.batch_size, s2s.epochs, s2s.dropout = 3, 64, 32, 16, 0.1
+        s2s.residual_connections = s2s.bridge_dense = True
+        s2s._rng = np.random.default_rng(1)
+        s2s.configure()
+        s2s.train([str(tmp_path / 'train.tsv')])
+    finally:
+        os.chdir(cwd)
+    hist = s2s.history
+    assert s2s.status == 2 and min(h['val_loss'] for h in hist) < hist[0]['val_loss'] - 0.1, hist
+    w = s2s.get_weights()
+    assert 'bridge3_c_K' in w and np.abs(w['bridge1_h_b']).max() > 0          # (the Dense layers trained: their biases left zero)
+    test = [l + '\n' for l in lines[:6]]
+    s2s.batch_size = 4
+    cfg = ModelConfig(depth=3, width=64, voc_size=s2s.voc_size, residual_connections=True, bridge_dense=True)
+    om = OracleModel(cfg, w, mapping=s2s.mapping, batch_size=4)
+    got, want = s2s.correct_lines(test, fast=True, greedy=True), correct_lines(om, test, fast=True, greedy=True)
+    assert got[0] == want[0] and np.allclose(got[2], want[2], atol=1e-4)
+    s2s.save(str(tmp_path / 'm.h5'))
+    other = Sequence2Sequence()
+    other.load_config(str(tmp_path / 'm.h5')); other.configure(); other.load_weights(str(tmp_path / 'm.h5'))
+    other.batch_size = 4
+    assert other.correct_lines(test, fast=True, greedy=True)[0] == got[0]
