@@ -282,11 +282,11 @@ def host_threads():
         return os.cpu_count() or 1
 
 
-def host_cores():
+def host_cores(cgroup='/sys/fs/cgroup'):
     """CPUs this process may really use: its affinity mask, capped by the cgroup's CPU quota where there is one (a GPU box hands a
     one-GPU job a share of the host -- 16 CPUs -- while the affinity mask still shows all 256)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+    for path in (os.path.join(cgroup, 'cpu.max'), os.path.join(cgroup, 'cpu', 'cpu.cfs_quota_us')):
         try:
             with open(path) as f:
                 parts = f.read().split()
@@ -296,7 +296,7 @@ def host_cores():
             else:
                 quota = int(parts[0])
                 if quota > 0:
-                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                    with open(os.path.join(cgroup, 'cpu', 'cpu.cfs_period_us')) as f:
                         n = min(n, max(1, int(round(quota / float(f.read().split()[0])))))
             break
         except (OSError, ValueError, IndexError):
@@ -908,9 +908,12 @@ def decode_bench(args):
             result['kernel_ms_per_step'] = {k: v['ms'] for k, v in others.items()}     # from one extra untimed step
         if world == 1 and not args.no_cpu_baseline and not dry:
             beam = {('rejection_threshold' if k == 'rejection' else k): wl[k] for k in ('rejection', 'beam_width_in', 'beam_threshold_in') if k in wl}
-            result['cpu_baseline'] = cpu_baseline(cfg, wl['emb'], all_lines[:256], wl['n'] if not wl['fast'] else 256, wl['fast'], L,
-                                                  budget_s=args.cpu_budget, confmat=bool(wl.get('confmat')),
-                                                  min_lines=1 if wl.get('confmat') else 16, **beam)
+            try:
+                result['cpu_baseline'] = cpu_baseline(cfg, wl['emb'], all_lines[:256], wl['n'] if not wl['fast'] else 256, wl['fast'], L,
+                                                      budget_s=args.cpu_budget, confmat=bool(wl.get('confmat')),
+                                                      min_lines=1 if wl.get('confmat') else 16, **beam)
+            except Exception as err:        # (a reported baseline: its failure must not take the measured line down)
+                result['cpu_baseline'] = {'value': None, 'unit': 'chars/s', 'cores': host_cores(), 'kind': 'port', 'sample': 'failed: %r' % (err,)}
     if comm:
         comm.close()
     elif dist_on:

@@ -498,7 +498,7 @@ static int settle_encoder(casv_model* m, const unsigned* flag = nullptr) {
 static int ensure_encoded(casv_model* m, int want) {
     if (m->enc_arith == want) return 0;
     m->enc_check_pending = false;
-    m->enc_arith = want;
+    m->enc_arith = want;                // (run_encoder reads it; taken back on every failure: the outputs on the device are then nobody's)
     if (!m->enc_explicit) {
         if (int rc = run_encoder(m, true)) { m->enc_arith = -1; return rc; }
         return 0;
@@ -510,7 +510,7 @@ static int ensure_encoded(casv_model* m, int want) {
     g.Bt = m->UT.as<float>(); g.bias = nullptr; g.M = m->B * m->T; g.N = m->W; g.Ktot = m->C;
     g.out = mkslot(m->u.as<float>(), m->W);
     run_gemm(m, EPI_PLAIN, g);
-    HIPCHK(hipGetLastError());
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) { m->enc_arith = -1; return fail(CASV_ERR_HIP, "attention_dense launch failed: %s", hipGetErrorString(e)); }
     return 0;
 }
 

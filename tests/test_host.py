@@ -374,3 +374,24 @@ def test_no_kernel_reads_a_register_whose_hidden_load_is_in_flight():
     res = subprocess.run([sys.executable, os.path.join(root, 'cor_asv_ann_amd', 'csrc', 'check_asm_loads.py')],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_bench_counts_the_cpus_of_its_cgroup(tmp_path, monkeypatch):
+    """bench.py's cpu_baseline sizes its worker pool to the CPUs the job may really use: the affinity mask capped by the cgroup's CPU
+    quota (a one-GPU box shows 256 CPUs in the mask and hands out 16: `cpu.max` = "1600000 100000")."""
+    import os
+    import bench
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(256)))
+    monkeypatch.delenv('CASV_BENCH_CPUS', raising=False)
+    (tmp_path / 'cpu.max').write_text('1600000 100000\n')
+    assert bench.host_cores(str(tmp_path)) == 16
+    (tmp_path / 'cpu.max').write_text('max 100000\n')
+    assert bench.host_cores(str(tmp_path)) == 256
+    os.remove(tmp_path / 'cpu.max')
+    os.makedirs(tmp_path / 'cpu')
+    (tmp_path / 'cpu' / 'cpu.cfs_quota_us').write_text('800000\n')
+    (tmp_path / 'cpu' / 'cpu.cfs_period_us').write_text('100000\n')
+    assert bench.host_cores(str(tmp_path)) == 8                      # cgroup v1
+    monkeypatch.setenv('CASV_BENCH_CPUS', '4')
+    assert bench.host_cores(str(tmp_path)) == 4
+    assert bench.host_cores(str(tmp_path / 'nowhere')) == 4
