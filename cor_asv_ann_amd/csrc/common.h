@@ -244,6 +244,8 @@ void launch_advance_step(int* step_ptr, hipStream_t stream);
 // elementwise helpers of the optional topologies (seq2seq.py:284-301): dst[i] += src[i]; dst[i] = tanh(src[i]) (n floats, 16-byte aligned)
 void launch_add_inplace(float* dst, const float* src, long long n, hipStream_t stream);
 void launch_tanh(const float* src, float* dst, long long n, hipStream_t stream);
+// deep_bidirectional_encoder's "cross sum" (seq2seq.py:246-259, as computed): dst[2k] = dst[2k+1] = src[2k] + src[2k+1] (n floats, n even)
+void launch_cross_sum(const float* src, float* dst, long long n, hipStream_t stream);
 // Source of the result records of one decode call (pack_records_kernel): row j * row_mul of idx / prob [rows][S];
 // beam: len / score per row (len == 0: no finished hypothesis -> the input line src_idx [B][T][A], slot 0);
 // batched greedy: len == nullptr, the line ends at its first `eos`, empty input lines (src_idx / src_val) give empty records.

@@ -260,6 +260,19 @@ void launch_tanh(const float* src, float* dst, long long n, hipStream_t stream) 
     if (n > 0) hipLaunchKernelGGL(tanh_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n);
 }
 
+__global__ void cross_sum_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n2) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = reinterpret_cast<const float2*>(src)[i];
+        const float sum = v.x + v.y;
+        reinterpret_cast<float2*>(dst)[i] = make_float2(sum, sum);
+    }
+}
+void launch_cross_sum(const float* src, float* dst, long long n, hipStream_t stream) {
+    const long long n2 = n / 2;
+    const int blocks = (int)std::min<long long>((n2 + 255) / 256, 4096);
+    if (n2 > 0) hipLaunchKernelGGL(cross_sum_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n2);
+}
+
 __global__ void scatter_rows_kernel(const float* src, int src_ld, float* dst, int dst_ld, int rows, int width,
                                     int dst_row_mul) {
     const int i = blockIdx.x;

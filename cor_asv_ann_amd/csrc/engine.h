@@ -109,6 +109,7 @@ struct casv_model {
     int persist_skip = 0, persist_penalty = 0; bool persist_told = false;   // back-off after a persistent launch gave up waiting
     int ncu = 0;
     LstmW enc_fw, enc_bw;
+    std::vector<LstmW> enc_dfw, enc_dbw;                  // deep_bidirectional_encoder: the two directions of layer n >= 2 at index n
     std::vector<DevBuf> br_hT, br_hb, br_cT, br_cb;        // bridge_dense: Dense kernels transposed [W][W] and biases of layer n at index n
     DevBuf br_tmp;
     std::vector<LstmW> enc, dec;                         // enc[n] for layer n>=2 at index n; dec[n] n=1..D

@@ -4,7 +4,7 @@
 #include <mutex>
 
 static std::map<std::string, size_t> expected_shapes(const casv_config& c) {
-    const size_t W = c.width, V = c.voc_size, D = c.depth, C = (D == 1 ? 2 * W : W);
+    const size_t W = c.width, V = c.voc_size, D = c.depth, C = ((D == 1 || c.deep_bidirectional_encoder) ? 2 * W : W);
     std::map<std::string, size_t> m;
     m["E"] = V * W;
     for (const char* d : {"fw", "bw"}) {
@@ -13,6 +13,10 @@ static std::map<std::string, size_t> expected_shapes(const casv_config& c) {
     }
     for (size_t n = 2; n <= D; ++n) {
         const size_t nin = n == 2 ? 2 * W : W; const std::string p = "enc" + std::to_string(n);
+        if (c.deep_bidirectional_encoder) {          // every layer bidirectional, 2W-wide inputs (seq2seq.py:273-276)
+            for (const char* d : {"_fw", "_bw"}) { m[p + d + "_K"] = 2 * W * 4 * W; m[p + d + "_R"] = W * 4 * W; m[p + d + "_b"] = 4 * W; }
+            continue;
+        }
         m[p + "_K"] = nin * 4 * W; m[p + "_R"] = W * 4 * W; m[p + "_b"] = 4 * W;
     }
     m["att_U"] = C * W;
@@ -38,8 +42,8 @@ extern "C" int casv_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) !=
 
 extern "C" int casv_model_create(const casv_config* cfg, int device_id, casv_model** out) {
     if (!cfg || !out) return fail(CASV_ERR_ARG, "null argument");
-    if (cfg->deep_bidirectional_encoder || cfg->lm || cfg->stateful)
-        return fail(CASV_ERR_ARG, "deep_bidirectional_encoder, lm_loss/lm_predict and stateful are not implemented (must be off)");
+    if (cfg->lm || cfg->stateful)
+        return fail(CASV_ERR_ARG, "lm_loss/lm_predict and stateful are not implemented (must be off)");
     if (cfg->depth < 1 || cfg->depth > 8) return fail(CASV_ERR_ARG, "depth %d out of range 1..8", cfg->depth);
     if (cfg->width < 32 || cfg->width % 32) return fail(CASV_ERR_ARG, "width %d must be a positive multiple of 32", cfg->width);
     if (cfg->voc_size < 2 || cfg->voc_size > 4096) return fail(CASV_ERR_ARG, "voc_size %d out of range 2..4096", cfg->voc_size);
@@ -52,7 +56,7 @@ extern "C" int casv_model_create(const casv_config* cfg, int device_id, casv_mod
     m->cfg = *cfg; m->device = device_id;
     { hipDeviceProp_t prop{}; if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) m->ncu = prop.multiProcessorCount; }
     m->W = cfg->width; m->V = cfg->voc_size; m->Vp = (cfg->voc_size + 31) & ~31; m->D = cfg->depth;
-    m->C = cfg->depth == 1 ? 2 * cfg->width : cfg->width;
+    m->C = (cfg->depth == 1 || cfg->deep_bidirectional_encoder) ? 2 * cfg->width : cfg->width;
     m->expect = expected_shapes(*cfg);
     hipError_t e = hipStreamCreate(&m->stream);
     if (e != hipSuccess) { delete m; return fail(CASV_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -60,6 +64,7 @@ extern "C" int casv_model_create(const casv_config* cfg, int device_id, casv_mod
     if (e != hipSuccess) { (void)hipStreamDestroy(m->stream); delete m; return fail(CASV_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     m->enc.resize(m->D + 1); m->dec.resize(m->D + 1); m->st_h.resize(m->D + 1); m->st_c.resize(m->D + 1);
     m->br_hT.resize(m->D + 1); m->br_hb.resize(m->D + 1); m->br_cT.resize(m->D + 1); m->br_cb.resize(m->D + 1);
+    m->enc_dfw.resize(m->D + 1); m->enc_dbw.resize(m->D + 1);
     *out = m;
     return CASV_OK;
 }
@@ -81,6 +86,7 @@ extern "C" void casv_model_destroy(casv_model* m) {
     for (DevBuf* b : bufs) b->release();
     for (auto& l : m->enc) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
     for (LstmW* l : {&m->enc_fw, &m->enc_bw}) { l->pw.release(); l->pbias.release(); }
+    for (auto* v : {&m->enc_dfw, &m->enc_dbw}) for (auto& l : *v) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
     for (auto& l : m->dec) { l.wt.release(); l.bias.release(); l.pw.release(); l.pbias.release(); }
     for (DevBuf* b : {&m->WaP, &m->EP, &m->p_ctx, &m->p_wq, &m->p_logits, &m->p_counters, &m->p_enc_counters, &m->d_flags}) b->release();
     if (m->pin_in) (void)hipHostFree(m->pin_in);
@@ -206,7 +212,12 @@ extern "C" int casv_commit_weights(casv_model* m) {
     if (int rc = upload(m->E, E)) return rc;
     if (int rc = pack_lstm(m, m->enc_fw, "enc1_fw", W, true)) return rc;
     if (int rc = pack_lstm(m, m->enc_bw, "enc1_bw", W, true)) return rc;
-    for (int n = 2; n <= D; ++n) if (int rc = pack_lstm(m, m->enc[n], "enc" + std::to_string(n), n == 2 ? 2 * W : W, true)) return rc;
+    const bool deep = m->cfg.deep_bidirectional_encoder != 0;
+    for (int n = 2; n <= D && !deep; ++n) if (int rc = pack_lstm(m, m->enc[n], "enc" + std::to_string(n), n == 2 ? 2 * W : W, true)) return rc;
+    for (int n = 2; n <= D && deep; ++n) {
+        if (int rc = pack_lstm(m, m->enc_dfw[n], "enc" + std::to_string(n) + "_fw", 2 * W)) return rc;
+        if (int rc = pack_lstm(m, m->enc_dbw[n], "enc" + std::to_string(n) + "_bw", 2 * W)) return rc;
+    }
     if (D == 1) {
         if (int rc = pack_dec1(m, m->dec[1], "dec1", C)) return rc;
     } else {
@@ -289,6 +300,7 @@ static bool persist_enc_applies(const casv_model* m, int B) {
     if (m->persist_mode == 0 || m->ncu < 64 || m->D > 8) return false;
     if (m->enc_arith > 0) return false;                    // (the persistent kernels are fp32-input kernels)
     if (m->cfg.residual_connections && m->D >= 3) return false;   // (the layers' sums of seq2seq.py:284-291 have no persistent form)
+    if (m->cfg.deep_bidirectional_encoder && m->D >= 2) return false;
     const int W = m->W, D = m->D;
     const int per_cu = persist_encode_blocks_per_cu((size_t)persist_enc_lds(m));            // 0: the staged rows do not fit the LDS
     if (per_cu < 1) return false;
@@ -319,23 +331,25 @@ static int run_encoder(casv_model* m, bool try_persistent) {
     float* cfin = m->cfin.as<float>();
     // layer 1 (seq2seq.py:272-281): the forward step at time t and the backward step at time T-1-t are
     // independent -> one launch of two jobs
-    auto layer1_job = [&](int dir, int t) {
+    // one direction of a bidirectional layer at step t (layer 1; with deep_bidirectional_encoder every layer n): inputs x [B][T][kin],
+    // outputs into its half of H [B][T][2W], cell state of the backward direction in cfin slot n - 1 (the forward one's in a scratch slot)
+    auto bidir_job = [&](const LstmW& w, int n, int dir, int t, const float* x, int kin, float* H) {
         GemmArgs g{};
-        const LstmW& w = dir == 0 ? m->enc_fw : m->enc_bw;
         const int mul = dir == 0 ? 1 : -1;
         const int addx = dir == 0 ? 0 : T - 1, addh = dir == 0 ? -1 : T;
         g.nseg = 2;
-        g.a[0] = mkseg(x0, T * W, W, 0, nullptr, W, mul, addx);
-        g.a[1] = mkseg(H1 + dir * W, T * 2 * W, W, W, nullptr, 2 * W, mul, addh, 1);
+        g.a[0] = mkseg(x, T * kin, kin, 0, nullptr, kin, mul, addx);
+        g.a[1] = mkseg(H + dir * W, T * 2 * W, W, kin, nullptr, 2 * W, mul, addh, 1);
         g.Bt = w.wt.as<float>(); g.bias = w.bias.as<float>();
-        g.M = B; g.N = 4 * W; g.Ktot = 2 * W;
-        g.out = mkslot(H1 + dir * W, T * 2 * W, 2 * W, mul, addx);
-        float* cb = cfin + (size_t)(dir == 0 ? D : 0) * B * W;
+        g.M = B; g.N = 4 * W; g.Ktot = kin + W;
+        g.out = mkslot(H + dir * W, T * 2 * W, 2 * W, mul, addx);
+        float* cb = cfin + (size_t)(dir == 0 ? D : n - 1) * B * W;
         g.c_in = mkseg(cb, W, W, 0, nullptr, 0, 0, 0, 1);
         g.c_out = mkslot(cb, W);
         g.step_imm = t; g.step_ptr = nullptr;
         return g;
     };
+    auto layer1_job = [&](int dir, int t) { return bidir_job(dir == 0 ? m->enc_fw : m->enc_bw, 1, dir, t, x0, W, H1); };
     std::vector<float*> lout(D + 1, nullptr);
     lout[1] = H1;
     for (int n = 2; n <= D; ++n) lout[n] = (n % 2 == 0) ? m->Ha.as<float>() : m->Hb.as<float>();
@@ -413,10 +427,39 @@ static int run_encoder(casv_model* m, bool try_persistent) {
         g.step_imm = t;
         return g;
     };
+    // deep_bidirectional_encoder (seq2seq.py:246-281): every layer n >= 2 is bidirectional too, reads the "cross sum" of the layer below
+    // (each pair of neighbouring features of [fw | bw] replaced by its sum) and hands on its BACKWARD final state -- layer after
+    // layer (a backward direction ends where the next layer starts), two jobs per launch; the outputs alternate between two buffers
+    const bool deep = m->cfg.deep_bidirectional_encoder && D >= 2;
+    float* deep_out = H1;
+    if (deep) {
+        if (int rc = m->Hc.ensure((size_t)2 * BT * 2 * W * 4)) return rc;
+        float* bufA = m->Hc.as<float>(); float* xs = bufA + (size_t)BT * 2 * W;
+        float* prev = H1;
+        {   // (layer 1's backward final h now: its buffer takes layer 3's outputs)
+            SmallOps ops{};
+            ops.rows(H1 + W, (long long)T * 2 * W, m->hfin.as<float>(), W, B, W, 1);
+            if (!launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
+        }
+        for (int n = 2; n <= D; ++n) {
+            float* H = prev == H1 ? bufA : H1;
+            launch_cross_sum(prev, xs, (long long)BT * 2 * W, m->stream);
+            for (int t = 0; t < T; ++t) {
+                GemmBatch b{};
+                b.g[0] = bidir_job(m->enc_dfw[n], n, 0, t, xs, 2 * W, H); b.g[1] = bidir_job(m->enc_dbw[n], n, 1, t, xs, 2 * W, H); b.count = 2;
+                run_gemm_batch(m, EPI_LSTM, b);
+            }
+            SmallOps ops{};         // backward final h of layer n = its output at time 0
+            ops.rows(H + W, (long long)T * 2 * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1);
+            if (!launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
+            prev = H;
+        }
+        deep_out = prev;
+    }
     // residual_connections (seq2seq.py:284-291): from layer 3 on a layer's output sequence is its LSTM output plus its input sequence
     // -- no wavefront across such layers: they run one after the other, the sum is taken in place over the whole sequence once a
     // layer has finished (its final h -- the LSTM's own -- set aside first)
-    const bool residual = m->cfg.residual_connections && D >= 3;
+    const bool residual = m->cfg.residual_connections && D >= 3 && !deep;       // (the sums live in the unidirectional branch, seq2seq.py:282-291)
     for (int n = 2; n <= D && residual && !persistent; ++n) {
         for (int t = 0; t < T; ++t) { GemmArgs g = layer_job(n, t); run_gemm(m, EPI_LSTM, g); }
         SmallOps ops{};
@@ -424,7 +467,7 @@ static int run_encoder(casv_model* m, bool try_persistent) {
         if (!launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
         if (n >= 3) launch_add_inplace(lout[n], lout[n - 1], (long long)BT * W, m->stream);
     }
-    for (int n0 = 2; n0 <= D && !persistent && !residual; n0 += GEMM_MAX_JOBS) {
+    for (int n0 = 2; n0 <= D && !persistent && !residual && !deep; n0 += GEMM_MAX_JOBS) {
         const int n1 = std::min(D, n0 + GEMM_MAX_JOBS - 1);
         for (int k = 0; k < T + (n1 - n0); ++k) {
             GemmBatch b{};
@@ -438,8 +481,8 @@ static int run_encoder(casv_model* m, bool try_persistent) {
     {   // final hidden states, and the persistent launch's give-up word set aside, in one launch:
         // backward final h of layer 1 = its output at time 0 (seq2seq.py:280); layers n >= 2: the output at the last position
         SmallOps ops{};
-        ops.rows(H1 + W, (long long)T * 2 * W, m->hfin.as<float>(), W, B, W, 1);
-        for (int n = 2; n <= D && !residual; ++n)
+        if (!deep) ops.rows(H1 + W, (long long)T * 2 * W, m->hfin.as<float>(), W, B, W, 1);
+        for (int n = 2; n <= D && !residual && !deep; ++n)
             ops.rows(lout[n] + (size_t)(T - 1) * W, (long long)T * W, m->hfin.as<float>() + (size_t)(n - 1) * B * W, W, B, W, 1);
         if (enc_abort_word) ops.rows(reinterpret_cast<const float*>(enc_abort_word), 1, m->d_flags.as<float>(), 1, 1, 1, 1);
         if (!launch_small_ops(ops, m->stream)) return fail(CASV_ERR_STATE, "too many set-up operations for one launch");
@@ -461,7 +504,7 @@ static int run_encoder(casv_model* m, bool try_persistent) {
             }
     }
     float* outb = lout[D];
-    m->enc_out = D == 1 ? H1 : outb;
+    m->enc_out = D == 1 ? H1 : deep ? deep_out : outb;
     // u = attention_dense(enc_out) once per line (seq2seq.py:313; the reference redoes it every step)
     {
         GemmArgs g{};

@@ -150,6 +150,8 @@ static void refresh_derived(casv_model* m) {
 extern "C" int casv_train_begin(casv_model* m, const casv_adam_params* ap, const char* frozen_csv) {
     if (!m || !ap) return fail(CASV_ERR_ARG, "null argument");
     if (m->W > 1024) return fail(CASV_ERR_ARG, "training supports width <= 1024");
+    if (m->cfg.deep_bidirectional_encoder && m->D >= 2)
+        return fail(CASV_ERR_ARG, "the train step has no deep_bidirectional_encoder form yet (such models decode, they do not train)");
     HIPCHK(hipSetDevice(m->device));
     for (auto& kv : m->expect)
         if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());

@@ -11,17 +11,24 @@ import numpy as np
 from . import _native as nv
 
 
-def weight_shapes(depth, width, voc_size, bridge_dense=False):
+def weight_shapes(depth, width, voc_size, bridge_dense=False, deep_bidirectional_encoder=False):
     """Ordered {name: shape} of the model's tensors in Keras layout (layer creation
     order of seq2seq.py:239-350 and attention.py:598-609; the bridge_dense layers of seq2seq.py:299-301 last)."""
     d, W, V = depth, width, voc_size
-    C = 2 * W if d == 1 else W
+    deep = bool(deep_bidirectional_encoder)
+    C = 2 * W if (d == 1 or deep) else W
     shapes = {'E': (V, W)}
     for direction in ('fw', 'bw'):
         shapes['enc1_%s_K' % direction] = (W, 4 * W)
         shapes['enc1_%s_R' % direction] = (W, 4 * W)
         shapes['enc1_%s_b' % direction] = (4 * W,)
     for n in range(2, d + 1):
+        if deep:                        # every layer bidirectional, 2W-wide inputs (seq2seq.py:273-276)
+            for direction in ('fw', 'bw'):
+                shapes['enc%d_%s_K' % (n, direction)] = (2 * W, 4 * W)
+                shapes['enc%d_%s_R' % (n, direction)] = (W, 4 * W)
+                shapes['enc%d_%s_b' % (n, direction)] = (4 * W,)
+            continue
         shapes['enc%d_K' % n] = (2 * W if n == 2 else W, 4 * W)
         shapes['enc%d_R' % n] = (W, 4 * W)
         shapes['enc%d_b' % n] = (4 * W,)
@@ -70,7 +77,7 @@ def _strip_blocks(a, axis, blocks, W, Wp):
     return np.ascontiguousarray(np.moveaxis(a, -1, axis))
 
 
-def _width_blocks(name, depth):
+def _width_blocks(name, depth, deep=False):
     """(blocks along axis 0, blocks along axis 1 or None) of the hidden width in a Keras-layout tensor of weight_shapes()."""
     d = depth
     top = 'dec%d_' % d
@@ -83,7 +90,7 @@ def _width_blocks(name, depth):
     if name == 'att_bv':
         return (None, None)
     if name == 'att_U':
-        return (2 if d == 1 else 1, 1)
+        return (2 if (d == 1 or deep) else 1, 1)
     if name == 'att_Wa':
         return (1, 1)
     if name.endswith('_b'):
@@ -91,10 +98,10 @@ def _width_blocks(name, depth):
     if name.endswith('_R'):
         return (1, 4)
     if name.endswith('_K'):
-        if name == 'enc2_K':
+        if name == 'enc2_K' or (deep and name.startswith('enc') and not name.startswith('enc1_')):
             return (2, 4)
         if name == top + 'K':
-            return (3 if d == 1 else 2, 4)       # input + context (2W wide at depth 1)
+            return (3 if (d == 1 or deep) else 2, 4)       # input + context (2W wide at depth 1 / with a deep bidirectional encoder)
         return (1, 4)
     raise KeyError(name)
 
@@ -115,8 +122,12 @@ class HipEngine(object):
         if self.width < 1:
             raise ValueError('width must be positive')
         self.pwidth = (self.width + 31) // 32 * 32            # what the device sees
-        self.ctx_width = 2 * self.width if self.depth == 1 else self.width
-        self.cblocks = 2 if self.depth == 1 else 1
+        self.deep = bool(deep_bidirectional_encoder)
+        if self.deep and self.width % 32:
+            # (the "cross sum" of seq2seq.py:246-259 pairs neighbouring features of [fw | bw]: dead-unit padding would move the pairs)
+            raise ValueError('deep_bidirectional_encoder needs a width that is a multiple of 32')
+        self.ctx_width = 2 * self.width if (self.depth == 1 or self.deep) else self.width
+        self.cblocks = 2 if (self.depth == 1 or self.deep) else 1
         self.window_width = int(window_width)
         cfg = nv.Config(self.depth, self.pwidth, self.voc_size, int(window_width), int(bool(residual_connections)),
                         int(bool(deep_bidirectional_encoder)), int(bool(bridge_dense)), int(bool(lm)),
@@ -125,8 +136,8 @@ class HipEngine(object):
         nv.check(self.lib.casv_model_create(byref(cfg), int(device), byref(handle)))
         self.handle = handle
         self.residual_connections, self.bridge_dense = bool(residual_connections), bool(bridge_dense)
-        self.shapes = weight_shapes(self.depth, self.width, self.voc_size, self.bridge_dense)
-        self.pshapes = weight_shapes(self.depth, self.pwidth, self.voc_size, self.bridge_dense)
+        self.shapes = weight_shapes(self.depth, self.width, self.voc_size, self.bridge_dense, self.deep)
+        self.pshapes = weight_shapes(self.depth, self.pwidth, self.voc_size, self.bridge_dense, self.deep)
         self.B = self.T = 0
 
     # -- dead-unit padding (class docstring) ---------------------------------------------------
@@ -134,7 +145,7 @@ class HipEngine(object):
         W, Wp = self.width, self.pwidth
         if W == Wp:
             return a
-        b0, b1 = _width_blocks(name, self.depth)
+        b0, b1 = _width_blocks(name, self.depth, self.deep)
         a = np.asarray(a, np.float32).reshape(self.shapes[name])
         if b0:
             a = _pad_blocks(a, 0, b0, W, Wp)
@@ -146,7 +157,7 @@ class HipEngine(object):
         W, Wp = self.width, self.pwidth
         if W == Wp:
             return a
-        b0, b1 = _width_blocks(name, self.depth)
+        b0, b1 = _width_blocks(name, self.depth, self.deep)
         a = np.asarray(a).reshape(self.pshapes[name])
         if b0:
             a = _strip_blocks(a, 0, b0, W, Wp)
@@ -307,7 +318,7 @@ class HipEngine(object):
         m_enc = m_dec = m_cell = None
         if masks is not None:
             # (dead units are multiplied by zero whatever their mask says)
-            m_enc = nv.carray(np.concatenate([self._padw(np.asarray(x, np.float32).ravel(), 2 if n == 0 else 1)
+            m_enc = nv.carray(np.concatenate([self._padw(np.asarray(x, np.float32).ravel(), 2 if (n == 0 or self.deep) else 1)
                                               for n, x in enumerate(masks['enc'])]), np.float32)
             if self.depth > 1:
                 m_dec = nv.carray(np.concatenate([self._padw(np.asarray(x, np.float32).ravel()) for x in masks['dec']]), np.float32)

@@ -30,7 +30,7 @@ def _bridge(out, n, names):
                                             else ['bridge%d_%s_K' % (n, part), 'bridge%d_%s_b' % (n, part)])
 
 
-def layer_tensors(depth, bridge_dense=False):
+def layer_tensors(depth, bridge_dense=False, deep=False):
     """Ordered {keras layer name: [tensor names in layer.weights order]} (seq2seq.py:239-350, attention.py:418-421,598-609)."""
     d = int(depth)
     out = OrderedDict()
@@ -39,7 +39,8 @@ def layer_tensors(depth, bridge_dense=False):
     if bridge_dense:
         _bridge(out, 1, False)
     for n in range(2, d + 1):
-        out['encoder_lstm_%d' % n] = ['enc%d_%s' % (n, part) for part in 'KRb']
+        out['encoder_lstm_%d' % n] = (['enc%d_%s_%s' % (n, direction, part) for direction in ('fw', 'bw') for part in 'KRb'] if deep
+                                      else ['enc%d_%s' % (n, part) for part in 'KRb'])
         if bridge_dense:
             _bridge(out, n, False)
     out['attention_dense'] = ['att_U']
@@ -49,7 +50,7 @@ def layer_tensors(depth, bridge_dense=False):
     return out
 
 
-def _keras_weight_names(depth, bridge_dense=False):
+def _keras_weight_names(depth, bridge_dense=False, deep=False):
     """Variable names keras/TF1 gives the weights (`<scope>/<name>:0`), per layer, in order."""
     d = int(depth)
     lstm = ['kernel:0', 'recurrent_kernel:0', 'bias:0']
@@ -60,7 +61,8 @@ def _keras_weight_names(depth, bridge_dense=False):
     if bridge_dense:
         _bridge(out, 1, True)
     for n in range(2, d + 1):
-        out['encoder_lstm_%d' % n] = ['encoder_lstm_%d/%s' % (n, w) for w in lstm]
+        out['encoder_lstm_%d' % n] = (['encoder_lstm_%d/%s_encoder_lstm_%d/%s' % (n, direction, n, w) for direction in ('forward', 'backward') for w in lstm]
+                                      if deep else ['encoder_lstm_%d/%s' % (n, w) for w in lstm])
         if bridge_dense:
             _bridge(out, n, True)
     out['attention_dense'] = ['attention_dense/kernel:0']
@@ -200,7 +202,8 @@ def write_model(filename, config, weights):
     """Write `weights` ({tensor name: array}, all tensors of the model) and `config` in the reference's layout."""
     depth = int(config['depth'])
     bridge = bool(np.asarray(config.get('bridge_dense', False)).item()) if 'bridge_dense' in config else False
-    table, knames = layer_tensors(depth, bridge), _keras_weight_names(depth, bridge)
+    deep = bool(np.asarray(config.get('deep_bidirectional_encoder', False)).item()) if 'deep_bidirectional_encoder' in config else False
+    table, knames = layer_tensors(depth, bridge, deep), _keras_weight_names(depth, bridge, deep)
     w = hdf5.Writer()
     w.set_attr('/', 'layer_names', np.array([n.encode('utf-8') for n in table], dtype='S'))
     w.set_attr('/', 'backend', np.bytes_(b'tensorflow'))

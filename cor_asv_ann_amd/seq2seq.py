@@ -23,7 +23,7 @@ from . import hdf5, keras_h5
 from .engine import HipEngine, weight_shapes
 from .realign import SparseAlignment
 
-_UNSUPPORTED = ('deep_bidirectional_encoder', 'lm_loss', 'lm_predict', 'scheduled_sampling', 'stateful')
+_UNSUPPORTED = ('lm_loss', 'lm_predict', 'scheduled_sampling', 'stateful')
 
 
 class _ShortSwitchInterval(object):
@@ -130,7 +130,7 @@ class Sequence2Sequence(object):
         rng = self._rng
         W = self.width
         out = {}
-        for name, shape in weight_shapes(self.depth, W, max(self.voc_size, 1), self.bridge_dense).items():
+        for name, shape in weight_shapes(self.depth, W, max(self.voc_size, 1), self.bridge_dense, self.deep_bidirectional_encoder).items():
             if name == 'E':
                 w = rng.standard_normal(shape) * 0.001
             elif name.endswith('_R'):
@@ -156,7 +156,7 @@ class Sequence2Sequence(object):
     def set_weights(self, weights):
         """Install all tensors (Keras layout, names of engine.weight_shapes) and resync the device."""
         assert self.status >= 1
-        shapes = weight_shapes(self.depth, self.width, self.voc_size, self.bridge_dense)
+        shapes = weight_shapes(self.depth, self.width, self.voc_size, self.bridge_dense, self.deep_bidirectional_encoder)
         new = {}
         for name, shape in shapes.items():
             a = np.asarray(weights[name], np.float32).reshape(shape)
@@ -228,8 +228,9 @@ class Sequence2Sequence(object):
         config = {k[len('config/'):]: v for k, v in src.items() if k.startswith('config/')}
         depth = int(config['depth']) if 'depth' in config else self.depth
         bridge = bool(np.asarray(config['bridge_dense']).item()) if 'bridge_dense' in config else self.bridge_dense
+        deep = bool(np.asarray(config['deep_bidirectional_encoder']).item()) if 'deep_bidirectional_encoder' in config else self.deep_bidirectional_encoder
         layers = OrderedDict()
-        for lname, tensors in keras_h5.layer_tensors(depth, bridge).items():
+        for lname, tensors in keras_h5.layer_tensors(depth, bridge, deep).items():
             if all(t in src for t in tensors):
                 layers[lname] = OrderedDict((t, src[t]) for t in tensors)
         return config, layers
@@ -260,7 +261,7 @@ class Sequence2Sequence(object):
         """Keras' by-name weight loading: a layer of the file goes into the layer of the same name if the number
         and the shapes of its weights agree (ValueError, or a warning with skip_mismatch); layers the file does
         not have keep their values."""
-        shapes = weight_shapes(self.depth, self.width, self.voc_size, self.bridge_dense)
+        shapes = weight_shapes(self.depth, self.width, self.voc_size, self.bridge_dense, self.deep_bidirectional_encoder)
         w = self.get_weights()
         taken = []
         for lname, tensors in table.items():
@@ -294,7 +295,7 @@ class Sequence2Sequence(object):
         assert self.status > 0
         self.logger.info('Loading model from "%s"', filename)
         _, layers = self._read_container(filename)
-        table = keras_h5.layer_tensors(self.depth, self.bridge_dense)
+        table = keras_h5.layer_tensors(self.depth, self.bridge_dense, self.deep_bidirectional_encoder)
         taken = self._assign_layers(layers, table, skip_mismatch=False)
         for lname in table:
             if lname not in taken:
@@ -312,7 +313,7 @@ class Sequence2Sequence(object):
             self._reconfigure_for_mapping()
             was_shallow = 'depth' in config and int(config['depth']) == self.depth - 1
         self.logger.info('Transferring model from "%s"', filename)
-        table = keras_h5.layer_tensors(self.depth, self.bridge_dense)
+        table = keras_h5.layer_tensors(self.depth, self.bridge_dense, self.deep_bidirectional_encoder)
         # the reference hands keras the attention CELL in place of the top decoder layer (seq2seq.py:1200-1204);
         # its name matches no layer of the file, so that layer is never transferred
         del table['decoder_lstm_%d' % self.depth]
@@ -431,7 +432,8 @@ class Sequence2Sequence(object):
             raise RuntimeError('model has no vocabulary yet (load or train a model first)')
         if self.engine is None:
             self.engine = HipEngine(self.depth, self.width, self.voc_size, device=self.device,
-                                    residual_connections=self.residual_connections, bridge_dense=self.bridge_dense)
+                                    residual_connections=self.residual_connections, bridge_dense=self.bridge_dense,
+                                    deep_bidirectional_encoder=self.deep_bidirectional_encoder)
             self._dirty = True
         if self._dirty:
             self.engine.set_weights(self._weights)

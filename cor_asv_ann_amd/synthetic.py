@@ -20,12 +20,13 @@ class ModelConfig:
     window: int = 5          # attention.py:515, seq2seq.py:347
     residual_connections: bool = False       # seq2seq.py:125,284-291,359-360
     bridge_dense: bool = False               # seq2seq.py:132,299-301
+    deep_bidirectional_encoder: bool = False # seq2seq.py:128,246-281: every encoder layer bidirectional, its input the "cross sum" of the layer below
 
     @property
     def ctx_width(self):
-        # attended width: the top encoder layer is the BiLSTM only when depth == 1
+        # attended width: the top encoder layer is a BiLSTM only when depth == 1 -- or always, with deep_bidirectional_encoder
         # (seq2seq.py:273-295)
-        return 2 * self.width if self.depth == 1 else self.width
+        return 2 * self.width if (self.depth == 1 or self.deep_bidirectional_encoder) else self.width
 
 
 def make_vocabulary(voc_size=256):
@@ -52,6 +53,11 @@ def weight_names(cfg):
                   ('enc1_%s_R' % direction, (W, 4 * W)),
                   ('enc1_%s_b' % direction, (4 * W,))]
     for n in range(2, d + 1):
+        if getattr(cfg, 'deep_bidirectional_encoder', False):
+            for direction in ('fw', 'bw'):
+                names += [('enc%d_%s_K' % (n, direction), (2 * W, 4 * W)), ('enc%d_%s_R' % (n, direction), (W, 4 * W)),
+                          ('enc%d_%s_b' % (n, direction), (4 * W,))]
+            continue
         nin = 2 * W if n == 2 else W
         names += [('enc%d_K' % n, (nin, 4 * W)), ('enc%d_R' % n, (W, 4 * W)), ('enc%d_b' % n, (4 * W,))]
     names += [('att_U', (C, W))]

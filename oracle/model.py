@@ -54,6 +54,13 @@ def bridge(cfg, w, n, h, c):
             np.tanh(c @ w['bridge%d_c_K' % n] + w['bridge%d_c_b' % n]).astype(c.dtype))
 
 
+def cross_sum(x):
+    """The Lambda of seq2seq.py:246-259 as the code computes it: the last axis (2W) is viewed as W pairs of neighbours, each pair is
+    reversed, and the result is added -- so BOTH features 2k and 2k+1 become x[2k] + x[2k+1].  (The comment there announces
+    fw[k] + bw[k]; what the reshape pairs are neighbours inside the concatenation [fw | bw].)"""
+    return x + x.reshape(x.shape[:-1] + (x.shape[-1] // 2, 2))[..., ::-1].reshape(x.shape)
+
+
 def encode(cfg, w, x):
     """encoder_model (seq2seq.py:403-406): x (B,T,V) dense rows (one-hot / confidences / zeros
     for padding) -> [enc_out (B,T,C), h1, c1, ..., hd, cd, a0 (B,T)].
@@ -72,6 +79,14 @@ def encode(cfg, w, x):
     out = np.concatenate([fw, bw], axis=2)
     states = list(bridge(cfg, w, 1, hb, cb))
     for n in range(2, cfg.depth + 1):
+        if getattr(cfg, 'deep_bidirectional_encoder', False):
+            # every layer bidirectional, fed the cross sum of the layer below, handing on its BACKWARD final state (seq2seq.py:273-281)
+            xin = cross_sum(out)
+            fw, _, _ = _run_lstm(xin, w['enc%d_fw_K' % n], w['enc%d_fw_R' % n], w['enc%d_fw_b' % n])
+            bw, h, c = _run_lstm(xin, w['enc%d_bw_K' % n], w['enc%d_bw_R' % n], w['enc%d_bw_b' % n], reverse=True)
+            out = np.concatenate([fw, bw], axis=2)
+            states += list(bridge(cfg, w, n, h, c))
+            continue
         out2, h, c = _run_lstm(out, w['enc%d_K' % n], w['enc%d_R' % n], w['enc%d_b' % n])
         out = out2 + out if (getattr(cfg, 'residual_connections', False) and n >= 3) else out2
         states += list(bridge(cfg, w, n, h, c))

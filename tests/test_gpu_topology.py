@@ -1,8 +1,10 @@
-"""The optional topologies `residual_connections` and `bridge_dense` (seq2seq.py:125,132,284-301,359-360) through the C ABI against
-the oracle, on a real MI355X.
+"""The optional topologies `residual_connections`, `bridge_dense` and `deep_bidirectional_encoder` (seq2seq.py:125-132,246-301,359-360)
+through the C ABI against the oracle, on a real MI355X.
 
 What they are: from the third encoder layer on a layer's output sequence is its LSTM output plus its input sequence; the final h and
-c of every encoder layer pass through Dense(width, tanh) layers ('bridge_h_<n>', 'bridge_c_<n>') on their way to the decoder.  The
+c of every encoder layer pass through Dense(width, tanh) layers ('bridge_h_<n>', 'bridge_c_<n>') on their way to the decoder; with
+a deep bidirectional encoder every layer is a BiLSTM that reads the "cross sum" of the layer below (neighbouring features of
+[fw | bw] summed pairwise, as the reference's Lambda computes it) and hands on its backward final state, the attended width is 2W.  The
 reference's INFERENCE decoder carries no residual sums (seq2seq.py:421-436 builds it layer by layer without the `add` of the training
 graph) -- restated as it is, so the decoder steps of such a model are the default topology's.  Same tolerances as
 tests/test_gpu_parity.py.
@@ -16,13 +18,15 @@ from oracle import ModelConfig, make_weights, make_lines, vectorize_lines
 from oracle.decode import OracleModel, correct_lines, decode_batch_greedy
 
 RT, AT = 2e-4, 2e-6
-FLAGS = [dict(residual_connections=True), dict(bridge_dense=True), dict(residual_connections=True, bridge_dense=True)]
+FLAGS = [dict(residual_connections=True), dict(bridge_dense=True), dict(residual_connections=True, bridge_dense=True),
+         dict(deep_bidirectional_encoder=True), dict(deep_bidirectional_encoder=True, bridge_dense=True, residual_connections=True)]
+TRAINABLE = FLAGS[:3]
 
 
 def _engine(cfg, weights, **kw):
     from cor_asv_ann_amd.engine import HipEngine
     eng = HipEngine(cfg.depth, cfg.width, cfg.voc_size, residual_connections=cfg.residual_connections,
-                    bridge_dense=cfg.bridge_dense, **kw)
+                    bridge_dense=cfg.bridge_dense, deep_bidirectional_encoder=cfg.deep_bidirectional_encoder, **kw)
     eng.set_weights(weights)
     return eng
 

@@ -283,3 +283,25 @@ def test_bridge_dense_layers_in_the_container(tmp_path):
     with hdf5.File(path) as f:
         names = [n.decode() for n in f['bridge_h_2'].attrs['weight_names']]
         assert names == ['bridge_h_2/kernel:0', 'bridge_h_2/bias:0'] and f['bridge_h_2/bridge_h_2/kernel:0'].shape == (32, 32)
+
+
+def test_deep_bidirectional_encoder_layers_in_the_container(tmp_path):
+    """deep_bidirectional_encoder (seq2seq.py:273-276): every 'encoder_lstm_<n>' is a Bidirectional layer with six weights
+    ('<layer>/forward_<layer>/kernel:0' ...), the second and higher ones with 2W-wide kernels; written and read back."""
+    from cor_asv_ann_amd.synthetic import ModelConfig, make_weights
+    cfg = ModelConfig(depth=3, width=32, voc_size=12, deep_bidirectional_encoder=True)
+    weights = make_weights(cfg)
+    config = {'width': np.array(32), 'depth': np.array(3), 'stateful': np.array(False), 'residual_connections': np.array(False),
+              'deep_bidirectional_encoder': np.array(True), 'bridge_dense': np.array(False), 'mapping': np.arange(12, dtype=np.uint32)}
+    path = str(tmp_path / 'deep.h5')
+    keras_h5.write_model(path, config, weights)
+    got_cfg, layers = keras_h5.read_model(path)
+    assert bool(got_cfg['deep_bidirectional_encoder'])
+    table = keras_h5.layer_tensors(3, False, True)
+    assert list(layers) == list(table) and table['encoder_lstm_3'][3] == 'enc3_bw_K'
+    for lname, tensors in layers.items():
+        assert list(tensors) == table[lname]
+        for name, arr in tensors.items():
+            assert np.array_equal(np.asarray(arr).reshape(weights[name].shape), weights[name]), name
+    with hdf5.File(path) as f:
+        assert f['encoder_lstm_2/encoder_lstm_2/backward_encoder_lstm_2/kernel:0'].shape == (64, 128)

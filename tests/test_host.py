@@ -84,19 +84,25 @@ def test_vectorize_lines_equals_oracle_layouts():
 
 
 def test_unsupported_topology_is_refused():
-    for flag in ('deep_bidirectional_encoder', 'lm_loss', 'lm_predict', 'stateful'):
+    for flag in ('lm_loss', 'lm_predict', 'stateful'):
         s2s = Sequence2Sequence()
         setattr(s2s, flag, True)
         with pytest.raises(NotImplementedError):
             s2s.configure()
-    # residual_connections / bridge_dense (seq2seq.py:284-301) are built since round 6: configure() takes them, and a bridged
-    # model has the Dense layers' tensors
+    # residual_connections / bridge_dense / deep_bidirectional_encoder (seq2seq.py:246-301) are built since round 6: configure() takes
+    # them, and a bridged model has the Dense layers' tensors
     s2s = Sequence2Sequence()
     s2s.residual_connections = s2s.bridge_dense = True
     s2s.depth, s2s.width, s2s.voc_size = 3, 32, 12
     s2s.configure()
     w = s2s.get_weights()
     assert w['bridge3_c_K'].shape == (32, 32) and w['bridge1_h_b'].shape == (32,) and not w['bridge1_h_b'].any()
+    s2s = Sequence2Sequence()
+    s2s.deep_bidirectional_encoder = True
+    s2s.depth, s2s.width, s2s.voc_size = 3, 32, 12
+    s2s.configure()
+    w = s2s.get_weights()
+    assert w['enc3_bw_K'].shape == (64, 128) and w['dec3_K'].shape == (96, 128) and w['att_U'].shape == (64, 32) and 'enc2_K' not in w
     s2s = Sequence2Sequence()
     s2s.scheduled_sampling = 'linear'
     with pytest.raises(NotImplementedError):

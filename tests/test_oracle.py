@@ -349,3 +349,32 @@ def test_keras_golden_hook_reads_the_schema_its_generator_writes(golden_dir, tmp
     np.savez_compressed(str(tmp_path / (name + '.npz')), **out)
     with pytest.raises(AssertionError):
         test_oracle_matches_keras_goldens(golden_dir)
+
+
+def test_deep_bidirectional_encoder_matches_torch():
+    """deep_bidirectional_encoder (seq2seq.py:246-281) against torch BiLSTMs in float64: every layer bidirectional, fed the Lambda's
+    "cross sum" of the layer below -- x + pairwise-reversed x, i.e. both features 2k and 2k+1 become x[2k] + x[2k+1] --, the backward
+    final states handed on, enc_out 2W wide."""
+    from oracle.model import cross_sum
+    cfg = ModelConfig(depth=3, width=32, voc_size=40, deep_bidirectional_encoder=True)
+    assert cfg.ctx_width == 64
+    w = make_weights(cfg, dtype=np.float64, emb_scale=8.0)
+    assert w['enc3_bw_K'].shape == (64, 128) and w['dec3_K'].shape == (32 + 64, 128) and w['att_U'].shape == (64, 32)
+    x = np.arange(12.0).reshape(1, 2, 6)
+    assert np.array_equal(cross_sum(x)[0, 0], [1, 1, 5, 5, 9, 9])
+    lines, idx = make_lines(5, 17, 3, voc_size=40)
+    xin = np.eye(40)[idx]
+    out = encode(cfg, w, xin)
+    with torch.no_grad():
+        y = torch.tensor(xin @ w['E'])
+        states = []
+        for n in (1, 2, 3):
+            if n > 1:
+                y = y + y.reshape(y.shape[:-1] + (y.shape[-1] // 2, 2)).flip(-1).reshape(y.shape)
+            layer = _torch_lstm(w['enc%d_fw_K' % n], w['enc%d_fw_R' % n], w['enc%d_fw_b' % n], True,
+                                w['enc%d_bw_K' % n], w['enc%d_bw_R' % n], w['enc%d_bw_b' % n])
+            y, (h, c) = layer(y)
+            states += [h[1].numpy(), c[1].numpy()]
+    assert out[0].shape == (5, 18, 64) and np.allclose(out[0], y.numpy(), atol=1e-10)
+    for got, want in zip(out[1:7], states):
+        assert np.allclose(got, want, atol=1e-10)
