@@ -46,6 +46,7 @@ struct TrainState {
     DevBuf e_idx, e_val, d_in, d_out, d_w, m_enc, m_dec, m_cell;
     DevBuf X0, H1, u, Y0, Ym, WQ, Ast, WIN, RecIn, prev, logits, dG, d_enc, du, DWQ, DSrows, dhatt, dfin, dcbuf, dcbuf2, HP, dX0, dXtop, dXl, dYl, dOin, dvaP, dbvP;
     std::vector<DevBuf> O, DO;             // masked layer outputs (encoder O[n], decoder DO[n])
+    std::vector<DevBuf> XD;                // deep_bidirectional_encoder: layer n's input = the cross sum of O[n-1] (seq2seq.py:246-259)
     DevBuf loss, normsq;
     DevBuf dcalt;                          // second dL/dc buffers of the fused backward steps (two layers)
     DevBuf rec_cnt; int rec_launches = 0, rec_checked = 0, rec_skip = 0, rec_penalty = 0;   // persistent recurrences: counters per launch, back-off
@@ -128,6 +129,7 @@ int casv_train_release(casv_model* m) {
     for (DevBuf* b : bufs) b->release();
     for (auto& b : ts->O) b.release();
     for (auto& b : ts->DO) b.release();
+    for (auto& b : ts->XD) b.release();
     delete ts;
     m->train = nullptr;
     return 0;
@@ -150,8 +152,6 @@ static void refresh_derived(casv_model* m) {
 extern "C" int casv_train_begin(casv_model* m, const casv_adam_params* ap, const char* frozen_csv) {
     if (!m || !ap) return fail(CASV_ERR_ARG, "null argument");
     if (m->W > 1024) return fail(CASV_ERR_ARG, "training supports width <= 1024");
-    if (m->cfg.deep_bidirectional_encoder && m->D >= 2)
-        return fail(CASV_ERR_ARG, "the train step has no deep_bidirectional_encoder form yet (such models decode, they do not train)");
     HIPCHK(hipSetDevice(m->device));
     for (auto& kv : m->expect)
         if (!m->host.count(kv.first)) return fail(CASV_ERR_STATE, "weight '%s' has not been set", kv.first.c_str());
@@ -177,7 +177,10 @@ extern "C" int casv_train_begin(casv_model* m, const casv_adam_params* ap, const
     };
     ts->iE = add_tensor(ts, "E", m->host["E"], false);
     int rc = add_lstm("enc1_fw", W, 0, false) | add_lstm("enc1_bw", W, 0, true);
-    for (int n = 2; n <= D; ++n) rc |= add_lstm("enc" + std::to_string(n), n == 2 ? 2 * W : W, 0, false);
+    const bool deep_b = m->cfg.deep_bidirectional_encoder != 0;
+    for (int n = 2; n <= D && !deep_b; ++n) rc |= add_lstm("enc" + std::to_string(n), n == 2 ? 2 * W : W, 0, false);
+    for (int n = 2; n <= D && deep_b; ++n)      // every layer bidirectional, 2W-wide inputs (seq2seq.py:273-276): [.. encN_fw, encN_bw ..]
+        rc |= add_lstm("enc" + std::to_string(n) + "_fw", 2 * W, 0, false) | add_lstm("enc" + std::to_string(n) + "_bw", 2 * W, 0, true);
     for (int n = 1; n < D; ++n) rc |= add_lstm("dec" + std::to_string(n), W, 0, false);
     rc |= add_lstm("dec" + std::to_string(D), W, C, false);
     std::vector<float> ut((size_t)W * C), wat((size_t)W * W);
@@ -210,7 +213,7 @@ extern "C" int casv_train_begin(casv_model* m, const casv_adam_params* ap, const
     if (ts->ETp.ensure((size_t)W * Vp * 4) || ts->WaN.ensure((size_t)W * W * 4) || ts->UaN.ensure((size_t)C * W * 4) ||
         ts->loss.ensure(16) || ts->normsq.ensure(16)) { casv_train_release(m); return fail(CASV_ERR_NOMEM, "out of memory"); }
     HIPCHK(hipMemset(ts->ETp.p, 0, (size_t)W * Vp * 4));
-    ts->O.resize(D + 1); ts->DO.resize(D + 1);
+    ts->O.resize(D + 1); ts->DO.resize(D + 1); ts->XD.resize(D + 1);
     refresh_derived(m);
     HIPCHK(hipStreamSynchronize(m->stream));
     return CASV_OK;
@@ -513,7 +516,8 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     // ---- buffers ----
 #define ENS(buf, bytes) if (int rc_ = (buf).ensure(bytes)) return rc_;
     ENS(ts->e_idx, TB * A * 4) ENS(ts->e_val, TB * A * 4) ENS(ts->d_in, UB * 4) ENS(ts->d_out, UB * 4) ENS(ts->d_w, UB * 4)
-    ENS(ts->m_enc, (size_t)(D + 1) * W * 4) ENS(ts->m_dec, (size_t)D * W * 4) ENS(ts->m_cell, (size_t)B * (W + C) * 4)
+    const bool deep = m->cfg.deep_bidirectional_encoder != 0 && D >= 2;
+    ENS(ts->m_enc, (size_t)std::max(D + 1, 2 * D) * W * 4) ENS(ts->m_dec, (size_t)D * W * 4) ENS(ts->m_cell, (size_t)B * (W + C) * 4)
     ENS(ts->X0, TB * W * 4) ENS(ts->H1, TB * 2 * W * 4) ENS(ts->u, TB * W * 4) ENS(ts->Y0, UB * W * 4) ENS(ts->Ym, UB * W * 4)
     ENS(ts->WQ, UB * W * 4) ENS(ts->Ast, (size_t)(U + 1) * B * T * 4) ENS(ts->WIN, UB * 4)
     ENS(ts->RecIn, UB * (C + W) * 4) ENS(ts->prev, (size_t)B * 4) ENS(ts->logits, UB * Vp * 4)
@@ -528,13 +532,16 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
         ENS(l.Cs, rows * W * 4) ENS(l.Gt, rows * 4 * W * 4) ENS(l.Z, rows * 4 * W * 4) ENS(l.dRec, rows * l.kr * 4)
         if (l.name == "enc1_fw") { l.hs = ts->H1.as<float>(); l.hs_ld = 2 * W; }
         else if (l.name == "enc1_bw") { l.hs = ts->H1.as<float>() + W; l.hs_ld = 2 * W; }
+        else if (deep && enc && l.name.size() > 3 && l.name.compare(l.name.size() - 3, 3, "_fw") == 0) { ENS(l.Hown, rows * 2 * W * 4) l.hs = l.Hown.as<float>(); l.hs_ld = 2 * W; }
+        else if (deep && enc) { l.hs = (&l - 1)->hs + W; l.hs_ld = 2 * W; }        // (a backward direction: the second half of its forward partner's rows)
         else { ENS(l.Hown, rows * W * 4) l.hs = l.Hown.as<float>(); l.hs_ld = W; }
     }
     ENS(ts->rec_cnt, 16 * train_recurrence_bwd_counter_bytes(B)) ENS(ts->dcalt, (size_t)2 * B * W * 4)
     const bool residual = m->cfg.residual_connections != 0, bridged = m->cfg.bridge_dense != 0;
     if (bridged) { ENS(ts->hbr, (size_t)D * B * W * 4) ENS(ts->cbr, (size_t)D * B * W * 4) ENS(ts->brtmp, (size_t)B * W * 4) }
     if (residual && D >= 2) ENS(ts->Ytop, UB * W * 4)
-    for (int n = 1; n <= D; ++n) ENS(ts->O[n], TB * (n == 1 ? 2 * W : W) * 4)
+    for (int n = 1; n <= D; ++n) ENS(ts->O[n], TB * ((n == 1 || deep) ? 2 * W : W) * 4)
+    for (int n = 2; n <= D && deep; ++n) ENS(ts->XD[n], TB * 2 * W * 4)
     for (int n = 1; n < D; ++n) ENS(ts->DO[n], UB * W * 4)
 #undef ENS
     // ---- inputs ----
@@ -545,10 +552,10 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     HIPCHK(hipMemcpyAsync(ts->d_w.p, weights, UB * 4, hipMemcpyHostToDevice, st));
     // masks: enc = 2W + (D-1)*W floats, dec = (D-1)*W floats, cell = B*(W+C)
     const float* menc = nullptr; const float* mdec = nullptr; const float* mcell = nullptr;
-    if (mask_enc) { HIPCHK(hipMemcpyAsync(ts->m_enc.p, mask_enc, (size_t)(D + 1) * W * 4, hipMemcpyHostToDevice, st)); menc = ts->m_enc.as<float>(); }
+    if (mask_enc) { HIPCHK(hipMemcpyAsync(ts->m_enc.p, mask_enc, (size_t)(deep ? 2 * D : D + 1) * W * 4, hipMemcpyHostToDevice, st)); menc = ts->m_enc.as<float>(); }
     if (mask_dec && D > 1) { HIPCHK(hipMemcpyAsync(ts->m_dec.p, mask_dec, (size_t)(D - 1) * W * 4, hipMemcpyHostToDevice, st)); mdec = ts->m_dec.as<float>(); }
     if (mask_cell) { HIPCHK(hipMemcpyAsync(ts->m_cell.p, mask_cell, (size_t)B * (W + C) * 4, hipMemcpyHostToDevice, st)); mcell = ts->m_cell.as<float>(); }
-    auto menc_n = [&](int n) { return menc ? menc + (n == 1 ? 0 : 2 * W + (n - 2) * W) : nullptr; };   // layer n (1-based)
+    auto menc_n = [&](int n) { return menc ? menc + (n == 1 ? 0 : deep ? (n - 1) * 2 * W : 2 * W + (n - 2) * W) : nullptr; };   // layer n (1-based)
     auto mdec_n = [&](int n) { return mdec ? mdec + (n - 1) * W : nullptr; };
     long cnt = 0;
     for (long long i = 0; i < UB; ++i) cnt += weights[i] != 0.f;
@@ -562,8 +569,9 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     if (training) for (auto& t : ts->tens) HIPCHK(hipMemsetAsync(t.g.p, 0, t.n * 4, st));
 
     TLayer* Lfw = &ts->layers[0]; TLayer* Lbw = &ts->layers[1];
-    auto enc_layer = [&](int n) -> TLayer& { return ts->layers[n]; };            // n >= 2 -> index n
-    auto dec_layer = [&](int n) -> TLayer& { return ts->layers[D + n]; };        // n = 1..D -> index D+n
+    auto enc_layer = [&](int n) -> TLayer& { return ts->layers[n]; };            // n >= 2 -> index n (not with a deep bidirectional encoder)
+    auto enc_dir = [&](int n, int dir) -> TLayer& { return ts->layers[2 * (n - 1) + dir]; };      // deep: layer n = 1..D, direction 0 fw / 1 bw
+    auto dec_layer = [&](int n) -> TLayer& { return ts->layers[(deep ? 2 * D - 1 : D) + n]; };    // n = 1..D
     float* hfin = m->hfin.as<float>(); float* cfin = m->cfin.as<float>();
     if (int rc = m->hfin.ensure((size_t)D * B * W * 4)) return rc;
     if (int rc = m->cfin.ensure((size_t)(D + 1) * B * W * 4)) return rc;
@@ -602,7 +610,35 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     // Encoder layer n and decoder layer n-1 depend only on encoder layer n-1 / decoder layer n-2, so the two
     // recurrences advance in lockstep, one launch per step for both.
     const float* y = ts->Y0.as<float>();
-    for (int n = 2; n <= D; ++n) {
+    // deep_bidirectional_encoder (seq2seq.py:246-281): every encoder layer n >= 2 is a BiLSTM on the cross sum of the (dropped-out) layer
+    // below; its two directions are the pair of a launch, the decoder layer n - 1 walks alone
+    for (int n = 2; n <= D && deep; ++n) {
+        TLayer& lf = enc_dir(n, 0); TLayer& lb = enc_dir(n, 1); TLayer& ld = dec_layer(n - 1);
+        launch_cross_sum(ts->O[n - 1].as<float>(), ts->XD[n].as<float>(), TB * 2 * W, st);
+        layer_input_gemm(m, lf, ts->XD[n].as<float>(), 2 * W);
+        layer_input_gemm(m, lb, ts->XD[n].as<float>(), 2 * W);
+        layer_input_gemm(m, ld, y, W);
+        bool maskede = false, maskedd = false;
+        {
+            const LayerFwd f[2] = {{&lf, nullptr, nullptr, ts->O[n].as<float>(), 2 * W, menc_n(n)},
+                                   {&lb, nullptr, nullptr, ts->O[n].as<float>() + W, 2 * W, menc_n(n) ? menc_n(n) + W : nullptr}};
+            if (int rc = layers_forward(m, f, 2, &maskede)) return rc;
+        }
+        HIPCHK(hipMemcpy2DAsync(hfin + (size_t)(n - 1) * B * W, (size_t)W * 4, lb.hs, (size_t)2 * W * 4, (size_t)W * 4, B, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(cfin + (size_t)(n - 1) * B * W, lb.Cs.p, (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+        bridge_forward(n);
+        if (!maskede) launch_mul_mask(lf.hs, 2 * W, menc_n(n), ts->O[n].as<float>(), 2 * W, TB, 2 * W, st);
+        const float* h0 = h0base + (size_t)(n - 2) * B * W; const float* c0 = c0base + (size_t)(n - 2) * B * W;
+        const bool res_n = residual && n >= 3;
+        {
+            const LayerFwd f[1] = {{&ld, h0, c0, res_n ? nullptr : ts->DO[n - 1].as<float>(), W, mdec_n(n - 1)}};
+            if (int rc = layers_forward(m, f, 1, &maskedd)) return rc;
+        }
+        if (res_n) launch_add_mul_mask(ld.hs, W, y, W, mdec_n(n - 1), ts->DO[n - 1].as<float>(), W, UB, W, st);
+        else if (!maskedd) launch_mul_mask(ld.hs, W, mdec_n(n - 1), ts->DO[n - 1].as<float>(), W, UB, W, st);
+        y = ts->DO[n - 1].as<float>();
+    }
+    for (int n = 2; n <= D && !deep; ++n) {
         TLayer& le = enc_layer(n);
         TLayer& ld = dec_layer(n - 1);
         layer_input_gemm(m, le, ts->O[n - 1].as<float>(), le.kx);
@@ -914,7 +950,33 @@ extern "C" int casv_train_step(casv_model* m, int32_t mode, int32_t B, int32_t T
     // (a pair's input gradients are the next pair's output gradients: two buffers per chain taking turns, nothing is copied)
     float* dy_bufs[2] = {ts->dXtop.as<float>(), ts->dYl.as<float>()}; int dy_cur = 0;
     float* do_bufs[2] = {ts->dXl.as<float>(), ts->dOin.as<float>()}; int do_out = 0;
-    for (int n = D - 1; n >= 1; --n) {
+    for (int n = D - 1; n >= 1 && deep; --n) {
+        TLayer& ld = dec_layer(n);
+        TLayer& lf = enc_dir(n + 1, 0); TLayer& lb = enc_dir(n + 1, 1);
+        const float* xin = n == 1 ? ts->Y0.as<float>() : ts->DO[n - 1].as<float>();
+        const bool res_d = residual && n >= 2;
+        if (res_d) launch_mul_mask(dy, W, mdec_n(n), dy_bufs[dy_cur ^ 1], W, UB, W, st);
+        {
+            LayerBwd one[1] = {{&ld, dy, W, mdec_n(n), nullptr, nullptr, h0base + (size_t)(n - 1) * B * W, c0base + (size_t)(n - 1) * B * W, dfin_c(n),
+                                xin, W, dy_bufs[dy_cur ^ 1], W, res_d ? 1 : 0}};
+            if (int rc = layers_backward(m, one, 1)) return rc;
+        }
+        HIPCHK(hipMemcpyAsync(dfin_h(n), ld.dRec.as<float>(), (size_t)B * W * 4, hipMemcpyDeviceToDevice, st));
+        bridge_backward(n);
+        dy_cur ^= 1; dy = dy_bufs[dy_cur];
+        // the BiLSTM n + 1: forward direction takes columns [0,W) of dO, backward direction [W,2W); both add into the gradient of their
+        // shared input, whose cross sum (the Lambda is its own adjoint) is the gradient w.r.t. O[n]
+        float* dXn = do_bufs[0]; float* dOn = do_bufs[1];
+        LayerBwd pair[2] = {
+            {&lf, dO, ld_dO, menc_n(n + 1), nullptr, nullptr, nullptr, nullptr, ts->dcbuf.as<float>(),
+             ts->XD[n + 1].as<float>(), 2 * W, dXn, 2 * W, 0},
+            {&lb, dO + W, ld_dO, menc_n(n + 1) ? menc_n(n + 1) + W : nullptr, dfin_h(n + 1), dfin_c(n + 1), nullptr, nullptr, ts->dcbuf2.as<float>(),
+             ts->XD[n + 1].as<float>(), 2 * W, dXn, 2 * W, 1}};
+        if (int rc = layers_backward(m, pair, 2)) return rc;
+        launch_cross_sum(dXn, dOn, TB * 2 * W, st);
+        dO = dOn; ld_dO = 2 * W;
+    }
+    for (int n = D - 1; n >= 1 && !deep; --n) {
         TLayer& ld = dec_layer(n);
         TLayer& le = enc_layer(n + 1);
         const float* xin = n == 1 ? ts->Y0.as<float>() : ts->DO[n - 1].as<float>();

@@ -132,9 +132,10 @@ def dropout_masks(s2s, B, rng):
     if rate <= 0.0:
         return None
     W, d = s2s.width, s2s.depth
-    C = 2 * W if d == 1 else W
+    deep = bool(getattr(s2s, 'deep_bidirectional_encoder', False))      # every encoder layer 2W wide (seq2seq.py:292-295)
+    C = 2 * W if (d == 1 or deep) else W
     keep = lambda shape: ((rng.uniform(0, 1, shape) >= rate) / (1.0 - rate)).astype(np.float32)
-    return {'enc': [keep(2 * W if n == 0 else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
+    return {'enc': [keep(2 * W if (n == 0 or deep) else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
             'cell': keep((B, W + C))}
 
 

@@ -84,7 +84,8 @@ def forward_backward(cfg, w, enc_in, dec_in, dec_out, weights, masks=None, want_
     B, T, _ = enc_in.shape
     U = dec_in.shape[1]
     one = lambda n: np.ones(n, dt)
-    m_enc = [one(2 * W if n == 0 else W) for n in range(d)] if masks is None else [np.asarray(m, dt) for m in masks['enc']]
+    deep = bool(getattr(cfg, 'deep_bidirectional_encoder', False))
+    m_enc = [one(2 * W if (n == 0 or deep) else W) for n in range(d)] if masks is None else [np.asarray(m, dt) for m in masks['enc']]
     m_dec = [one(W) for _ in range(d - 1)] if masks is None else [np.asarray(m, dt) for m in masks['dec']]
     m_cell = np.ones((B, W + C), dt) if masks is None else np.asarray(masks['cell'], dt)
 
@@ -98,7 +99,16 @@ def forward_backward(cfg, w, enc_in, dec_in, dec_out, weights, masks=None, want_
     enc_caches = [None]
     fin = [(hb, cb)]
     res = bool(getattr(cfg, 'residual_connections', False))
+    cross = lambda x: x + x.reshape(x.shape[:-1] + (x.shape[-1] // 2, 2))[..., ::-1].reshape(x.shape)     # seq2seq.py:246-259 (model.cross_sum)
     for n in range(2, d + 1):
+        if deep:            # every layer bidirectional on the cross sum of the (dropped-out) layer below; backward final states handed on
+            xin = cross(O[-1])
+            _, _, _, cfw = lstm_forward(xin, w['enc%d_fw_K' % n], w['enc%d_fw_R' % n], w['enc%d_fw_b' % n])
+            _, h, c, cbw2 = lstm_forward(xin, w['enc%d_bw_K' % n], w['enc%d_bw_R' % n], w['enc%d_bw_b' % n], reverse=True)
+            enc_caches.append((cfw, cbw2))
+            Hn = np.concatenate([cfw['h'], cbw2['h']], axis=2)
+            H.append(Hn); O.append(Hn * m_enc[n - 1]); fin.append((h, c))
+            continue
         Hn, h, c, cache = lstm_forward(O[-1], w['enc%d_K' % n], w['enc%d_R' % n], w['enc%d_b' % n])
         enc_caches.append(cache)
         # residual_connections (seq2seq.py:284-291): output sequence = LSTM output + the layer's (already dropped-out) input
@@ -247,6 +257,12 @@ def forward_backward(cfg, w, enc_in, dec_in, dec_out, weights, masks=None, want_
     dO = d_enc_out
     for n in range(d, 1, -1):
         dHn = dO * m_enc[n - 1]
+        if deep:
+            cfw, cbw2 = enc_caches[n - 1]
+            dXf, g_['enc%d_fw_K' % n], g_['enc%d_fw_R' % n], g_['enc%d_fw_b' % n], _, _ = lstm_backward(cfw, dHn[:, :, :W])
+            dXb, g_['enc%d_bw_K' % n], g_['enc%d_bw_R' % n], g_['enc%d_bw_b' % n], _, _ = lstm_backward(cbw2, dHn[:, :, W:], dfin[n - 1][0], dfin[n - 1][1])
+            dO = cross(dXf + dXb)           # (the cross sum is its own adjoint: x + P x with a symmetric permutation P)
+            continue
         dX, dK, dR, db, _, _ = lstm_backward(enc_caches[n - 1], dHn, dfin[n - 1][0], dfin[n - 1][1])
         g_['enc%d_K' % n], g_['enc%d_R' % n], g_['enc%d_b' % n] = dK, dR, db
         dO = dX + dHn if (res and n >= 3) else dX

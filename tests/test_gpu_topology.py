@@ -20,7 +20,6 @@ from oracle.decode import OracleModel, correct_lines, decode_batch_greedy
 RT, AT = 2e-4, 2e-6
 FLAGS = [dict(residual_connections=True), dict(bridge_dense=True), dict(residual_connections=True, bridge_dense=True),
          dict(deep_bidirectional_encoder=True), dict(deep_bidirectional_encoder=True, bridge_dense=True, residual_connections=True)]
-TRAINABLE = FLAGS[:3]
 
 
 def _engine(cfg, weights, **kw):

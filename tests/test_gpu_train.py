@@ -45,6 +45,17 @@ def test_train_step_with_optional_topologies_matches_oracle(d, W, V, B, L, es, w
     _train_step_case(d, W, V, B, L, es, with_masks, path, flags)
 
 
+@pytest.mark.parametrize('flags', [dict(deep_bidirectional_encoder=True),
+                                   dict(deep_bidirectional_encoder=True, residual_connections=True, bridge_dense=True)])
+@pytest.mark.parametrize('d,W,V,B,L,es,with_masks', [(4, 64, 96, 6, 10, 8.0, True), (3, 128, 40, 37, 7, 4.0, True), (2, 96, 40, 5, 8, 4.0, True),
+                                                     (5, 96, 40, 5, 8, 4.0, False)])
+@pytest.mark.parametrize('path', ['fused', 'stepwise'])
+def test_train_step_with_a_deep_bidirectional_encoder_matches_oracle(d, W, V, B, L, es, with_masks, path, flags):
+    """deep_bidirectional_encoder (seq2seq.py:246-281) in the train step: every encoder layer a BiLSTM on the cross sum of the layer
+    below (2W-wide masks, inputs and attended sequence), alone and with the other two optional topologies."""
+    _train_step_case(d, W, V, B, L, es, with_masks, path, flags)
+
+
 def _train_step_case(d, W, V, B, L, es, with_masks, path, flags):
     from cor_asv_ann_amd.engine import HipEngine
     cfg = ModelConfig(depth=d, width=W, voc_size=V, **flags)
@@ -62,7 +73,7 @@ def _train_step_case(d, W, V, B, L, es, with_masks, path, flags):
     masks = None
     if with_masks:
         keep = lambda shape: ((rng.random(shape) > 0.2) / 0.8).astype(np.float32)
-        masks = {'enc': [keep(2 * W if n == 0 else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
+        masks = {'enc': [keep(2 * W if (n == 0 or cfg.deep_bidirectional_encoder) else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
                  'cell': keep((B, W + C))}
     loss, grads, aux = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, masks)
     eng = HipEngine(d, W, V, **flags)

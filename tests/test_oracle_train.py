@@ -37,6 +37,13 @@ def torch_loss(cfg, w, enc_in, dec_in, dec_out, weights, masks):
     fin = [(hb, cb)]
     res, bridged = cfg.residual_connections, cfg.bridge_dense
     for n in range(2, d + 1):
+        if cfg.deep_bidirectional_encoder:          # seq2seq.py:246-281, written as the Keras layers are
+            xin = out + out.reshape(out.shape[:-1] + (out.shape[-1] // 2, 2)).flip(-1).reshape(out.shape)
+            f2, _, _ = _lstm(xin, w['enc%d_fw_K' % n], w['enc%d_fw_R' % n], w['enc%d_fw_b' % n], W)
+            b2, h, c = _lstm(xin, w['enc%d_bw_K' % n], w['enc%d_bw_R' % n], w['enc%d_bw_b' % n], W, reverse=True)
+            out = torch.cat([f2, b2], 2) * masks['enc'][n - 1]
+            fin.append((h, c))
+            continue
         hs, h, c = _lstm(out, w['enc%d_K' % n], w['enc%d_R' % n], w['enc%d_b' % n], W)
         if res and n >= 3:                  # the training graph of seq2seq.py:284-291, written as the Keras layers are
             hs = hs + out
@@ -86,7 +93,9 @@ def torch_loss(cfg, w, enc_in, dec_in, dec_out, weights, masks):
 @pytest.mark.parametrize('d,with_masks,flags', [(1, False, {}), (2, True, {}), (3, False, {}),
                                                 (4, True, dict(residual_connections=True)), (2, True, dict(residual_connections=True)),
                                                 (3, True, dict(bridge_dense=True)), (1, False, dict(bridge_dense=True)),
-                                                (4, True, dict(residual_connections=True, bridge_dense=True))])
+                                                (4, True, dict(residual_connections=True, bridge_dense=True)),
+                                                (3, True, dict(deep_bidirectional_encoder=True)), (2, False, dict(deep_bidirectional_encoder=True)),
+                                                (3, True, dict(deep_bidirectional_encoder=True, bridge_dense=True, residual_connections=True))])
 def test_backward_matches_autograd(d, with_masks, flags):
     W, V = 16, 12
     cfg = ModelConfig(depth=d, width=W, voc_size=V, **flags)
@@ -104,10 +113,10 @@ def test_backward_matches_autograd(d, with_masks, flags):
     C = cfg.ctx_width
     if with_masks:
         keep = lambda shape: (rng.random(shape) > 0.2) / 0.8
-        masks = {'enc': [keep(2 * W if n == 0 else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
+        masks = {'enc': [keep(2 * W if (n == 0 or cfg.deep_bidirectional_encoder) else W) for n in range(d)], 'dec': [keep(W) for _ in range(d - 1)],
                  'cell': keep((4, W + C))}
     else:
-        masks = {'enc': [np.ones(2 * W if n == 0 else W) for n in range(d)], 'dec': [np.ones(W) for _ in range(d - 1)],
+        masks = {'enc': [np.ones(2 * W if (n == 0 or cfg.deep_bidirectional_encoder) else W) for n in range(d)], 'dec': [np.ones(W) for _ in range(d - 1)],
                  'cell': np.ones((4, W + C))}
     loss, grads, aux = forward_backward(cfg, w, enc_in, dec_in, dec_out, wts, masks)
     tw = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
