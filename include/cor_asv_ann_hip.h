@@ -40,12 +40,15 @@ typedef enum {
     CASV_ERR_NAN = -5       /* numpy would have raised "All-NaN slice" (seq2seq.py:1329,1335) */
 } casv_status;
 
-/* Topology of seq2seq.py:108-157.  residual_connections (seq2seq.py:284-291, 359-360) and bridge_dense (seq2seq.py:299-301) are
- * built: encoder layers >= 3 hand on LSTM output + input sequence, the final h / c of every encoder layer pass through
- * Dense(width, tanh) layers "bridge<n>_h_K|b", "bridge<n>_c_K|b" ((W,W) kernel, (W) bias) on their way to the decoder; the train
- * step adds the training graph's decoder sums (layers >= 2 and the projection's input) -- which the reference's inference decoder
- * does not have (seq2seq.py:421-436), restated as it is.  deep_bidirectional_encoder, lm_loss/lm_predict and stateful must be 0
- * (both published models use the default topology, wrapper/ocrd-tool.json:61-74). */
+/* Topology of seq2seq.py:108-157.  residual_connections (seq2seq.py:284-291, 359-360), bridge_dense (seq2seq.py:299-301) and
+ * deep_bidirectional_encoder (seq2seq.py:246-281) are built: encoder layers >= 3 hand on LSTM output + input sequence; the final
+ * h / c of every encoder layer pass through Dense(width, tanh) layers "bridge<n>_h_K|b", "bridge<n>_c_K|b" ((W,W) kernel, (W) bias)
+ * on their way to the decoder; with a deep bidirectional encoder EVERY encoder layer n is a BiLSTM ("enc<n>_fw_K|R|b",
+ * "enc<n>_bw_K|R|b", kernels (2W,4W) for n >= 2) that reads the reference Lambda's "cross sum" of the layer below -- features 2k and
+ * 2k+1 of [fw | bw] both replaced by their sum -- and hands on its backward final state; the attended width is then 2 * width for
+ * every depth (att_U (2W,W), top decoder kernel (3W,4W)).  The train step adds the training graph's decoder sums (layers >= 2 and
+ * the projection's input) -- which the reference's inference decoder does not have (seq2seq.py:421-436), restated as it is.
+ * lm_loss/lm_predict and stateful must be 0 (both published models use the default topology, wrapper/ocrd-tool.json:61-74). */
 typedef struct {
     int32_t depth;          /* seq2seq.py:117 */
     int32_t width;          /* seq2seq.py:115; must be a multiple of 32 (any other width: pad with dead units, as
@@ -163,7 +166,8 @@ int casv_train_begin(casv_model* m, const casv_adam_params* p, const char* froze
  * enc_idx/enc_val: encoder input as in casv_encode, (B,T,A); dec_in / dec_out: (B,U) character indices of the
  * one-hot decoder input and target rows of vectorize_lines (seq2seq.py:1095-1106), -1 = true-zero row;
  * weights (B,U) temporal sample weights (seq2seq.py:1111-1112).  Dropout enters as explicit keep-masks already
- * scaled by 1/(1-rate), or NULL for none: mask_enc = 2W + (depth-1)*W floats (seq2seq.py:293-298), mask_dec =
+ * scaled by 1/(1-rate), or NULL for none: mask_enc = 2W + (depth-1)*W floats (seq2seq.py:293-298; depth*2W with a deep
+ * bidirectional encoder), mask_dec =
  * (depth-1)*W floats (seq2seq.py:363-367), mask_cell = (B, W+C) (LSTMCell(dropout), seq2seq.py:345).
  * loss = weighted categorical cross-entropy (+ embedding regulariser in the train phase); grad_norm = global
  * L2 norm of the gradients before clipping. */

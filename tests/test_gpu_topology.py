@@ -113,10 +113,11 @@ def test_model_file_round_trip_with_bridge_layers(tmp_path):
     again.engine.close()
 
 
-def test_facade_trains_a_model_with_both_flags(tmp_path):
+@pytest.mark.parametrize('deep', [False, True])
+def test_facade_trains_a_model_with_the_flags_set(tmp_path, deep):
     """cor-asv-ann-train's path (`Sequence2Sequence.train()`, seq2seq.py:590-649) on a small copy task with residual_connections and
-    bridge_dense set: the validation loss falls, the trained model -- bridges included -- decodes like the oracle on its weights and
-    survives the reference's container."""
+    bridge_dense set -- and, second case, a deep bidirectional encoder on top: the validation loss falls, the trained model --
+    bridges included -- decodes like the oracle on its weights and survives the reference's container."""
     import os
     from cor_asv_ann_amd.seq2seq import Sequence2Sequence
     rng = np.random.default_rng(5)
@@ -129,6 +130,7 @@ def test_facade_trains_a_model_with_both_flags(tmp_path):
         s2s = Sequence2Sequence()
         s2s.depth, s2s.width, s2s.batch_size, s2s.epochs, s2s.dropout = 3, 64, 32, 16, 0.1
         s2s.residual_connections = s2s.bridge_dense = True
+        s2s.deep_bidirectional_encoder = deep
         s2s._rng = np.random.default_rng(1)
         s2s.configure()
         s2s.train([str(tmp_path / 'train.tsv')])
@@ -140,7 +142,8 @@ def test_facade_trains_a_model_with_both_flags(tmp_path):
     assert 'bridge3_c_K' in w and np.abs(w['bridge1_h_b']).max() > 0          # (the Dense layers trained: their biases left zero)
     test = [l + '\n' for l in lines[:6]]
     s2s.batch_size = 4
-    cfg = ModelConfig(depth=3, width=64, voc_size=s2s.voc_size, residual_connections=True, bridge_dense=True)
+    cfg = ModelConfig(depth=3, width=64, voc_size=s2s.voc_size, residual_connections=True, bridge_dense=True, deep_bidirectional_encoder=deep)
+    assert ('enc3_bw_K' in w) == deep
     om = OracleModel(cfg, w, mapping=s2s.mapping, batch_size=4)
     got, want = s2s.correct_lines(test, fast=True, greedy=True), correct_lines(om, test, fast=True, greedy=True)
     assert got[0] == want[0] and np.allclose(got[2], want[2], atol=1e-4)
