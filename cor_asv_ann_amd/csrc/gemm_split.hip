@@ -50,10 +50,18 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // the shader clock the loop ran at (the bf16 matrix pipe with and without memory traffic beside it: power management).
 #ifdef CASV_S2_CLOCK
 __device__ unsigned long long g_s2_clk[4];
+// ... and every workgroup adds the wall-clock ticks (10 ns) of its phases: [0] entry -> first steady tile (prologue), [1] steady loop,
+// [2] tail tiles, [3] epilogue (cells, stores) -> end, [4] workgroups counted
+__device__ unsigned long long g_s2_phase[8];
 void s2_clock_dump() {
-    unsigned long long h[4];
+    unsigned long long h[4], ph[8];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_s2_clk), sizeof(h));
+    (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_s2_phase), sizeof(ph));
     if (h[1]) fprintf(stderr, "gemm_split256: loop of workgroup 0: %llu cycles in %llu wall ticks (10 ns) = %.3f GHz\n", h[0], h[1], (double)h[0] / (double)h[1] * 0.1);
+    if (ph[4]) fprintf(stderr, "gemm_split256: per workgroup (average of %llu), us: prologue %.2f, steady loop %.2f, tail tiles %.2f, epilogue %.2f\n", ph[4],
+                       ph[0] * 0.01 / ph[4], ph[1] * 0.01 / ph[4], ph[2] * 0.01 / ph[4], ph[3] * 0.01 / ph[4]);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_s2_phase), z, sizeof(z));
 }
 #endif
 constexpr int S2_BM = 256, S2_BN = 256, S2_BK = 16;
@@ -77,6 +85,9 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     extern __shared__ __attribute__((aligned(16))) char s2_smem[];
     const GemmArgs& g = batch.g[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CASV_S2_CLOCK
+    const unsigned long long ph_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
     const int step = __builtin_amdgcn_readfirstlane(g.step_ptr ? *g.step_ptr : g.step_imm);
@@ -508,8 +519,9 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     }
 
 #ifdef CASV_S2_CLOCK
+    const unsigned long long ph_t2 = __builtin_amdgcn_s_memrealtime();
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        g_s2_clk[0] = __builtin_amdgcn_s_memtime() - ck0; g_s2_clk[1] = __builtin_amdgcn_s_memrealtime() - cr0;
+        g_s2_clk[0] = __builtin_amdgcn_s_memtime() - ck0; g_s2_clk[1] = ph_t2 - cr0;
     }
 #endif
     // ---- previous cell state: every wave fetches the 64 rows x 32 units it will need itself, as LDS-DMA under the last tiles ----
@@ -545,6 +557,9 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
 #undef CASV_S2_MMA
 #undef CASV_S2_PIN
     CASV_S2_LANDED(gt);                                  // (pins the staging registers until nothing can be in flight into them)
+#ifdef CASV_S2_CLOCK
+    const unsigned long long ph_t3 = __builtin_amdgcn_s_memrealtime();
+#endif
 #undef CASV_S2_LANDED
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the wave's own cell-state transfers (an LDS-DMA must not outlive its workgroup either)
 
@@ -589,6 +604,14 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
             hb[(long long)dm * g.out.ld] = hv[r];
         }
     }
+#ifdef CASV_S2_CLOCK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the stores have left)
+    if (tid == 0) {
+        const unsigned long long ph_t4 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&g_s2_phase[0], cr0 - ph_t0); atomicAdd(&g_s2_phase[1], ph_t2 - cr0); atomicAdd(&g_s2_phase[2], ph_t3 - ph_t2);
+        atomicAdd(&g_s2_phase[3], ph_t4 - ph_t3); atomicAdd(&g_s2_phase[4], 1ull);
+    }
+#endif
 }
 
 // ---- weight images (BIMG) ----
