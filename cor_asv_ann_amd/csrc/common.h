@@ -162,6 +162,7 @@ struct TnArgs {
     int nsplit;          // set by launch_gemm_tn: K shares of the launch
 };
 void launch_gemm_tn(const TnArgs& g, hipStream_t stream);
+bool launch_gemm_tn_split(const TnArgs& g, hipStream_t stream);      // the same contraction on bf16x3-split operands (gemm_tn_split.hip); false: no such form for the shape
 void launch_gemm(int epi, const GemmArgs& g, hipStream_t stream);
 void launch_gemm_batch(int epi, const GemmBatch& b, hipStream_t stream);
 void launch_gemm_skinny(int epi, const GemmBatch& b, int ksplit, int rows, hipStream_t stream);

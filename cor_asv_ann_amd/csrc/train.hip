@@ -256,7 +256,8 @@ static void run_gemm_tn(casv_model* m, const float* A, long long lda, int M, int
     g.colsum = colsum;
     hipEvent_t ev{};
     m->prof_begin(PC_GEMM, 2.0 * Mstore * (double)N * (double)K, 4.0 * ((double)K * (M + N) + (double)Mstore * N), ev);
-    launch_gemm_tn(g, m->stream);
+    // (the step's arithmetic, engine.h ENTRY_TRAIN: the big weight gradients on bf16x3-split operands where the shape has that form)
+    if (!(gemm_split_bf16() && launch_gemm_tn_split(g, m->stream))) launch_gemm_tn(g, m->stream);
     m->prof_end(PC_GEMM, ev);
 }
 
