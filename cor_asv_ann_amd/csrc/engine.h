@@ -179,8 +179,9 @@ struct casv_model {
 //   ENTRY_CHAIN   the greedy decodes, the explicit decoder step, casv_get_encoder_outputs: the fp32-input instruction's k-ordered
 //                 chain (0) -- the arithmetic the persistent small-batch kernels are built on;
 //   ENTRY_TRAIN   casv_train_step: 2 -- the whole-sequence contractions that have a split form (input projections of all time
-//                 steps, their data gradients, logits: gemm_split.hip / gemm.hip's SPLIT tiles) take it; the persistent recurrences,
-//                 the per-time-step launches that must equal them and the K-major weight gradients are fp32-input kernels.
+//                 steps, their data gradients, logits: gemm_split.hip / gemm.hip's SPLIT tiles; the K-major weight gradients:
+//                 gemm_tn_split.hip) take it; the persistent recurrences and the per-time-step launches that must equal them are
+//                 fp32-input kernels.
 // So a line's bits are a function of (weights, line, entry point) only: they do not change with the batch it sits in, the tile
 // shape, the launch form (persistent or per step), what was decoded from the same encoding before, or the shard of a multi-GPU job.
 // A handle's "arithmetic" option (0 / 1 / 2) or the process-wide override put all of them on one arithmetic.
