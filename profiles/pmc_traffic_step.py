@@ -29,7 +29,8 @@ def main():
     steps, outname, wide = int(sys.argv[3]), sys.argv[4], sys.argv[5:]
     kernels, total = {}, 0.0
     for name in sorted(set(fetch) | set(write)):
-        scale = 2.0 if any(w in name for w in wide) else 1.0
+        # (gemm_tn_split256_kernel stages its K-major operands with 4-byte loads: as read, like every other narrow reader)
+        scale = 2.0 if any(w in name for w in wide) and 'gemm_tn_split' not in name else 1.0
         f, w = fetch.get(name, [0.0, 0]), write.get(name, [0.0, 0])
         by = (scale * f[0] + w[0]) * 1024.0 / steps
         total += by
