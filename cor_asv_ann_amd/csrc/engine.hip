@@ -1465,6 +1465,19 @@ extern "C" int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int3
     HIPCHK(hipMemcpyAsync(Bt.p, Bt_, (size_t)N * K * 4, hipMemcpyHostToDevice, m->stream));
     if (bias_) HIPCHK(hipMemcpyAsync(bias.p, bias_, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemsetAsync(C.p, 0xff, (size_t)M * N * 4, m->stream));           // (NaN: an element the launch does not write shows)
+    if (flags & 8) {
+        // K-major operands (the train step's weight gradients): A_ is [K][M], Bt_ is [K][N], C = A^T . B (+ colsum(A) into bias_'s place:
+        // not taken here) through gemm_tn_split.hip under the split arithmetic where the shape has that form, else gemm_tn.hip
+        if (M % 4 || N % 4) return fail(CASV_ERR_ARG, "K-major operands: M and N multiples of 4");
+        TnArgs t{};
+        t.A = A.as<float>(); t.lda = M; t.B = Bt.as<float>(); t.ldb = N; t.C = C.as<float>(); t.ldc = N;
+        t.M = M; t.Mstore = M; t.N = N; t.K = K; t.accumulate = 0; t.out_zeroed = 0; t.colsum = nullptr;
+        if (!(gemm_split_bf16() && launch_gemm_tn_split(t, m->stream))) launch_gemm_tn(t, m->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(C_, C.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        return CASV_OK;
+    }
     GemmArgs g{};
     g.nseg = 1; g.a[0] = mkseg(A.as<float>(), K, K, 0);
     g.Bt = Bt.as<float>(); g.bias = bias_ ? bias.as<float>() : nullptr; g.M = M; g.N = N; g.Ktot = K;

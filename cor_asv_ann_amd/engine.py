@@ -358,9 +358,16 @@ class HipEngine(object):
     def set_option(self, key, value):
         nv.check(self.lib.casv_set_option(self.handle, key.encode(), int(value)))
 
-    def debug_contract(self, A, Bt, bias=None, split_k=False, wave_groups=False, weight=False):
-        """Test support (casv_debug_contract): C = A . Bt^T (+ bias) through the launcher all GEMMs of the path go through."""
+    def debug_contract(self, A, Bt, bias=None, split_k=False, wave_groups=False, weight=False, k_major=False):
+        """Test support (casv_debug_contract): C = A . Bt^T (+ bias) through the launcher all GEMMs of the path go through;
+        k_major: A (K,M), Bt (K,N), C = A^T . Bt through the weight-gradient kernels."""
         A, Bt = nv.carray(A, np.float32), nv.carray(Bt, np.float32)
+        if k_major:
+            (K, M), N = A.shape, Bt.shape[1]
+            assert Bt.shape[0] == K and bias is None
+            C = np.empty((M, N), np.float32)
+            nv.check(self.lib.casv_debug_contract(self.handle, 8, M, N, K, nv.ptr(A), nv.ptr(Bt), None, nv.ptr(C)))
+            return C
         bias = None if bias is None else nv.carray(bias, np.float32)
         (M, K), N = A.shape, Bt.shape[0]
         assert Bt.shape[1] == K and (bias is None or bias.shape == (N,))

@@ -231,7 +231,9 @@ int casv_debug_gemm(casv_model* m, int32_t lstm, int32_t M, int32_t N, int32_t K
  * launcher every GEMM of the path goes through -- with whatever tile shape ("tile") and arithmetic ("arithmetic" / "split_bf16";
  * by entry point: 0) the options select; K a multiple of 32.  flags: 1 = the launcher may split K over workgroups and 2 = over the two wave groups of a
  * workgroup (the forms the train step's contractions take: sums in another order), 4 = Bt counts as a weight (the split-bf16
- * arithmetic keeps a pre-split image of it for the call).  tests/test_gpu_gemm.py compares the result with a float64 product. */
+ * arithmetic keeps a pre-split image of it for the call), 8 = the operands lie K-MAJOR -- A is (K,M), Bt is (K,N), C = A^T . Bt, no
+ * bias: the train step's weight gradients (csrc/gemm_tn.hip; csrc/gemm_tn_split.hip under the split arithmetic where M and N are
+ * multiples of 256).  tests/test_gpu_gemm.py compares the result with a float64 product. */
 int casv_debug_contract(casv_model* m, int32_t flags, int32_t M, int32_t N, int32_t K, const float* A, const float* Bt,
                         const float* bias, float* C);
 /* Options: "graph" = replay the decode step through a captured hipGraph (1) or launch kernels eagerly (0);

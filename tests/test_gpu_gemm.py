@@ -129,3 +129,28 @@ def test_split_bf16_is_as_accurate_as_the_fp32_chain(engine, K, scale):
             rms, mx = _errors(C, A, Bt, bias)
             assert rms <= 1.1 * chain[0] and mx <= 1.1 * chain[1], (mode, weight, K, (rms, mx), chain)
     engine.set_option('split_bf16', -1)
+
+
+@pytest.mark.parametrize('M,N,K', [(2048, 512, 8192), (2048, 1024, 4096), (512, 512, 2048), (256, 768, 16384)])
+def test_weight_gradient_contraction_on_split_operands_is_as_accurate_as_the_fp32_one(engine, M, N, K):
+    """The train step's weight gradients, C = A^T . B on K-major operands: the split kernel (csrc/gemm_tn_split.hip: 256x256 tiles, the
+    transposition in the staging's load pattern, K shared out over workgroups with float atomics) against float64, beside the
+    fp32-input kernel (csrc/gemm_tn.hip) against float64 -- error at most 1.1 x the fp32 kernel's plus the noise floor of a sum in
+    blocks -- and never a missing or doubled K tile (that would show as 1e4 in these units)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M)).astype(np.float32)
+    B = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    mag = np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)
+
+    def errors(C):
+        assert np.isfinite(C).all(), 'an element was not written'
+        err = (C.astype(np.float64) - ref) / (mag * 2.0 ** -24)
+        return float(np.sqrt(np.mean(err ** 2))), float(np.abs(err).max())
+    engine.set_option('split_bf16', 0)
+    fp32 = errors(engine.debug_contract(A, B, k_major=True))
+    engine.set_option('split_bf16', 2)
+    split = errors(engine.debug_contract(A, B, k_major=True))
+    engine.set_option('split_bf16', -1)
+    assert fp32[0] < RMS_BOUND and fp32[1] < MAX_BOUND, fp32
+    assert split[0] <= 1.1 * fp32[0] + 0.05 and split[1] <= 1.1 * fp32[1] + 0.5, (split, fp32)
