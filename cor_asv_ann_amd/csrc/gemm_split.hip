@@ -261,10 +261,20 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][c][r] = 0.0f;
     bf16x8 fb[4][3], fa[2][3];
+    // (timing-only build -DCASV_S2_SHAPE16, wrong results: every product as two v_mfma_f32_16x16x32_bf16 -- the same matrix-pipe cycles
+    // and operand registers -- to see what clock the real loop holds on that instruction shape: profiles/r05_mfma_shape_probe.txt)
+#ifdef CASV_S2_SHAPE16
+#define CASV_S2_PROD(A, B, ACC) { \
+        f32x4 p0_ = __builtin_shufflevector(ACC, ACC, 0, 1, 2, 3), p1_ = __builtin_shufflevector(ACC, ACC, 4, 5, 6, 7);                       \
+        p0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, p0_, 0, 0, 0); p1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, p1_, 0, 0, 0);   \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { ACC[e_] = p0_[e_]; ACC[4 + e_] = p1_[e_]; } }
+#else
+#define CASV_S2_PROD(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0);
+#endif
 #define CASV_S2_MMA(PA, PB)                                                                               \
     _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)                                                   \
         _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                  \
-            acc[rb_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb_][PA], fb[c_][PB], acc[rb_][c_], 0, 0, 0);
+            CASV_S2_PROD(fa[rb_][PA], fb[c_][PB], acc[rb_][c_])
     // scheduling fence that only vector arithmetic may cross (the split's arithmetic finds its own place between the products;
     // matrix, LDS and memory instructions stay where the pipeline above puts them)
 #define CASV_S2_PIN __builtin_amdgcn_sched_barrier(0x2);
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     // instructions), the three 8-byte LDS stores of a row once its four values are split -- so that the matrix pipe is fed every
     // ~32 cycles by this wave alone.  Left to itself the compiler issues the ~45 vector instructions of an operand's split in
     // one run (180 cycles without a product), and its group-barrier solver gives up on all but the first block of such a tile.
-#define CASV_S2_M1(RB, C, PA, PB) acc[RB][C] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[RB][PA], fb[C][PB], acc[RB][C], 0, 0, 0);
+#define CASV_S2_M1(RB, C, PA, PB) CASV_S2_PROD(fa[RB][PA], fb[C][PB], acc[RB][C])
 #define CASV_S2_FENCE __builtin_amdgcn_sched_barrier(0);
 #define CASV_S2_TILE(T, PAR) \
     { \
@@ -555,6 +565,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
 #undef CASV_S2_M1
 #undef CASV_S2_FENCE
 #undef CASV_S2_MMA
+#undef CASV_S2_PROD
 #undef CASV_S2_PIN
     CASV_S2_LANDED(gt);                                  // (pins the staging registers until nothing can be in flight into them)
 #ifdef CASV_S2_CLOCK
