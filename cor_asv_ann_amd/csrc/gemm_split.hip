@@ -114,12 +114,16 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     const Seg sg0 = g.a[0], sg1 = g.a[1], sg2 = g.a[2], sgc = g.c_in;
     const Seg* const sgs[3] = {&sg0, &sg1, &sg2};
     const int nseg = g.nseg;
+    const int* const no_rows = reinterpret_cast<const int*>(g.Bt);          // any readable word
+    int ridx[3][2];
     bool act[3], gat[3];
 #pragma unroll
     for (int S = 0; S < 3; ++S) {
         const Seg& sg = *sgs[S];
         act[S] = nseg > S && !(sg.skip_first && step == 0 && !sg.first_base);
         gat[S] = act[S] && sg.rows && !(sg.first_base && step == 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ridx[S][i] = *(gat[S] ? sg.rows + (m0 + r0 + 128 * i) : no_rows);
     }
     const float* abase[3]; long long ald[3]; int tiles[3], koff[3];
 #pragma unroll
@@ -128,16 +132,12 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
         const bool first = sg.first_base && step == 0;
         abase[S] = !act[S] ? nullptr : first ? sg.first_base : sg.base + (long long)(step * sg.step_mul + sg.step_add) * sg.slot_stride;
         ald[S] = sg.ld; tiles[S] = act[S] ? sg.width / S2_BK : 0; koff[S] = sg.koff;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) if (!gat[S]) ridx[S][i] = m0 + r0 + 128 * i;
     }
     const int c0 = __builtin_amdgcn_readfirstlane(tiles[0]), c1 = __builtin_amdgcn_readfirstlane(tiles[0] + tiles[1]);
     const int nt = __builtin_amdgcn_readfirstlane(tiles[0] + tiles[1] + tiles[2]);
-    // (a gathered segment's row indices are fetched where the request stream enters it -- twice per K loop at most -- instead of
-    // waiting in six registers)
-    auto arow = [&](int S, int i) {
-        const int m = m0 + r0 + 128 * i;
-        const int r = gat[S] ? sgs[S]->rows[m] : m;
-        return reinterpret_cast<const char*>(abase[S] + (long long)r * ald[S] + 4 * kc);
-    };
+    auto arow = [&](int S, int i) { return reinterpret_cast<const char*>(abase[S] + (long long)ridx[S][i] * ald[S] + 4 * kc); };
 
     // running request pointers: one K tile further per request, re-based where the request stream enters the next segment
     int rseg = c0 > 0 ? 0 : c1 > c0 ? 1 : 2;
@@ -146,73 +146,58 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
     if (rseg == 0) { ra0 = arow(0, 0); ra1 = arow(0, 1); } else if (rseg == 1) { ra0 = arow(1, 0); ra1 = arow(1, 1); } else { ra0 = arow(2, 0); ra1 = arow(2, 1); }
     const float* rb0 = g.Bt + (long long)(n0 + r0) * g.Ktot + 4 * kc + koff[rseg];
     const float* rb1 = rb0 + (long long)128 * g.Ktot;
-    // BIMG: the tile image of (column tile bn, K tile kt) -- a workgroup-uniform address (scalar registers); the lane's 16 bytes of this
-    // wave's 1-KB piece of a plane sit at img_lane behind it
-    const char* rbi = nullptr;
-    if (BIMG) {
-        const unsigned long long a64 = (unsigned long long)(reinterpret_cast<const char*>(g.Bimg) + ((long long)bn * (g.Ktot / S2_BK) + koff[rseg] / S2_BK) * S2_BIMG_TILE);
-        rbi = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a64 >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a64));
-    }
-    const unsigned img_lane = wave * 1024 + lane * 16;
-    auto cross_a = [&]() {          // the request stream has used up its segment: on to the next one (or past the end)
-        asm volatile("" ::: "memory");
-        if (rseg == 0 && c1 > c0) {
-            rseg = 1; rleft = c1 - c0; ra0 = arow(1, 0); ra1 = arow(1, 1);
-            rb0 += koff[1] - koff[0] - c0 * S2_BK; rb1 += koff[1] - koff[0] - c0 * S2_BK;
-        } else if (rseg <= 1 && nt > c1) {
-            const int kprev = rseg == 0 ? koff[0] + c0 * S2_BK : koff[1] + (c1 - c0) * S2_BK;
-            rseg = 2; rleft = nt - c1; ra0 = arow(2, 0); ra1 = arow(2, 1);
-            rb0 += koff[2] - kprev; rb1 += koff[2] - kprev;
-        } else rleft = 1 << 30;
-    };
+    // BIMG: this wave's 3 KB of the tile image of (column tile bn, K tile kt): the lane's 16 bytes of its first 1-KB piece
+    const char* rbi = BIMG ? reinterpret_cast<const char*>(g.Bimg) + ((long long)bn * (g.Ktot / S2_BK) + koff[rseg] / S2_BK) * S2_BIMG_TILE + wave * 3072 + lane * 16 : nullptr;
     auto advance = [&]() {
         ra0 += S2_BK * 4; ra1 += S2_BK * 4; rb0 += S2_BK; rb1 += S2_BK;
-        if (--rleft == 0) cross_a();
+        if (--rleft == 0) {
+            asm volatile("" ::: "memory");
+            if (rseg == 0 && c1 > c0) {
+                rseg = 1; rleft = c1 - c0; ra0 = arow(1, 0); ra1 = arow(1, 1);
+                rb0 += koff[1] - koff[0] - c0 * S2_BK; rb1 += koff[1] - koff[0] - c0 * S2_BK;
+            } else if (rseg <= 1 && nt > c1) {
+                const int kprev = rseg == 0 ? koff[0] + c0 * S2_BK : koff[1] + (c1 - c0) * S2_BK;
+                rseg = 2; rleft = nt - c1; ra0 = arow(2, 0); ra1 = arow(2, 1);
+                rb0 += koff[2] - kprev; rb1 += koff[2] - kprev;
+            } else rleft = 1 << 30;
+        }
     };
     // (the image pointer runs on its own: the planes of tile t + 2 are transferred a tile later than A's tile t + 3 is requested)
     int bseg = rseg, bleft = rleft;
-    auto cross_b = [&]() {
-        if (bseg == 0 && c1 > c0) {
-            bseg = 1; bleft = c1 - c0; rbi += (long long)((koff[1] - koff[0]) / S2_BK - c0) * S2_BIMG_TILE;
-        } else if (bseg <= 1 && nt > c1) {
-            const int kprev = bseg == 0 ? koff[0] + c0 * S2_BK : koff[1] + (c1 - c0) * S2_BK;
-            bseg = 2; bleft = nt - c1; rbi += (long long)((koff[2] - kprev) / S2_BK) * S2_BIMG_TILE;
-        } else bleft = 1 << 30;
-    };
     auto advance_b = [&]() {
         rbi += S2_BIMG_TILE;
-        if (--bleft == 0) cross_b();
+        if (--bleft == 0) {
+            if (bseg == 0 && c1 > c0) {
+                bseg = 1; bleft = c1 - c0; rbi += (long long)((koff[1] - koff[0]) / S2_BK - c0) * S2_BIMG_TILE;
+            } else if (bseg <= 1 && nt > c1) {
+                const int kprev = bseg == 0 ? koff[0] + c0 * S2_BK : koff[1] + (c1 - c0) * S2_BK;
+                bseg = 2; bleft = nt - c1; rbi += (long long)((koff[2] - kprev) / S2_BK) * S2_BIMG_TILE;
+            } else bleft = 1 << 30;
+        }
     };
-    // Operand rows on their way in: LDS-DMA into the area the previous cell state will take at the end of the K loop (idle until
-    // then) -- every lane its 16 bytes, piece `slot` of this wave's 1 KB: rows r0 / r0 + 128 of the stage's two K tiles of A
-    // (slots 0..3) and, without a weight image, of B (slots 4..7).  The lane reads back what its own wave transferred (no barrier,
-    // the wave's own vmcnt wait), splits it and stores the planes.  No operand value waits in a register while its stage's
-    // products run, and there is no load whose destination registers the compiler does not know about.
-    auto raw_in = [&](const char* src, int slot) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)s2_smem)
-                             + (unsigned)(S2_CB + slot * 8192) + (unsigned)__builtin_amdgcn_readfirstlane(wave * 1024);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    struct GTile { f32x4 a[2], b[2]; };
+    // (one statement per load: the steady state spreads a tile's memory instructions over its products -- eight waves that
+    // pass the barrier together and each issue five of them in a row queue up at the CU's one memory pipeline while the matrix
+    // pipe has nothing to do: 3 960 instead of 3 210 cycles per tile, profiles/r04_split_bf16.txt)
+    auto request_a0 = [&](GTile& gt) { if (!(CASV_ABLM & 4)) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[0]) : "v"(ra0)); };
+    auto request_a1 = [&](GTile& gt) { if (!(CASV_ABLM & 4)) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.a[1]) : "v"(ra1)); };
+    auto request_b0 = [&](GTile& gt) { if (!(CASV_ABLM & 4) && !BIMG) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[0]) : "v"(rb0)); };
+    auto request_b1 = [&](GTile& gt) { if (!(CASV_ABLM & 4) && !BIMG) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gt.b[1]) : "v"(rb1)); };
+    auto request = [&](GTile& gt) { request_a0(gt); request_a1(gt); request_b0(gt); request_b1(gt); };
+#define CASV_S2_LANDED(G) { if (!(CASV_ABLM & (4 | 32))) { if (BIMG) asm volatile("s_waitcnt vmcnt(0)" : "+v"(G.a[0]), "+v"(G.a[1])); \
+                            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(G.a[0]), "+v"(G.a[1]), "+v"(G.b[0]), "+v"(G.b[1])); } }
+    // BIMG: the B planes of the tile the running image pointer stands at -> LDS buffer `buf`, this wave's three 1-KB pieces
+    auto dma_b1 = [&](int buf, int j) {
+        if (CASV_ABLM & 4) return;
+        {
+            const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)s2_smem)
+                                 + (unsigned)(S2_TB + buf * S2_BUF + 3 * S2_PLANE) + (unsigned)__builtin_amdgcn_readfirstlane(wave * 3072) + (unsigned)(j * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(rbi + j * 1024), "s"(dst) : "memory");
+        }
     };
-    const char* const raw_lane = s2_smem + S2_CB + wave * 1024 + lane * 16;
-    auto raw = [&](int slot) { return *reinterpret_cast<const f32x4*>(raw_lane + slot * 8192); };
-    auto request = [&](int i) {           // K tile i (0 / 1) of the stage being requested: where the running pointers stand
-        raw_in(ra0, 2 * i); raw_in(ra1, 2 * i + 1);
-        if (!BIMG) { raw_in(reinterpret_cast<const char*>(rb0), 4 + 2 * i); raw_in(reinterpret_cast<const char*>(rb1), 4 + 2 * i + 1); }
-    };
-#define CASV_S2_LANDED asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // BIMG: plane p of the image tile whose (lane's) address is `tile` -> B plane p of LDS buffer `buf`, this wave's 1-KB piece
-    auto dma_at = [&](const char* tile, int buf, int p) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)s2_smem)
-                             + (unsigned)(S2_TB + buf * S2_BUF + (3 + p) * S2_PLANE) + (unsigned)__builtin_amdgcn_readfirstlane(wave * 1024);
-        unsigned keep;
-        const unsigned long long t64 = (unsigned long long)(tile + p * S2_PLANE);       // (said to be uniform: a scalar register pair)
-        const unsigned long long tu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(t64 >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)t64);     // (the builtin returns int: no sign extension of the low half)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(img_lane), "s"(tu), "s"(dst) : "memory");
-    };
-    auto dma_tile = [&](int buf, int p) { dma_at(rbi, buf, p); };
+    auto dma_b = [&](int buf) { dma_b1(buf, 0); dma_b1(buf, 1); dma_b1(buf, 2); };
 
     // ---- staging: split and store ----
     auto split4 = [&](const f32x4 x, u32x2& p0, u32x2& p1, u32x2& p2) {
@@ -257,139 +242,304 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
         char* base = s2_smem + S2_TB + buf * S2_BUF + plane0 * S2_PLANE + st_off + i * 128 * 32;
         *reinterpret_cast<u32x2*>(base) = p0; *reinterpret_cast<u32x2*>(base + S2_PLANE) = p1; *reinterpret_cast<u32x2*>(base + 2 * S2_PLANE) = p2;
     };
-    // Fragments of the 32-deep instruction: lane l holds row (l & 15) of its 16-row block and the stage's k 8 (l >> 4) .. + 7 --
-    // 16-byte piece (l >> 4) & 1 of K tile l >> 5, i.e. of LDS buffer l >> 5 (a row's two pieces are swapped where bit 4 of the
-    // row is set: odd blocks)
-    const int fr_lane = (lane >> 5) * S2_BUF + (lane & 15) * 32;
-    const int fr_e = fr_lane + ((lane >> 4) & 1) * 16, fr_o = fr_lane + (((lane >> 4) & 1) ^ 1) * 16;
-    // (four lane addresses; plane and block are 16-bit instruction offsets behind them)
-    const char* const fa_e = s2_smem + S2_TB + wm * 64 * 32 + fr_e; const char* const fa_o = s2_smem + S2_TB + wm * 64 * 32 + fr_o;
-    auto frag_a = [&](int plane, int rb) { return *reinterpret_cast<const bf16x8*>(((rb & 1) ? fa_o : fa_e) + plane * S2_PLANE + rb * 16 * 32); };
-    // (B's lane addresses are A's plus a wave-uniform distance, added where a fragment is read: two registers instead of four)
-    const int fb_delta = __builtin_amdgcn_readfirstlane(3 * S2_PLANE + (wn * 128 - wm * 64) * 32);
-    auto frag_b = [&](int plane, int c) {
-        return *reinterpret_cast<const bf16x8*>(((c & 1) ? fa_o : fa_e) + fb_delta + plane * S2_PLANE + c * 16 * 32);
+    // a lane's 8 k of its row: the 16-byte half lh (k = 8 lh .. 8 lh + 7, the same for both operands)
+    const int fr_off = l31 * 32 + (((lh ^ (l31 >> 4)) & 1) * 16);
+    auto frag_a = [&](int buf, int plane, int rb) {
+        if (CASV_ABLM & 16) { bf16x8 z; asm volatile("" : "=v"(z)); return z; }
+        return *reinterpret_cast<const bf16x8*>(s2_smem + S2_TB + buf * S2_BUF + plane * S2_PLANE + (wm * 64 + rb * 32) * 32 + fr_off);
     };
-    char* const st_b0 = s2_smem + S2_TB + st_off; char* const st_b1 = s2_smem + S2_TB + S2_BUF + st_off;
-    // staging in two windows: split four k of row r0 + 128 i, store two of the planes now, hand the third back
-    auto split_store = [&](const f32x4 x, int buf, int plane0, int i, const bool hold_last, u32x2& held) {
-        u32x2 p0, p1, p2;
-        split4(x, p0, p1, p2);
-        char* base = (buf ? st_b1 : st_b0) + plane0 * S2_PLANE + i * 128 * 32;
-        if (hold_last) { *reinterpret_cast<u32x2*>(base) = p0; *reinterpret_cast<u32x2*>(base + S2_PLANE) = p1; held = p2; }          // A: a0, a1 now, a2 later
-        else { *reinterpret_cast<u32x2*>(base + S2_PLANE) = p1; *reinterpret_cast<u32x2*>(base + 2 * S2_PLANE) = p2; held = p0; }     // B: b1, b2 now, b0 later
-    };
-    auto store_plane = [&](const u32x2 v, int buf, int plane, int i) {
-        *reinterpret_cast<u32x2*>((buf ? st_b1 : st_b0) + plane * S2_PLANE + i * 128 * 32) = v;
-    };
-    auto zero_rows = [&](int buf, int plane0, int nplanes) {          // a stage's missing second K tile: zeros in both operands
-        for (int p = plane0; p < plane0 + nplanes; ++p) { store_plane(u32x2{0u, 0u}, buf, p, 0); store_plane(u32x2{0u, 0u}, buf, p, 1); }
+    auto frag_b = [&](int buf, int plane, int c) {
+        if (CASV_ABLM & 16) { bf16x8 z; asm volatile("" : "=v"(z)); return z; }
+        return *reinterpret_cast<const bf16x8*>(s2_smem + S2_TB + buf * S2_BUF + (3 + plane) * S2_PLANE + (wn * 128 + c * 32) * 32 + fr_off);
     };
 
-
-    // ---- accumulators: 16x16 blocks [row block of 16][column block of 16] of the wave's 64 x 128 ----
-    f32x4 acc16[4][8];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc16[rb][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    // fragment registers: ONE B plane (8 column blocks), two A planes (4 row blocks each): fX / fY take turns as "a0 of the stage,
-    // kept from its first product to its last" and "a1, then a2, then a0 of the next stage"
-    bf16x8 fb[8], fX[4], fY[4];
-#define CASV_S2_PROD(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, ACC, 0, 0, 0);
-#define CASV_S2_FENCE __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][c][r] = 0.0f;
+    bf16x8 fb[4][3], fa[2][3];
+    // (timing-only build -DCASV_S2_SHAPE16, wrong results: every product as two v_mfma_f32_16x16x32_bf16 -- the same matrix-pipe cycles
+    // and operand registers -- to see what clock the real loop holds on that instruction shape: profiles/r05_mfma_shape_probe.txt)
+#ifdef CASV_S2_SHAPE16
+#define CASV_S2_PROD(A, B, ACC) { \
+        f32x4 p0_ = __builtin_shufflevector(ACC, ACC, 0, 1, 2, 3), p1_ = __builtin_shufflevector(ACC, ACC, 4, 5, 6, 7);                       \
+        p0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, p0_, 0, 0, 0); p1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, p1_, 0, 0, 0);   \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { ACC[e_] = p0_[e_]; ACC[4 + e_] = p1_[e_]; } }
+#else
+#define CASV_S2_PROD(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0);
+#endif
+#define CASV_S2_MMA(PA, PB)                                                                               \
+    _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)                                                   \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                  \
+            CASV_S2_PROD(fa[rb_][PA], fb[c_][PB], acc[rb_][c_])
+    // scheduling fence that only vector arithmetic may cross (the split's arithmetic finds its own place between the products;
+    // matrix, LDS and memory instructions stay where the pipeline above puts them)
+#define CASV_S2_PIN __builtin_amdgcn_sched_barrier(0x2);
 
-    // ---- prologue: stage 0 (tiles 0 and 1) into LDS, stage 1 requested; a0 and b2 of stage 0 in registers ----
-    if (nt > 0) {
-        request(0); if (BIMG) { dma_tile(0, 0); dma_tile(0, 1); dma_tile(0, 2); advance_b(); } advance();
-        if (nt > 1) { request(1); if (BIMG) { dma_tile(1, 0); dma_tile(1, 1); dma_tile(1, 2); advance_b(); } advance(); }
-        CASV_S2_LANDED
-        store_op(raw(0), raw(1), 0, 0); if (!BIMG) store_op(raw(4), raw(5), 0, 3);
-        if (nt > 1) { store_op(raw(2), raw(3), 1, 0); if (!BIMG) store_op(raw(6), raw(7), 1, 3); }
-        else zero_rows(1, 0, 6);
+    // ---- prologue: tiles 0 and 1 into LDS, tile 2 requested; the fragments a tile expects in registers ----
+    GTile gt;
+    if (nt > 1) {       // tiles 0 and 1 requested together: one memory round trip in front of the first product instead of two
+        GTile g1;
+        request(gt); if (BIMG) { dma_b(0); advance_b(); } advance();
+        request(g1); if (BIMG) { dma_b(1); advance_b(); } advance();
+        CASV_S2_LANDED(gt); CASV_S2_LANDED(g1);
+        store_op(gt.a[0], gt.a[1], 0, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], 0, 3);
+        store_op(g1.a[0], g1.a[1], 1, 0); if (!BIMG) store_op(g1.b[0], g1.b[1], 1, 3);
+    } else if (nt > 0) {
+        request(gt); if (BIMG) { dma_b(0); advance_b(); } advance(); CASV_S2_LANDED(gt);
+        store_op(gt.a[0], gt.a[1], 0, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], 0, 3);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the read-backs have returned before the next transfers overwrite them)
-    if (nt > 2) { request(0); advance(); }
-    if (nt > 3) { request(1); advance(); }
+    if (nt > 2) { request(gt); advance(); }
     __syncthreads();
     if (nt > 0) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) fb[c] = frag_b(2, c);
+        for (int c = 0; c < 4; ++c) { fb[c][1] = frag_b(0, 1, c); fb[c][2] = frag_b(0, 2, c); }
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) fX[rb] = frag_a(0, rb);
+        for (int rb = 0; rb < 2; ++rb) { fa[rb][1] = frag_a(0, 1, rb); fa[rb][2] = frag_a(0, 2, rb); }
     }
 
-    // One stage = two K tiles (k 0..15 from buffer 0, k 16..31 from buffer 1) = six products of 32 instructions per wave:
-    //   p1 a0.b2, p2 a0.b1 | barrier X | p3 a1.b1, p4 a1.b0, p5 a2.b0 | barrier Y | p6 a0.b0
-    // Q holds a0 of the stage; P takes a1 (read under p1), a2 (rolled in under p4), a0 of the next stage (read under p6);
-    // fb rolls b2 -> b1 (under p1) -> b0 (under p3) -> b2 of the next stage (under p6); p2 and p5, in front of the barriers, read
-    // nothing.  A plane's place in LDS is refilled IN PLACE with the same plane of the next stage once every wave has read it: behind
-    // X the planes b2, a0, b1, a1 (window 1: the transfers of b2', b1', the split of A with the stores of a0', a1', the requests
-    // for the stage after next), behind Y the planes b0, a2 (window 2: the stores of a2' -- held in registers since the split --
-    // and the transfers of b0').  Y publishes window 1 (read from p6 on), the next X window 2 (read from the next p3 on).
-#define CASV_S2_P_COUT(QA, ROLL_STMT)                                                                         \
-    _Pragma("unroll") for (int c_ = 0; c_ < 8; ++c_) {                                                        \
-        _Pragma("unroll") for (int rb_ = 0; rb_ < 4; ++rb_) CASV_S2_PROD(QA[rb_], fb[c_], acc16[rb_][c_])     \
-        ROLL_STMT                                                                                             \
-        CASV_S2_FENCE                                                                                         \
+    // steady state: tiles T+1..T+3 exist, no conditionals.  Behind the barrier the issue order is written out product by product
+    // with a full scheduling fence behind each: a product, at most one fragment read, half of a value pair's split (5-6 vector
+    // instructions), the three 8-byte LDS stores of a row once its four values are split -- so that the matrix pipe is fed every
+    // ~32 cycles by this wave alone.  Left to itself the compiler issues the ~45 vector instructions of an operand's split in
+    // one run (180 cycles without a product), and its group-barrier solver gives up on all but the first block of such a tile.
+#define CASV_S2_M1(RB, C, PA, PB) CASV_S2_PROD(fa[RB][PA], fb[C][PB], acc[RB][C])
+#define CASV_S2_FENCE __builtin_amdgcn_sched_barrier(0);
+#define CASV_S2_TILE(T, PAR) \
+    { \
+        u32x2 w0_, w1_, w2_; unsigned q0_; f32x2 r1_;                                                          \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) fb[c_][0] = frag_b(PAR, 0, c_);                       \
+        _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) fa[rb_][0] = frag_a(PAR, 0, rb_);                  \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_MMA(1, 1) CASV_S2_MMA(0, 2) CASV_S2_MMA(0, 1)                                                  \
+        CASV_S2_FENCE                                                                                          \
+        if (!(CASV_ABLM & 8)) __syncthreads();                                                                 \
+        CASV_S2_LANDED(gt);                                                                                    \
+        CASV_S2_M1(0, 0, 2, 0)                                                                                 \
+        fb[0][1] = frag_b(1 - PAR, 1, 0);                                                                      \
+        split_l1(gt.a[0], 0, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 1, 2, 0)                                                                                 \
+        fb[1][1] = frag_b(1 - PAR, 1, 1);                                                                      \
+        split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 2, 2, 0)                                                                                 \
+        fb[2][1] = frag_b(1 - PAR, 1, 2);                                                                      \
+        split_l1(gt.a[0], 1, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 3, 2, 0)                                                                                 \
+        fb[3][1] = frag_b(1 - PAR, 1, 3);                                                                      \
+        split_l23(q0_, r1_, 1, w0_, w1_, w2_);                                                                 \
+        store_row(w0_, w1_, w2_, PAR, 0, 0);                                                                   \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 0, 2, 0)                                                                                 \
+        fb[0][2] = frag_b(1 - PAR, 2, 0);                                                                      \
+        split_l1(gt.a[1], 0, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 1, 2, 0)                                                                                 \
+        fb[1][2] = frag_b(1 - PAR, 2, 1);                                                                      \
+        split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        request_a0(gt);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 2, 2, 0)                                                                                 \
+        fb[2][2] = frag_b(1 - PAR, 2, 2);                                                                      \
+        split_l1(gt.a[1], 1, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 3, 2, 0)                                                                                 \
+        fb[3][2] = frag_b(1 - PAR, 2, 3);                                                                      \
+        split_l23(q0_, r1_, 1, w0_, w1_, w2_);                                                                 \
+        store_row(w0_, w1_, w2_, PAR, 0, 1);                                                                   \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 0, 1, 0)                                                                                 \
+        fa[0][2] = frag_a(1 - PAR, 2, 0);                                                                      \
+        split_l1(gt.b[0], 0, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 1, 1, 0)                                                                                 \
+        fa[1][2] = frag_a(1 - PAR, 2, 1);                                                                      \
+        split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        request_a1(gt);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 2, 1, 0)                                                                                 \
+        split_l1(gt.b[0], 1, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 3, 1, 0)                                                                                 \
+        split_l23(q0_, r1_, 1, w0_, w1_, w2_);                                                                 \
+        store_row(w0_, w1_, w2_, PAR, 3, 0);                                                                   \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 0, 1, 0)                                                                                 \
+        split_l1(gt.b[1], 0, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 1, 1, 0)                                                                                 \
+        split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 2, 1, 0)                                                                                 \
+        split_l1(gt.b[1], 1, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 3, 1, 0)                                                                                 \
+        split_l23(q0_, r1_, 1, w0_, w1_, w2_);                                                                 \
+        store_row(w0_, w1_, w2_, PAR, 3, 1);                                                                   \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 0, 0, 0)                                                                                 \
+        fa[0][1] = frag_a(1 - PAR, 1, 0);                                                                      \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 1, 0, 0)                                                                                 \
+        fa[1][1] = frag_a(1 - PAR, 1, 1);                                                                      \
+        request_b0(gt);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 2, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 3, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 0, 0, 0)                                                                                 \
+        request_b1(gt);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 1, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 2, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 3, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        advance();                                                                                             \
     }
-#define CASV_S2_P_ROUT(PA, ROLL_STMT)                                                                         \
-    _Pragma("unroll") for (int rb_ = 0; rb_ < 4; ++rb_) {                                                     \
-        _Pragma("unroll") for (int c_ = 0; c_ < 8; ++c_) CASV_S2_PROD(PA[rb_], fb[c_], acc16[rb_][c_])        \
-        ROLL_STMT                                                                                             \
-        CASV_S2_FENCE                                                                                         \
+    // the same with the B planes from the weight image (BIMG): only A is staged through registers
+#define CASV_S2_TILE_BI(T, PAR) \
+    { \
+        u32x2 w0_, w1_, w2_; unsigned q0_; f32x2 r1_;                                                          \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) fb[c_][0] = frag_b(PAR, 0, c_);                       \
+        _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) fa[rb_][0] = frag_a(PAR, 0, rb_);                  \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_MMA(1, 1) CASV_S2_MMA(0, 2) CASV_S2_MMA(0, 1)                                                  \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_LANDED(gt);   /* (this wave's plane transfers of the previous tile too: they are read behind the barrier) */ \
+        if (!(CASV_ABLM & 8)) __syncthreads();                                                                 \
+        CASV_S2_M1(0, 0, 2, 0)                                                                                 \
+        fb[0][1] = frag_b(1 - PAR, 1, 0);                                                                      \
+        split_l1(gt.a[0], 0, q0_, r1_);                                                                        \
+        dma_b1(PAR, 0);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 1, 2, 0)                                                                                 \
+        fb[1][1] = frag_b(1 - PAR, 1, 1);                                                                      \
+        split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 2, 2, 0)                                                                                 \
+        fb[2][1] = frag_b(1 - PAR, 1, 2);                                                                      \
+        split_l1(gt.a[0], 1, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 3, 2, 0)                                                                                 \
+        fb[3][1] = frag_b(1 - PAR, 1, 3);                                                                      \
+        split_l23(q0_, r1_, 1, w0_, w1_, w2_);                                                                 \
+        store_row(w0_, w1_, w2_, PAR, 0, 0);                                                                   \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 0, 2, 0)                                                                                 \
+        fb[0][2] = frag_b(1 - PAR, 2, 0);                                                                      \
+        split_l1(gt.a[1], 0, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 1, 2, 0)                                                                                 \
+        fb[1][2] = frag_b(1 - PAR, 2, 1);                                                                      \
+        split_l23(q0_, r1_, 0, w0_, w1_, w2_);                                                                 \
+        request_a0(gt);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 2, 2, 0)                                                                                 \
+        fb[2][2] = frag_b(1 - PAR, 2, 2);                                                                      \
+        split_l1(gt.a[1], 1, q0_, r1_);                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 3, 2, 0)                                                                                 \
+        fb[3][2] = frag_b(1 - PAR, 2, 3);                                                                      \
+        split_l23(q0_, r1_, 1, w0_, w1_, w2_);                                                                 \
+        store_row(w0_, w1_, w2_, PAR, 0, 1);                                                                   \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 0, 1, 0)                                                                                 \
+        fa[0][2] = frag_a(1 - PAR, 2, 0);                                                                      \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 1, 1, 0)                                                                                 \
+        fa[1][2] = frag_a(1 - PAR, 2, 1);                                                                      \
+        request_a1(gt);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 2, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 3, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 0, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 1, 1, 0)                                                                                 \
+        dma_b1(PAR, 1);                                                                                        \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 2, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 3, 1, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 0, 0, 0)                                                                                 \
+        fa[0][1] = frag_a(1 - PAR, 1, 0);                                                                      \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 1, 0, 0)                                                                                 \
+        fa[1][1] = frag_a(1 - PAR, 1, 1);                                                                      \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 2, 0, 0)                                                                                 \
+        dma_b1(PAR, 2); advance_b();                                                                           \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(0, 3, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 0, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 1, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 2, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        CASV_S2_M1(1, 3, 0, 0)                                                                                 \
+        CASV_S2_FENCE                                                                                          \
+        advance();                                                                                             \
     }
-    // FULL: steady state (the two stages behind this one exist whole): no conditions, counted waits.
-#define CASV_S2_STAGE(S, P, Q, FULL)                                                                          \
-    {                                                                                                         \
-        const bool next_ = FULL || 2 * (S) + 2 < nt, next1_ = FULL || 2 * (S) + 3 < nt;                       \
-        const bool req0_ = FULL || 2 * (S) + 4 < nt, req1_ = FULL || 2 * (S) + 5 < nt;                        \
-        CASV_S2_P_COUT(Q, { fb[c_] = frag_b(1, c_); if (c_ < 4) P[c_] = frag_a(1, c_); })           /* p1 */ \
-        CASV_S2_P_COUT(Q, {})                                                                       /* p2 */ \
-        CASV_S2_FENCE                                                                                         \
-        CASV_S2_LANDED                       /* the requests of the stage before; window 2's transfers of this wave with them */ \
-        __syncthreads();                                                                            /* X */  \
-        if (next_) {                                                                         /* window 1 */  \
-            if (BIMG) { tb0_ = rbi; dma_at(tb0_, 0, 2); dma_at(tb0_, 0, 1); advance_b();                      \
-                        if (next1_) { tb1_ = rbi; dma_at(tb1_, 1, 2); dma_at(tb1_, 1, 1); advance_b(); } }    \
-            split_store(raw(0), 0, 0, 0, true, h2_[0]); split_store(raw(1), 0, 0, 1, true, h2_[1]);               \
-            if (!BIMG) { split_store(raw(4), 0, 3, 0, false, hb_[0]); split_store(raw(5), 0, 3, 1, false, hb_[1]); }  \
-            if (next1_) {                                                                                     \
-                split_store(raw(2), 1, 0, 0, true, h2_[2]); split_store(raw(3), 1, 0, 1, true, h2_[3]);       \
-                if (!BIMG) { split_store(raw(6), 1, 3, 0, false, hb_[2]); split_store(raw(7), 1, 3, 1, false, hb_[3]); }  \
-            } else { zero_rows(1, 0, 2); zero_rows(1, 4, 2); }                                                \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-            if (req0_) { request(0); advance(); }                                                             \
-            if (req1_) { request(1); advance(); }                                                             \
-        }                                                                                                     \
-        CASV_S2_P_COUT(P, { fb[c_] = frag_b(0, c_); })                                              /* p3 */ \
-        CASV_S2_P_ROUT(P, { P[rb_] = frag_a(2, rb_); })                                             /* p4 */ \
-        CASV_S2_P_ROUT(P, {})                                                                       /* p5 */ \
-        CASV_S2_FENCE                                                                                         \
-        if (FULL) { if (BIMG) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }     /* this wave's four transfers of window 1; the four requests behind them stay in flight */ \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
-        __syncthreads();                                                                            /* Y */  \
-        if (!FULL && !req0_ && cell_pending) { cell_request(); cell_pending = false; }   /* (every wave has read its last operand rows back: the area is the cell state's from here) */ \
-        if (next_) {                                                                         /* window 2 */  \
-            store_plane(h2_[0], 0, 2, 0); store_plane(h2_[1], 0, 2, 1);                                       \
-            if (!BIMG) { store_plane(hb_[0], 0, 3, 0); store_plane(hb_[1], 0, 3, 1); }                        \
-            if (BIMG) dma_at(tb0_, 0, 0);                                                                     \
-            if (next1_) {                                                                                     \
-                store_plane(h2_[2], 1, 2, 0); store_plane(h2_[3], 1, 2, 1);                                   \
-                if (!BIMG) { store_plane(hb_[2], 1, 3, 0); store_plane(hb_[3], 1, 3, 1); }                    \
-                if (BIMG) dma_at(tb1_, 1, 0);                                                                 \
-            } else zero_rows(1, 2, 2);                                                                        \
-        }                                                                                                     \
-        CASV_S2_P_COUT(Q, { if (next_) { fb[c_] = frag_b(2, c_); if (c_ < 4) P[c_] = frag_a(0, c_); } })   /* p6 */ \
+    // the last tiles: the same order with (workgroup-uniform) conditions; staging in one piece behind the barrier
+#define CASV_S2_TAIL(T, PAR)                                                                              \
+    {                                                                                                     \
+        const bool next_ = (T) + 1 < nt;                                                                  \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) fb[c_][0] = frag_b(PAR, 0, c_);                  \
+        _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) fa[rb_][0] = frag_a(PAR, 0, rb_);             \
+        CASV_S2_MMA(1, 1) CASV_S2_MMA(0, 2) CASV_S2_MMA(0, 1)                                             \
+        CASV_S2_LANDED(gt);     /* (unconditional: no path carries a request past a tile, whatever the checker assumes about the conditions; BIMG: the previous tile's plane transfers) */ \
+        __syncthreads();                                                                                  \
+        if (BIMG && (T) + 2 < nt) { dma_b(PAR); advance_b(); }                                            \
+        if (next_) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) { fb[c_][1] = frag_b(1 - PAR, 1, c_); fb[c_][2] = frag_b(1 - PAR, 2, c_); } }   \
+        if ((T) + 2 < nt) {                                                                               \
+            store_op(gt.a[0], gt.a[1], PAR, 0); if (!BIMG) store_op(gt.b[0], gt.b[1], PAR, 3);            \
+            if ((T) + 3 < nt) { request(gt); advance(); }                                                 \
+        }                                                                                                 \
+        CASV_S2_MMA(2, 0)                                                                                 \
+        if (next_) { _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) fa[rb_][2] = frag_a(1 - PAR, 2, rb_); }   \
+        CASV_S2_MMA(1, 0)                                                                                 \
+        if (next_) { _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) fa[rb_][1] = frag_a(1 - PAR, 1, rb_); }   \
+        CASV_S2_MMA(0, 0)                                                                                 \
     }
-    // ---- previous cell state: every wave fetches the 64 rows x 32 units it will need itself, as LDS-DMA under the last stages (into
-    // the area the operand rows were staged through, once the last of them has been read back) ----
+    int t = 0;
+#ifdef CASV_S2_CLOCK
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if constexpr (BIMG) {
+        for (; t + 4 < nt; t += 2) {
+            CASV_S2_TILE_BI(t, 0)
+            CASV_S2_TILE_BI(t + 1, 1)
+        }
+    } else
+    for (; t + 4 < nt; t += 2) {
+        CASV_S2_TILE(t, 0)
+        CASV_S2_TILE(t + 1, 1)
+    }
+
+#ifdef CASV_S2_CLOCK
+    const unsigned long long ph_t2 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        g_s2_clk[0] = __builtin_amdgcn_s_memtime() - ck0; g_s2_clk[1] = ph_t2 - cr0;
+    }
+#endif
+    // ---- previous cell state: every wave fetches the 64 rows x 32 units it will need itself, as LDS-DMA under the last tiles ----
     const bool plain = EPI == EPI_PLAIN || g.epi_plain;
     const bool cfirst = !plain && sgc.first_base && step == 0;
     const bool czero = !plain && sgc.skip_first && step == 0 && !cfirst;
-    char* const cellw = s2_smem + S2_CB + wave * (64 * 128);
-    bool cell_pending = !plain && !czero;
-    auto cell_request = [&]() {
+    char* const cellw = s2_smem + S2_CB + wave * (64 * 128);        // (LDS-DMA destinations beyond 64 KB work too: the -DCASV_S2_CELL_LAST build, cell state at 96..160 KB, passes the same tests)
+    if (!plain && !czero) {
         const float* cin = cfirst ? sgc.first_base : sgc.base + (long long)(step * sgc.step_mul + sgc.step_add) * sgc.slot_stride;
         const bool cgat = sgc.rows && !cfirst;
         int crow[8];
@@ -403,173 +553,66 @@ __global__ __launch_bounds__(512, 1) void gemm_split256_kernel(const GemmBatch b
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         }
-    };
-    // The steady state written out group by group (four products of one column block, or half a row block's eight), a full scheduling
-    // fence behind each: the group, at most one fragment read, and ONE piece of the windows' work -- a transfer, a read-back, half of a
-    // value pair's split (5-6 vector instructions), the stores of a row once its four values are split -- so that the matrix pipe is
-    // fed by this wave alone while its SIMD partner does the same.  As one run behind the barrier the ~100 vector instructions of a
-    // window would leave the pipe idle in both waves at once (they pass the barrier together).
-    f32x4 xa_[4], xb_[4]; unsigned qa_ = 0, qb_ = 0; f32x2 ra_ = {0.f, 0.f}, rb__ = {0.f, 0.f};
-    u32x2 wa0_ = {0u, 0u}, wa1_ = {0u, 0u}, wa2_ = {0u, 0u}, wb0_ = {0u, 0u}, wb1_ = {0u, 0u}, wb2_ = {0u, 0u};
-    u32x2 h2_[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}}, hb_[4] = {u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}};
-    const char* tb0_ = rbi; const char* tb1_ = rbi;
-    auto st_read = [&](int v) { xa_[v] = raw(v); if (!BIMG) xb_[v] = raw(4 + v); };
-    auto st_b = [&](int v, int h) { split_l1(xa_[v], h, qa_, ra_); if (!BIMG) split_l1(xb_[v], h, qb_, rb__); };
-    auto st_c = [&](int v, int h) { split_l23(qa_, ra_, h, wa0_, wa1_, wa2_); if (!BIMG) split_l23(qb_, rb__, h, wb0_, wb1_, wb2_); };
-    auto st_store = [&](int v) {
-        store_plane(wa0_, v >> 1, 0, v & 1); store_plane(wa1_, v >> 1, 1, v & 1); h2_[v] = wa2_;
-        if (!BIMG) { store_plane(wb1_, v >> 1, 4, v & 1); store_plane(wb2_, v >> 1, 5, v & 1); hb_[v] = wb0_; }
-    };
-    // window 1, slot n of 24 (behind the groups of p3, p4, p5)
-    // (kind 0: a stage in the middle; 1: the last but one -- nothing is requested any more, the cell state is; 2: the last -- no windows)
-    auto w1 = [&](int n, const bool steady, const int kind) {
-        if (kind == 2 || (kind == 1 && n >= 18)) return;
-        switch (n) {
-        case 0: if (BIMG) dma_at(tb0_, 0, 2); st_read(0); break;
-        case 1: if (BIMG) dma_at(tb1_, 1, 2); break;
-        case 2: if (BIMG) dma_at(tb0_, 0, 1); st_b(0, 0); break;
-        case 3: if (BIMG) dma_at(tb1_, 1, 1); st_c(0, 0); break;
-        case 4: st_read(1); st_b(0, 1); break;
-        case 5: st_c(0, 1); st_store(0); break;
-        case 6: st_b(1, 0); break;
-        case 7: st_c(1, 0); st_read(2); break;
-        case 8: st_b(1, 1); break;
-        case 9: st_c(1, 1); st_store(1); break;
-        case 10: st_b(2, 0); st_read(3); break;
-        case 11: st_c(2, 0); break;
-        case 12: st_b(2, 1); break;
-        case 13: st_c(2, 1); st_store(2); break;
-        case 14: st_b(3, 0); break;
-        case 15: st_c(3, 0); break;
-        case 16: st_b(3, 1); break;
-        case 17: st_c(3, 1); st_store(3); break;
-        case 18: raw_in(ra0, 0); if (!BIMG) raw_in(reinterpret_cast<const char*>(rb0), 4); break;     // (the read-backs have long returned: their values are split)
-        case 19: raw_in(ra1, 1); if (!BIMG) raw_in(reinterpret_cast<const char*>(rb1), 5);
-                 if (steady) { ra0 += S2_BK * 4; ra1 += S2_BK * 4; rb0 += S2_BK; rb1 += S2_BK; } else advance(); break;
-        case 20: raw_in(ra0, 2); if (!BIMG) raw_in(reinterpret_cast<const char*>(rb0), 6); break;
-        case 21: raw_in(ra1, 3); if (!BIMG) raw_in(reinterpret_cast<const char*>(rb1), 7);
-                 if (steady) { ra0 += S2_BK * 4; ra1 += S2_BK * 4; rb0 += S2_BK; rb1 += S2_BK; } else advance(); break;
-        default: break;
-        }
-    };
-    auto w2 = [&](int n, const int kind) {          // window 2, behind the groups of p6
-        if (kind == 2) return;
-        if (kind == 1 && n == 4 && cell_pending) { cell_request(); cell_pending = false; }      // (every wave has read its last operand rows back)
-        switch (n) {
-        case 0: store_plane(h2_[0], 0, 2, 0); store_plane(h2_[1], 0, 2, 1); if (BIMG) dma_at(tb0_, 0, 0); break;
-        case 1: store_plane(h2_[2], 1, 2, 0); store_plane(h2_[3], 1, 2, 1); if (BIMG) dma_at(tb1_, 1, 0); break;
-        case 2: if (!BIMG) { store_plane(hb_[0], 0, 3, 0); store_plane(hb_[1], 0, 3, 1); } break;
-        case 3: if (!BIMG) { store_plane(hb_[2], 1, 3, 0); store_plane(hb_[3], 1, 3, 1); } break;
-        default: break;
-        }
-    };
-#define CASV_S2_GC(QA, C) _Pragma("unroll") for (int rb_ = 0; rb_ < 4; ++rb_) CASV_S2_PROD(QA[rb_], fb[C], acc16[rb_][C])
-#define CASV_S2_GR(PA, HG) _Pragma("unroll") for (int c_ = 4 * ((HG) & 1); c_ < 4 * ((HG) & 1) + 4; ++c_) CASV_S2_PROD(PA[(HG) >> 1], fb[c_], acc16[(HG) >> 1][c_])
-#define CASV_S2_STAGE_FULL(P, Q, STEADY, KIND)                                                                            \
-    {                                                                                                         \
-        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                          /* p1 */ \
-            CASV_S2_GC(Q, g_) fb[g_] = frag_b(1, g_); if (g_ < 4) P[g_] = frag_a(1, g_); CASV_S2_FENCE }      \
-        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) { CASV_S2_GC(Q, g_) CASV_S2_FENCE }        /* p2 */ \
-        CASV_S2_LANDED                                                                                        \
-        __syncthreads();                                                                            /* X */  \
-        if (KIND == 2) {} else if (STEADY) { tb0_ = rbi; tb1_ = rbi + S2_BIMG_TILE; rbi += 2 * S2_BIMG_TILE; } \
-        else { tb0_ = rbi; advance_b(); tb1_ = rbi; advance_b(); }                                            \
-        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                          /* p3 */ \
-            CASV_S2_GC(P, g_) fb[g_] = frag_b(0, g_); w1(g_, STEADY, KIND); CASV_S2_FENCE }                                 \
-        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                          /* p4 */ \
-            CASV_S2_GR(P, g_) if (g_ & 1) P[g_ >> 1] = frag_a(2, g_ >> 1); w1(8 + g_, STEADY, KIND); CASV_S2_FENCE }        \
-        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) { CASV_S2_GR(P, g_) w1(16 + g_, STEADY, KIND); CASV_S2_FENCE }   /* p5 */ \
-        if (KIND == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
-        else if (KIND == 0 && BIMG) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      /* this wave's four plane transfers of window 1; the four requests behind them stay in flight */ \
-        __syncthreads();                                                                            /* Y */  \
-        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                          /* p6 */ \
-            CASV_S2_GC(Q, g_) if (KIND != 2) { fb[g_] = frag_b(2, g_); if (g_ < 4) P[g_] = frag_a(0, g_); } w2(g_, KIND); CASV_S2_FENCE }   \
     }
-    int s = 0;
-#ifdef CASV_S2_CLOCK
-    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // Steady pairs of stages while the next four requests and the next four image tiles stay inside their K segments (a stage is
-    // ONE basic block: the pointers just step; a stream that has used up its segment is re-based behind the pair); everything else --
-    // a segment that ends inside a pair, the last three stages -- goes through the stage with conditions below, one at a time (it
-    // leaves a0 of the next stage in fY: handed to fX).
-    for (;;) {
-        while (2 * s + 7 < nt && rleft >= 4 && (!BIMG || bleft >= 4)) {
-            CASV_S2_STAGE_FULL(fY, fX, true, 0)
-            CASV_S2_STAGE_FULL(fX, fY, true, 0)
-            s += 2; rleft -= 4; bleft -= 4;
-            if (rleft == 0) cross_a();
-            if (BIMG && bleft == 0) cross_b();
-        }
-        if (2 * s + 4 == nt) {              // exactly two whole stages left: the same code without what reaches beyond the end
-            CASV_S2_STAGE_FULL(fY, fX, false, 1)
-            CASV_S2_STAGE_FULL(fX, fY, false, 2)
-            s += 2;
-        }
-        if (2 * s >= nt) break;
-        CASV_S2_STAGE(s, fY, fX, false)
-        _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) fX[rb] = fY[rb];
-        s += 1;
+    for (; t + 1 < nt; t += 2) {
+        CASV_S2_TAIL(t, 0)
+        CASV_S2_TAIL(t + 1, 1)
     }
-#ifdef CASV_S2_CLOCK
-    const unsigned long long ph_t2 = __builtin_amdgcn_s_memrealtime();
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        g_s2_clk[0] = __builtin_amdgcn_s_memtime() - ck0; g_s2_clk[1] = ph_t2 - cr0;
-    }
-#endif
-
-    if (cell_pending) { __syncthreads(); cell_request(); }
-#undef CASV_S2_STAGE
-#undef CASV_S2_STAGE_FULL
-#undef CASV_S2_GC
-#undef CASV_S2_GR
-#undef CASV_S2_P_COUT
-#undef CASV_S2_P_ROUT
+    if (t < nt) CASV_S2_TAIL(t, 0)
+#undef CASV_S2_TILE
+#undef CASV_S2_TILE_BI
+#undef CASV_S2_TAIL
+#undef CASV_S2_M1
 #undef CASV_S2_FENCE
+#undef CASV_S2_MMA
 #undef CASV_S2_PROD
+#undef CASV_S2_PIN
+    CASV_S2_LANDED(gt);                                  // (pins the staging registers until nothing can be in flight into them)
 #ifdef CASV_S2_CLOCK
     const unsigned long long ph_t3 = __builtin_amdgcn_s_memrealtime();
 #endif
 #undef CASV_S2_LANDED
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the wave's own cell-state transfers (an LDS-DMA must not outlive its workgroup either)
 
-    // ---- epilogue: lane l holds column (l & 15) of a 16-column block and the rows 4 (l >> 4) .. + 3 of a 16-row block ----
-    const int l15 = lane & 15, lq = lane >> 4;
+    // ---- epilogue ----
     if (plain) {
         float* cbase = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
-        float bcol[8];
+        float bcol[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) bcol[c] = g.bias ? g.bias[n0 + wn * 128 + c * 16 + l15] : 0.0f;
+        for (int c = 0; c < 4; ++c) bcol[c] = g.bias ? g.bias[n0 + wn * 128 + c * 32 + l31] : 0.0f;
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            float* cb = cbase + (long long)(m0 + wm * 64 + rb * 16 + 4 * lq) * g.out.ld + n0 + wn * 128 + l15;
+        for (int rb = 0; rb < 2; ++rb) {
+            float* cb = cbase + (long long)(m0 + wm * 64 + rb * 32 + 4 * lh) * g.out.ld + n0 + wn * 128 + l31;
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cb[(long long)j * g.out.ld + c * 16] = acc16[rb][c][j] + bcol[c];
+                for (int r = 0; r < 16; ++r) cb[(long long)((r & 3) + 8 * (r >> 2)) * g.out.ld + c * 32] = acc[rb][c][r] + bcol[c];
         }
         return;
     }
-    const int nb = n0 + wn * 128;                 // this wave's 128 columns: gates i, f, c~, o of 32 units (column block 2 gate + unit half)
+    const int nb = n0 + wn * 128;                 // this wave's 128 columns: gates i, f, c~, o of 32 units
+    const int u = nb / 4 + l31;                   // hidden unit of this lane
+    float bi = 0.f, bf_ = 0.f, bg = 0.f, bo = 0.f;
+    if (g.bias) { bi = g.bias[nb + l31]; bf_ = g.bias[nb + 32 + l31]; bg = g.bias[nb + 64 + l31]; bo = g.bias[nb + 96 + l31]; }
     float* cout = g.c_out.base + (long long)(step * g.c_out.step_mul + g.c_out.step_add) * g.c_out.slot_stride;
     float* hout = g.out.base + (long long)(step * g.out.step_mul + g.out.step_add) * g.out.slot_stride;
 #pragma unroll
-    for (int uh = 0; uh < 2; ++uh) {
-        const int uw = uh * 16 + l15;             // hidden unit of this lane inside the wave's 32
-        float bi = 0.f, bf_ = 0.f, bg = 0.f, bo = 0.f;
-        if (g.bias) { bi = g.bias[nb + uw]; bf_ = g.bias[nb + 32 + uw]; bg = g.bias[nb + 64 + uw]; bo = g.bias[nb + 96 + uw]; }
+    for (int rb = 0; rb < 2; ++rb) {
+        float hv[16], cv[16];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            float* cb = cout + (long long)(m0 + wm * 64 + rb * 16 + 4 * lq) * g.c_out.ld + nb / 4 + uw;
-            float* hb = hout + (long long)(m0 + wm * 64 + rb * 16 + 4 * lq) * g.out.ld + nb / 4 + uw;
+        for (int r = 0; r < 16; ++r) {
+            const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float cprev = czero ? 0.0f : *reinterpret_cast<const float*>(cellw + row * 128 + l31 * 4);
+            const LstmCellOut cell = lstm_cell(acc[rb][0][r] + bi, acc[rb][1][r] + bf_, acc[rb][2][r] + bg, acc[rb][3][r] + bo, cprev);
+            hv[r] = cell.h; cv[r] = cell.c;
+        }
+        float* cb = cout + (long long)(m0 + wm * 64 + rb * 32 + 4 * lh) * g.c_out.ld + u;
+        float* hb = hout + (long long)(m0 + wm * 64 + rb * 32 + 4 * lh) * g.out.ld + u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = rb * 16 + 4 * lq + j;
-                const float cprev = czero ? 0.0f : *reinterpret_cast<const float*>(cellw + row * 128 + uw * 4);
-                const LstmCellOut cell = lstm_cell(acc16[rb][uh][j] + bi, acc16[rb][2 + uh][j] + bf_, acc16[rb][4 + uh][j] + bg, acc16[rb][6 + uh][j] + bo, cprev);
-                cb[(long long)j * g.c_out.ld] = cell.c;
-                hb[(long long)j * g.out.ld] = cell.h;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int dm = (r & 3) + 8 * (r >> 2);
+            cb[(long long)dm * g.c_out.ld] = cv[r];
+            hb[(long long)dm * g.out.ld] = hv[r];
         }
     }
 #ifdef CASV_S2_CLOCK

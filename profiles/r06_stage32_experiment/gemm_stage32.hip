@@ -312,34 +312,31 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     };
     // (staging rows r0 and r0 + 64 share bit 4: one offset serves both)
     const int st_off = r0 * 32 + ((((kc >> 1) ^ (r0 >> 4)) & 1) * 16) + (kc & 1) * 8;
-    auto store_tile_split = [&](const GTile& gt, int buf, const bool opa = true, const bool opb = true) {
-        if (CASV_ABLM & 2) { asm volatile("" :: "v"(gt.a[0]), "v"(gt.a[1]), "v"(gt.b[0]), "v"(gt.b[1])); return; }
-        char* base = reinterpret_cast<char*>(smem + buf * BUF_FLOATS) + st_off;
+    char* const st_base = reinterpret_cast<char*>(smem) + st_off;
+    // plane `plane` (A 0..2, B 3..5) of LDS buffer `buf`, row r0 + 64 i: the thread's 8 bytes
+    auto store_plane = [&](const u32x2 v, int buf, int plane, int i) {
+        *reinterpret_cast<u32x2*>(st_base + buf * (BUF_FLOATS * 4) + plane * SPLIT_PLANE_BYTES + i * 64 * 32) = v;
+    };
+    auto store_tile_split = [&](const GTile& gt, int buf) {          // all six planes of a K tile (prologue)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             u32x2 p0, p1, p2;
-            if (opa) {
-                split4(gt.a[i], p0, p1, p2, false);
-                *reinterpret_cast<u32x2*>(base + i * 64 * 32) = p0;
-                *reinterpret_cast<u32x2*>(base + SPLIT_PLANE_BYTES + i * 64 * 32) = p1;
-                *reinterpret_cast<u32x2*>(base + 2 * SPLIT_PLANE_BYTES + i * 64 * 32) = p2;
-            }
-            if (opb) {
-                split4(gt.b[i], p0, p1, p2, true);
-                *reinterpret_cast<u32x2*>(base + 3 * SPLIT_PLANE_BYTES + i * 64 * 32) = p0;
-                *reinterpret_cast<u32x2*>(base + 4 * SPLIT_PLANE_BYTES + i * 64 * 32) = p1;
-                *reinterpret_cast<u32x2*>(base + 5 * SPLIT_PLANE_BYTES + i * 64 * 32) = p2;
-            }
+            split4(gt.a[i], p0, p1, p2, false);
+            store_plane(p0, buf, 0, i); store_plane(p1, buf, 1, i); store_plane(p2, buf, 2, i);
+            split4(gt.b[i], p0, p1, p2, true);
+            store_plane(p0, buf, 3, i); store_plane(p1, buf, 4, i); store_plane(p2, buf, 5, i);
         }
     };
-    // a lane's 8 k of its row: the 16-byte half lh (k = 8 lh .. 8 lh + 7, the same for both operands)
-    const int fr_off = l31 * 32 + (((lh ^ (l31 >> 4)) & 1) * 16);
-    auto frag_a = [&](int buf, int plane) {
-        return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(smem + buf * BUF_FLOATS) + plane * SPLIT_PLANE_BYTES + wave * 32 * 32 + fr_off);
+    auto zero_tile_split = [&](int buf, int plane0, int nplanes) {   // a stage's missing second K tile: zeros in both operands
+        for (int p = plane0; p < plane0 + nplanes; ++p) { store_plane(u32x2{0u, 0u}, buf, p, 0); store_plane(u32x2{0u, 0u}, buf, p, 1); }
     };
-    auto frag_b = [&](int buf, int plane, int c) {
-        return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(smem + buf * BUF_FLOATS) + (3 + plane) * SPLIT_PLANE_BYTES + c * 32 * 32 + fr_off);
-    };
+    // Fragments of the 32-deep instruction (gemm_split.hip): lane l holds row (l & 15) of its 16-row block and the stage's
+    // k 8 (l >> 4) .. + 7 -- 16-byte piece (l >> 4) & 1 of K tile l >> 5, i.e. of LDS buffer l >> 5; pieces swapped in odd blocks
+    const int fr_lane = (lane >> 5) * (BUF_FLOATS * 4) + (lane & 15) * 32;
+    const char* const fr_e = reinterpret_cast<const char*>(smem) + fr_lane + ((lane >> 4) & 1) * 16;
+    const char* const fr_o = reinterpret_cast<const char*>(smem) + fr_lane + (((lane >> 4) & 1) ^ 1) * 16;
+    auto frag_a = [&](int plane, int rb) { return *reinterpret_cast<const bf16x8*>(((rb & 1) ? fr_o : fr_e) + plane * SPLIT_PLANE_BYTES + (wave * 32 + rb * 16) * 32); };
+    auto frag_b = [&](int plane, int c) { return *reinterpret_cast<const bf16x8*>(((c & 1) ? fr_o : fr_e) + (3 + plane) * SPLIT_PLANE_BYTES + c * 16 * 32); };
     const int a_off = (wave * 32 + l31) * LDW + 4 * lh;
     const int b_off = TILE_FLOATS + l31 * LDW + 4 * lh;
     struct Frag { f32x4 a[2]; f32x4 b[4][2]; };
@@ -391,6 +388,106 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 #ifdef CASV_GEMM_PROF
     CASV_STAMP(pb)
 #endif
+    // SPLIT: the stage pipeline of gemm_split.hip (two K tiles per stage, k 0..15 from buffer 0 and k 16..31 from buffer 1; six products
+    // of v_mfma_f32_16x16x32_bf16 per 16x16 block: a0.b2, a0.b1 | X | a1.b1, a1.b0, a2.b0 | Y | a0.b0; a plane's place in LDS refilled in
+    // place with the next stage's once every wave has read it: b2, a0, b1, a1 behind X, b0, a2 behind Y) on this kernel's 128x128 tile --
+    // a wave 32 rows x 128 columns, operands through registers -- so that an element's sum is the same instruction sequence in both
+    // kernels (same bits).  Written with conditions throughout (any tile count, ragged tiles); the compiler schedules it.
+    const bool c_late = !SPLIT && EPI == EPI_LSTM && KS == 1 && nt_min > 5;
+    if constexpr (SPLIT) {
+        f32x4 acc16[2][8];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc16[rb][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        bf16x8 fb[8], fP[2], fQ[2];
+        GTile gt0, gt1;
+        if (ntiles > 0) load_tile(gt0, 0);
+        if (ntiles > 1) load_tile(gt1, 1);
+        if (cstage) {           // the previous cell state into its LDS image (its area is not part of the K loop): requested with the first tiles
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<f32x4*>(cs + (j * 128 + r0 + 64 * i) * 16 + 4 * kc) = *reinterpret_cast<const f32x4*>(cptr(i) + 16 * j);
+        }
+        if (ntiles > 0) store_tile_split(gt0, 0);
+        if (ntiles > 1) store_tile_split(gt1, 1); else if (ntiles > 0) zero_tile_split(1, 0, 6);
+        if (ntiles > 2) load_tile(gt0, 2);
+        if (ntiles > 3) load_tile(gt1, 3);
+        __syncthreads();
+        if (ntiles > 0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) fb[c] = frag_b(2, c);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) fQ[rb] = frag_a(0, rb);
+        }
+#define CASV_SPLIT_PROD(PA, RB, C) acc16[RB][C] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA[RB], fb[C], acc16[RB][C], 0, 0, 0);
+#define CASV_SPLIT_COUT(PA, ROLL) _Pragma("unroll") for (int c_ = 0; c_ < 8; ++c_) { _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) CASV_SPLIT_PROD(PA, rb_, c_) ROLL }
+#define CASV_SPLIT_ROUT(PA, ROLL) _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) { _Pragma("unroll") for (int c_ = 0; c_ < 8; ++c_) CASV_SPLIT_PROD(PA, rb_, c_) ROLL }
+        for (int s = 0; 2 * s < ntiles; ++s) {
+            const bool next = 2 * s + 2 < ntiles, next1 = 2 * s + 3 < ntiles;
+            u32x2 ha[4], hb[4];                                                                 // a2', b0' of the next stage until window 2
+            CASV_SPLIT_COUT(fQ, { fb[c_] = frag_b(1, c_); if (c_ < 2) fP[c_] = frag_a(1, c_); })   // p1 a0.b2
+            CASV_SPLIT_COUT(fQ, {})                                                                // p2 a0.b1
+            __syncthreads();                                                                    // X
+            if (next) {                                                                         // window 1
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    u32x2 p0, p1, p2;
+                    split4(gt0.a[i], p0, p1, p2, false); store_plane(p0, 0, 0, i); store_plane(p1, 0, 1, i); ha[i] = p2;
+                    split4(gt0.b[i], p0, p1, p2, true); store_plane(p1, 0, 4, i); store_plane(p2, 0, 5, i); hb[i] = p0;
+                }
+                if (next1) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        u32x2 p0, p1, p2;
+                        split4(gt1.a[i], p0, p1, p2, false); store_plane(p0, 1, 0, i); store_plane(p1, 1, 1, i); ha[2 + i] = p2;
+                        split4(gt1.b[i], p0, p1, p2, true); store_plane(p1, 1, 4, i); store_plane(p2, 1, 5, i); hb[2 + i] = p0;
+                    }
+                } else { zero_tile_split(1, 0, 2); zero_tile_split(1, 4, 2); }
+                if (2 * s + 4 < ntiles) load_tile(gt0, 2 * s + 4);
+                if (2 * s + 5 < ntiles) load_tile(gt1, 2 * s + 5);
+            }
+            CASV_SPLIT_COUT(fP, { fb[c_] = frag_b(0, c_); })                                       // p3 a1.b1
+            CASV_SPLIT_ROUT(fP, { fP[rb_] = frag_a(2, rb_); })                                     // p4 a1.b0
+            CASV_SPLIT_ROUT(fP, {})                                                                // p5 a2.b0
+            __syncthreads();                                                                    // Y
+            if (next) {                                                                         // window 2
+                store_plane(ha[0], 0, 2, 0); store_plane(ha[1], 0, 2, 1); store_plane(hb[0], 0, 3, 0); store_plane(hb[1], 0, 3, 1);
+                if (next1) { store_plane(ha[2], 1, 2, 0); store_plane(ha[3], 1, 2, 1); store_plane(hb[2], 1, 3, 0); store_plane(hb[3], 1, 3, 1); }
+                else zero_tile_split(1, 2, 2);
+            }
+            CASV_SPLIT_COUT(fQ, { if (next) { fb[c_] = frag_b(2, c_); if (c_ < 2) fP[c_] = frag_a(0, c_); } })   // p6 a0.b0
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) fQ[rb] = fP[rb];
+        }
+#undef CASV_SPLIT_COUT
+#undef CASV_SPLIT_ROUT
+#undef CASV_SPLIT_PROD
+        // the accumulators as 32x32 blocks (the layout the epilogue is written for: lane l holds column l & 31 and the rows
+        // 4 (l >> 5) + (r & 3) + 8 (r >> 2)) through a private 4.5-KB piece of the tile buffers: the four 16x16 blocks of a 32x32 one are
+        // written column by column (a lane's four consecutive rows: one 16-byte store; 36-float columns: conflict-free), read back as
+        // four 16-byte pieces per lane
+        __syncthreads();
+        {
+            float* const cv = smem + wave * (32 * 36);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                    for (int bj = 0; bj < 2; ++bj)
+                        *reinterpret_cast<f32x4*>(cv + (16 * bj + (lane & 15)) * 36 + 16 * bi + 4 * (lane >> 4)) = acc16[bi][2 * c + bj];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(cv + l31 * 36 + 4 * lh + 8 * m);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[c][4 * m + j] = v[j];
+                }
+            }
+        }
+    } else {
     Frag f0, f1;
     GTile g0, g1;
     // prologue: LDS[0] <- tile 0, LDS[1] <- tile 1, F0 <- LDS[0]; G0 <- tile 2, G1 <- tile 3
@@ -402,60 +499,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
 #ifdef CASV_GEMM_PROF
     CASV_STAMP(pc)
 #endif
-    if constexpr (SPLIT) {
-        if (ntiles > 0) store_tile_split(g0, 0);
-        if (ntiles > 1) store_tile_split(g1, 1);
-    } else {
-        if (ntiles > 0) store_tile(g0, 0);
-        if (ntiles > 1) store_tile(g1, 1);
-    }
-    // SPLIT: rolling fragment registers -- B planes [block][plane], A plane 0 double-buffered (it serves a tile's first and last product)
-    bf16x8 sb[4][3], sa0x, sa0y, sa1, sa2;
-    auto split_first_frags = [&]() {            // what a tile expects to find in registers: B planes 2 and 1, all of A (tile 0, buffer 0)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { sb[c][2] = frag_b(0, 2, c); sb[c][1] = frag_b(0, 1, c); }
-        sa0x = frag_a(0, 0); sa1 = frag_a(0, 1); sa2 = frag_a(0, 2);
-    };
-#define CASV_SPLIT_MMA(A, P)                                                              \
-    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                      \
-        acc[c_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, sb[c_][P], acc[c_], 0, 0, 0);
-    // (scheduling fence that vector arithmetic may cross -- the split's arithmetic finds its own place between the
-    // products -- while matrix, LDS and memory instructions stay on their side: left to itself the compiler issues a plane's
-    // fragment reads two products ahead of their first use and every tile waits for the LDS twice)
-#define CASV_SPLIT_PIN __builtin_amdgcn_sched_barrier(0x2);
-    // One K tile of the SPLIT variant.  FULL: steady state (tiles KT+1..KT+4 exist, hidden loads, no conditionals).
-#define CASV_SPLIT_TILE(AC, AN, G, KT, FULL)                                              \
-    {                                                                                     \
-        const bool have_ = FULL || (KT) < ntiles, next_ = FULL || (KT) + 1 < ntiles;      \
-        const bool reads_ = !(FULL && (CASV_ABLM & 16)), loads_ = !(CASV_ABLM & 4);       \
-        if (FULL && loads_) asm volatile("s_waitcnt vmcnt(4)" : "+v"(G.a[0]), "+v"(G.a[1]), "+v"(G.b[0]), "+v"(G.b[1]));  \
-        if (have_) {                                                                      \
-            if (reads_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) sb[c_][0] = frag_b((KT) & 1, 0, c_);   \
-            if (FULL) CASV_SPLIT_PIN                                                      \
-            CASV_SPLIT_MMA(sa1, 1) CASV_SPLIT_MMA(AC, 2) CASV_SPLIT_MMA(AC, 1)    /* (the product order of gemm_split.hip: same bits) */ \
-        }                                                                                 \
-        if (FULL) CASV_SPLIT_PIN        /* the 12 products stay in front of the barrier: plane 0's reads land under them */ \
-        if (!(FULL && (CASV_ABLM & 8))) __syncthreads();                                  \
-        if (next_ && reads_) {                                                            \
-            _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) { sb[c_][2] = frag_b(((KT) + 1) & 1, 2, c_); sb[c_][1] = frag_b(((KT) + 1) & 1, 1, c_); }  \
-            AN = frag_a(((KT) + 1) & 1, 0);                                               \
-        }                                                                                 \
-        if (FULL) CASV_SPLIT_PIN                                                          \
-        if (have_) CASV_SPLIT_MMA(sa2, 0)                                                 \
-        if (FULL) CASV_SPLIT_PIN                                                          \
-        if (next_ && reads_) sa2 = frag_a(((KT) + 1) & 1, 2);                             \
-        if (FULL || (KT) + 2 < ntiles) store_tile_split(G, (KT) & 1, true, false);        \
-        if (FULL) CASV_SPLIT_PIN                                                          \
-        if (have_) CASV_SPLIT_MMA(sa1, 0)                                                 \
-        if (FULL) CASV_SPLIT_PIN                                                          \
-        if (next_ && reads_) sa1 = frag_a(((KT) + 1) & 1, 1);                             \
-        if (FULL || (KT) + 2 < ntiles) store_tile_split(G, (KT) & 1, false, true);        \
-        if (FULL) { if (loads_) load_tile_run(G); } else if ((KT) + 4 < ntiles) load_tile_run_plain(G);   \
-        if (FULL) CASV_SPLIT_PIN                                                          \
-        if (have_) CASV_SPLIT_MMA(AC, 0)                                                  \
-        if (FULL) run_advance();                                                          \
-    }
-
+    if (ntiles > 0) store_tile(g0, 0);
+    if (ntiles > 1) store_tile(g1, 1);
     // Steady state (tiles kt+1..kt+4 exist, no conditionals): while the 32 MFMAs of tile kt issue from FC,
     //   LDS[kt&1] <- G (tile kt+2, requested two steps ago; the buffer's old content, tile kt, sits in FC)
     //   G <- global tile kt+4 ;  FN <- LDS[(kt+1)&1]
@@ -491,7 +536,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
     int kt = 0;
     // (hidden transfers in flight across the tail below are older than anything the tail requests itself -- an odd tile count
     // requests one more tile there --, so the compiler's counted waits for its own loads stay correct: they only wait longer)
-    const bool c_late = EPI == EPI_LSTM && KS == 1 && nt_min > 5;
     if (nt_min > 5) {
         // Tiles 2 and 3 are requested the hidden way already: a compiler-tracked load pending on ANY path into the loop would
         // put a full vmcnt(0) at the loop head, executed in every iteration.  (The cell-state loads above are older than
@@ -518,7 +562,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
             issue_tile_asm(g0, qa0, qa1, qb0, qb1); issue_tile_asm(g1, ra0, ra1, rb0, rb1);
         }
         __syncthreads();
-        if constexpr (SPLIT) split_first_frags(); else read_frags(f0, 0);
+        read_frags(f0, 0);
         // The first steady-state step stores tile 2 into LDS buffer 0: every wave must have taken its fragments of tile 0
         // out of it first.  (Without this barrier only the latency of the tile-2 global loads kept a fast wave's store
         // behind a slow wave's read -- not enough once other kernels share the CU.)
@@ -527,12 +571,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime();
 #endif
         if (KS == 1) run_set(4);                    // the first steady-state tile requests tile 4
-        if constexpr (SPLIT) {
-            for (; kt + 5 < nt_min; kt += 2) {
-                CASV_SPLIT_TILE(sa0x, sa0y, g0, kt, true)
-                CASV_SPLIT_TILE(sa0y, sa0x, g1, kt + 1, true)
-            }
-        } else
         for (; kt + 5 < nt_min; kt += 2) {          // both wave groups have all the tiles of the steady state
             CASV_TILE_FULL(f0, f1, g0, kt)
             CASV_TILE_FULL(f1, f0, g1, kt + 1)
@@ -558,7 +596,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
         if (ntiles > 3) load_tile(g1, 3);
         if (KS == 1 && ntiles > 4) run_set(4);
         __syncthreads();
-        if constexpr (SPLIT) { if (ntiles > 0) split_first_frags(); } else { if (ntiles > 0) read_frags(f0, 0); }
+        if (ntiles > 0) read_frags(f0, 0);
         __syncthreads();
     }
     if (cstage && !c_late) {        // (short K, odd tile counts, wave-group split-K: through registers, stored into the same image)
@@ -568,25 +606,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bm, const
             for (int j = 0; j < 2; ++j)
                 *reinterpret_cast<f32x4*>(cs + (j * 128 + r0 + 64 * i) * 16 + 4 * kc) = *reinterpret_cast<const f32x4*>(cptr(i) + 16 * j);
     }
-    if constexpr (SPLIT) {
-        for (; kt + 1 < nt_max; kt += 2) {
-            CASV_SPLIT_TILE(sa0x, sa0y, g0, kt, false)
-            CASV_SPLIT_TILE(sa0y, sa0x, g1, kt + 1, false)
-        }
-        if (kt < nt_max) CASV_SPLIT_TILE(sa0x, sa0y, g0, kt, false)
-    } else {
+    {
     for (; kt + 1 < nt_max; kt += 2) {          // same barrier count for both groups
         CASV_TILE_STEP(f0, f1, g0, kt)
         CASV_TILE_STEP(f1, f0, g1, kt + 1)
     }
     if (kt < nt_max) CASV_TILE_STEP(f0, f1, g0, kt)
     }
-#undef CASV_SPLIT_TILE
-#undef CASV_SPLIT_PIN
-#undef CASV_SPLIT_MMA
 #undef CASV_TILE_STEP
 #undef CASV_TILE_FULL
 
+    }
 #ifdef CASV_GEMM_PROF
     pe = __builtin_amdgcn_s_memtime();
 #endif
